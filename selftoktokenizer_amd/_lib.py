@@ -1,0 +1,53 @@
+"""ctypes loader for libselftok_hip.so (the C ABI of include/selftok_hip.h).
+
+No fallback: if the library is missing or a symbol is absent this raises -- the product path must
+fail loudly rather than silently run something else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libselftok_hip.so")
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol declared in include/selftok_hip.h
+SIGNATURES = {
+    "selftok_version": (_i, []),
+    "selftok_last_error": (C.c_char_p, []),
+    "selftok_vq_workspace_bytes": (_sz, [_i, _i]),
+    "selftok_vq_encode_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "selftok_vq_pack_codebook": (_i, [_vp, _vp, _i, _i, _vp]),
+    "selftok_vq_encode_packed_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "selftok_code_gather_ln_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+}
+
+_lib = None
+
+
+class SelftokHipError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SelftokHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().selftok_last_error().decode("utf-8", "replace")
+        raise SelftokHipError(f"{what} failed (rc={rc}): {msg}")

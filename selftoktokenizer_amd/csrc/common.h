@@ -1,0 +1,44 @@
+// Shared helpers for the Selftok gfx950 kernels.  CDNA4 only: wave64, no portability shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SELFTOK_OK 0
+#define SELFTOK_EINVAL (-1)
+#define SELFTOK_EHIP (-2)
+
+#define WAVE 64
+
+namespace selftok {
+
+void set_last_error(const char* msg);
+int check_launch(const char* what);
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// monotone map float -> uint32 for every non-NaN value (after -0 -> +0 canonicalisation by the caller)
+__device__ __forceinline__ uint32_t f32_orderable(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_orderable(uint32_t k)
+{
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+}  // namespace selftok

@@ -1,0 +1,468 @@
+// Selftok VQ nearest-code lookup for gfx950 (MI355X).
+//
+// Replaces, on device, the eval path of the reference's
+//   VectorQuantize.forward -> l2norm -> CosineSimCodebook.forward
+//   (mimogpt/models/selftok/vector_quantize_pytorch.py:854, 561, 125-143)
+// i.e. ids[n] = argmax_c <l2norm(z[n]), codebook[c]>, WITHOUT materialising the [N,C] score
+// matrix or the two [N,C] one-hot tensors the reference builds (:561, :136, :969).
+//
+// Bit-exactness contract (checked against oracle/selftok_oracle.c, which is pinned to the
+// reference on torch-CPU):
+//   * l2norm: a_j = fma(z[j+8],z[j+8], z[j]*z[j]) (j<8), s = ((a0+a1)+...)+a7,
+//             x = z / max(sqrt(s), 1e-12) with correctly rounded sqrt and divide;
+//   * score : s = 0; for k in 0..15: s = fma(x[k], e[k], s)   (k-ordered fp32 FMA chain);
+//   * argmax: first maximal index; a NaN score is the maximum and the first NaN wins.
+// Two kernels implement the same arithmetic:
+//   vq_valu_kernel : fp32 VALU.  Code tiles are staged coalesced HBM->LDS, each lane keeps 4
+//                    whole codes in registers, the wave's rows are read as LDS broadcasts, every
+//                    lane keeps a running (best,idx) per row and the 64 lanes are combined with a
+//                    wave-shuffle reduction at the end.
+//   vq_mfma_kernel : v_mfma_f32_32x32x2_f32.  On gfx950 the fp32-input MFMA is bit-for-bit the
+//                    same k-ordered FMA chain at the fp32 vector rate, which frees the VALU for the
+//                    argmax bookkeeping (~2x the VALU kernel).  Needs the codebook re-laid once
+//                    into MFMA fragment order (vq_pack_kernel).
+// Both write one 64-bit key per (code-split, row): (orderable(best) << 32) | ~idx, so that an
+// unsigned max picks the larger score and, on ties, the lower index.  vq_finalize_kernel
+// reduces the splits and emits ids (int64, the reference's dtype, or int32) and the top-1 score.
+//
+// This file is compiled with -ffp-contract=off: every FMA below is explicit.
+#include "common.h"
+
+namespace selftok {
+
+constexpr int D = 16;
+constexpr uint32_t KEY_NAN = 0xFFFFFFFFu;
+
+struct Best {
+    float v;    // running best score; +inf once the best is a NaN
+    int i;      // its code index
+    bool nan;   // best is NaN (first NaN wins; never updated afterwards)
+};
+
+__device__ __forceinline__ void best_init(Best& b, int first_idx)
+{
+    b.v = -__builtin_inff();
+    b.i = first_idx;
+    b.nan = false;
+}
+
+// hot-path update: valid when the score is known to be non-NaN or the row state is already NaN
+__device__ __forceinline__ void best_upd_fast(Best& b, float s, int idx)
+{
+    bool g = s > b.v;
+    b.v = g ? s : b.v;
+    b.i = g ? idx : b.i;
+}
+
+// exact update incl. NaN ("NaN is the maximum, first NaN wins" == torch.argmax on CPU)
+__device__ __forceinline__ void best_upd_exact(Best& b, float s, int idx)
+{
+    if (!b.nan) {
+        if (s != s) { b.nan = true; b.v = __builtin_inff(); b.i = idx; }
+        else if (s > b.v) { b.v = s; b.i = idx; }
+    }
+}
+
+__device__ __forceinline__ unsigned long long best_key(const Best& b)
+{
+    float v = b.v;
+    if (v == 0.0f) v = 0.0f;  // -0 -> +0: torch treats them as equal, the lower index must win
+    uint32_t hi = b.nan ? KEY_NAN : f32_orderable(v);
+    return ((unsigned long long)hi << 32) | (uint32_t)(~(uint32_t)b.i);
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long k, int o)
+{
+    uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+    lo = __shfl_xor(lo, o, WAVE);
+    hi = __shfl_xor(hi, o, WAVE);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// canonical l2norm of one 16-float row (see header)
+__device__ __forceinline__ void l2norm16(const float (&z)[D], float (&x)[D])
+{
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = __builtin_fmaf(z[j + 8], z[j + 8], z[j] * z[j]);
+    float s = a[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) s = s + a[j];
+    float nrm = __builtin_sqrtf(s);   // correctly rounded (refined v_sqrt); __fsqrt_rn is the raw 1-ulp v_sqrt_f32 on gfx950
+    nrm = (nrm > 1e-12f) ? nrm : 1e-12f;
+    if (s != s) nrm = s;
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = z[k] / nrm;   // IEEE divide (div_scale/div_fmas/div_fixup)
+}
+
+__device__ __forceinline__ void load_row16(const float* __restrict__ p, float (&z)[D])
+{
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 t = p4[q];
+        z[4 * q + 0] = t.x; z[4 * q + 1] = t.y; z[4 * q + 2] = t.z; z[4 * q + 3] = t.w;
+    }
+}
+
+// a value that can make a score non-finite: NaN/inf or absurdly large
+__device__ __forceinline__ bool suspicious(float v) { return !(fabsf(v) < 1.0e18f); }
+
+// ---------------------------------------------------------------------------------------
+// VALU kernel
+// ---------------------------------------------------------------------------------------
+constexpr int V_ROWS = 16;             // rows per wave
+constexpr int V_CL = 4;                // codes per lane per tile
+constexpr int V_TILE = WAVE * V_CL;    // 256 codes per tile
+constexpr int V_STRIDE = 20;           // padded LDS row stride (floats): 80 B keeps 16-B alignment, spreads banks
+
+__global__ __launch_bounds__(256) void vq_valu_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                      unsigned long long* __restrict__ partial, int N, int C,
+                                                      int tiles_per_split, int normalize)
+{
+    __shared__ __attribute__((aligned(16))) float s_code[2][V_TILE * V_STRIDE];   // 2 x 20 KB
+    __shared__ __attribute__((aligned(16))) float s_x[4][V_ROWS * D];             // 4 KB
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = (blockIdx.x * 4 + wave) * V_ROWS;
+
+    // ---- rows of this wave: lanes 0..15 normalise one row each into LDS ----
+    bool xbad = false;
+    if (lane < V_ROWS) {
+        float zz[D], xx[D];
+        int r = row0 + lane;
+        if (r < N) load_row16(z + (size_t)r * D, zz);
+        else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) zz[k] = 0.f;
+        }
+        if (normalize) l2norm16(zz, xx);
+        else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) xx[k] = zz[k];
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) { s_x[wave][lane * D + k] = xx[k]; xbad |= suspicious(xx[k]); }
+    }
+    const bool wave_xbad = __any(xbad);
+
+    Best best[V_ROWS];
+    const int tile_first = blockIdx.y * tiles_per_split;
+    const int ntiles_total = (C + V_TILE - 1) / V_TILE;
+    int tile_last = tile_first + tiles_per_split;
+    if (tile_last > ntiles_total) tile_last = ntiles_total;
+#pragma unroll
+    for (int r = 0; r < V_ROWS; ++r) best_init(best[r], tile_first * V_TILE);
+
+    // stage one tile (256 codes x 16 floats = 1024 float4) coalesced: 4 float4 per thread
+    auto stage = [&](int tile, int buf) {
+        const float4* src = reinterpret_cast<const float4*>(cb) + (size_t)tile * V_TILE * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int f4 = q * 256 + tid;           // float4 index inside the tile
+            int code = f4 >> 2, part = f4 & 3;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tile * V_TILE + code < C) v = src[f4];
+            *reinterpret_cast<float4*>(&s_code[buf][code * V_STRIDE + part * 4]) = v;
+        }
+    };
+
+    if (tile_first < tile_last) stage(tile_first, 0);
+    __syncthreads();
+
+    for (int tile = tile_first; tile < tile_last; ++tile) {
+        const int buf = (tile - tile_first) & 1;
+        if (tile + 1 < tile_last) stage(tile + 1, buf ^ 1);
+
+        // my 4 codes -> registers
+        float e[V_CL][D];
+        bool ebad = false;
+#pragma unroll
+        for (int c = 0; c < V_CL; ++c) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 t = *reinterpret_cast<const float4*>(&s_code[buf][(lane * V_CL + c) * V_STRIDE + q * 4]);
+                e[c][4 * q + 0] = t.x; e[c][4 * q + 1] = t.y; e[c][4 * q + 2] = t.z; e[c][4 * q + 3] = t.w;
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) ebad |= suspicious(e[c][k]);
+        }
+        const int code0 = tile * V_TILE + lane * V_CL;
+        const bool slow = wave_xbad || __any(ebad);
+        const bool tail = (tile + 1) * V_TILE > C;
+
+#pragma unroll
+        for (int r = 0; r < V_ROWS; ++r) {
+            float x[D];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 t = *reinterpret_cast<const float4*>(&s_x[wave][r * D + q * 4]);   // LDS broadcast
+                x[4 * q + 0] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+            }
+            float s[V_CL];
+#pragma unroll
+            for (int c = 0; c < V_CL; ++c) s[c] = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+#pragma unroll
+                for (int c = 0; c < V_CL; ++c) s[c] = __builtin_fmaf(x[k], e[c][k], s[c]);
+            if (!slow && !tail) {
+#pragma unroll
+                for (int c = 0; c < V_CL; ++c) best_upd_fast(best[r], s[c], code0 + c);
+            } else {
+#pragma unroll
+                for (int c = 0; c < V_CL; ++c)
+                    if (code0 + c < C) best_upd_exact(best[r], s[c], code0 + c);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- wave-shuffle reduction of the 64 per-lane candidates of every row ----
+#pragma unroll
+    for (int r = 0; r < V_ROWS; ++r) {
+        unsigned long long k = best_key(best[r]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            unsigned long long other = shfl_xor_u64(k, o);
+            k = other > k ? other : k;
+        }
+        if (lane == 0 && row0 + r < N) partial[(size_t)blockIdx.y * N + row0 + r] = k;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// MFMA kernel
+// ---------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// packed layout: tile t (32 codes) = 512 floats; lane l = (h = l>>5, i = l&31) owns 8 consecutive
+// floats e[t*32+i][2m+h], m = 0..7  -- exactly the A fragments of the 8 chained 32x32x2 MFMAs.
+__global__ void vq_pack_kernel(const float* __restrict__ cb, float* __restrict__ packed, int C)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (code, k)
+    if (g >= C * D) return;
+    int c = g >> 4, k = g & 15;
+    int t = c >> 5, i = c & 31, h = k & 1, m = k >> 1;
+    packed[(size_t)t * 512 + (h * 32 + i) * 8 + m] = cb[g];
+}
+
+template <int RT>
+__global__ __launch_bounds__(256) void vq_mfma_kernel(const float* __restrict__ z, const float* __restrict__ packed,
+                                                      unsigned long long* __restrict__ partial, int N, int C,
+                                                      int tiles_per_split, int normalize)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int row0 = (blockIdx.x * 4 + wave) * 32 * RT;
+
+    // B operands: B[k][j] = x[row j][k]; lane (half, col) holds k = 2m + half of row col
+    float b[RT][8];
+    bool xbad = false;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        float zz[D], xx[D];
+        int r = row0 + t * 32 + col;
+        if (r < N) load_row16(z + (size_t)r * D, zz);
+        else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) zz[k] = 0.f;
+        }
+        if (normalize) l2norm16(zz, xx);
+        else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) xx[k] = zz[k];
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) xbad |= suspicious(xx[k]);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) b[t][m] = half ? xx[2 * m + 1] : xx[2 * m];
+    }
+    const bool wave_xbad = __any(xbad);
+
+    const int ntiles_total = C >> 5;
+    const int tile_first = blockIdx.y * tiles_per_split;
+    int tile_last = tile_first + tiles_per_split;
+    if (tile_last > ntiles_total) tile_last = ntiles_total;
+
+    Best best[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) best_init(best[t], tile_first * 32 + 4 * half);
+
+    const float4* ap = reinterpret_cast<const float4*>(packed) + (size_t)tile_first * 128 + lane * 2;
+    float4 a_lo = make_float4(0, 0, 0, 0), a_hi = a_lo;
+    if (tile_first < tile_last) { a_lo = ap[0]; a_hi = ap[1]; }
+
+    for (int tile = tile_first; tile < tile_last; ++tile) {
+        float a[8] = {a_lo.x, a_lo.y, a_lo.z, a_lo.w, a_hi.x, a_hi.y, a_hi.z, a_hi.w};
+        // prefetch next tile's A fragments
+        ap += 128;
+        if (tile + 1 < tile_last) { a_lo = ap[0]; a_hi = ap[1]; }
+        bool ebad = false;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) ebad |= suspicious(a[m]);
+        const bool slow = wave_xbad || __any(ebad);
+        const int code_base = tile * 32 + 4 * half;
+
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < 8; ++m)   // k = 2m (lanes 0-31), 2m+1 (lanes 32-63): k-ordered chain
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[t][m], acc, 0, 0, 0);
+            // acc[r] = score(code = tile*32 + (r&3) + 8*(r>>2) + 4*half, row = col); increasing in r
+            if (!slow) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) best_upd_fast(best[t], acc[r], code_base + (r & 3) + 8 * (r >> 2));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) best_upd_exact(best[t], acc[r], code_base + (r & 3) + 8 * (r >> 2));
+            }
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        unsigned long long k = best_key(best[t]);
+        unsigned long long other = shfl_xor_u64(k, 32);   // the other half holds the other 16 codes of each tile
+        k = other > k ? other : k;
+        int r = row0 + t * 32 + col;
+        if (half == 0 && r < N) partial[(size_t)blockIdx.y * N + r] = k;
+    }
+}
+
+template <typename IdT>
+__global__ void vq_finalize_kernel(const unsigned long long* __restrict__ partial, IdT* __restrict__ ids,
+                                   float* __restrict__ best, int N, int nsplit)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    unsigned long long k = partial[r];
+    for (int s = 1; s < nsplit; ++s) {
+        unsigned long long o = partial[(size_t)s * N + r];
+        k = o > k ? o : k;
+    }
+    uint32_t hi = (uint32_t)(k >> 32);
+    ids[r] = (IdT)(~(uint32_t)k);
+    if (best) best[r] = (hi == KEY_NAN) ? __uint_as_float(0x7FC00000u) : f32_from_orderable(hi);
+}
+
+// codes = codebook[ids]  (reference get_codes_from_indices, vector_quantize_pytorch.py:787-794) fused with
+// final_layer_norm3 = LayerNorm(16, eps=1e-6, affine) (models_ours.py:88,241; SelftokPipeline.py:239-240).
+// One thread per token; ln_w == nullptr -> plain gather.
+template <typename IdT>
+__global__ void code_gather_ln_kernel(const IdT* __restrict__ ids, const float* __restrict__ cb, const float* __restrict__ ln_w,
+                                      const float* __restrict__ ln_b, float* __restrict__ out, int n, int C, float eps)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    long long id = (long long)ids[r];
+    if (id < 0) id += C;                       // torch indexing semantics for negative ids
+    id = id < 0 ? 0 : (id >= C ? C - 1 : id);  // never read out of bounds
+    float v[D];
+    load_row16(cb + (size_t)id * D, v);
+    if (ln_w) {
+        float mean = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) mean += v[k];
+        mean *= (1.0f / D);
+        float var = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { float d = v[k] - mean; var = __builtin_fmaf(d, d, var); }
+        var *= (1.0f / D);
+        float rstd = 1.0f / __builtin_sqrtf(var + eps);
+#pragma unroll
+        for (int k = 0; k < D; ++k) v[k] = (v[k] - mean) * rstd * ln_w[k] + ln_b[k];
+    }
+    float4* o4 = reinterpret_cast<float4*>(out + (size_t)r * D);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o4[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+}  // namespace selftok
+
+using namespace selftok;
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+size_t selftok_vq_workspace_bytes(int N, int C)
+{
+    (void)C;
+    return (size_t)64 * (size_t)(N > 0 ? N : 1) * sizeof(unsigned long long);   // up to 64 code splits
+}
+
+int selftok_vq_pack_codebook(const float* codebook, float* packed, int C, int Dm, hipStream_t stream)
+{
+    if (!codebook || !packed || Dm != D || C <= 0 || (C & 31)) { set_last_error("vq_pack: need D==16 and C%32==0"); return SELFTOK_EINVAL; }
+    int total = C * D;
+    hipLaunchKernelGGL(vq_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, codebook, packed, C);
+    return check_launch("vq_pack_kernel");
+}
+
+static int pick_split(int row_blocks, int ntiles, int max_split)
+{
+    // aim for >= ~1024 workgroups (4 per CU) while keeping >= 8 tiles per split
+    int split = 1;
+    while (row_blocks * split < 1024 && split * 2 <= max_split && ntiles / (split * 2) >= 8) split *= 2;
+    return split;
+}
+
+// flags: bit0 = ids are int32 (default int64), bit1 = z is already unit-norm (skip l2norm)
+int selftok_vq_encode_f32(const float* z, const float* codebook, void* ids, float* best, void* workspace,
+                          int N, int C, int Dm, int flags, hipStream_t stream)
+{
+    if (Dm != D || C <= 0 || N < 0 || !z || !codebook || !ids || !workspace) { set_last_error("vq_encode: bad argument"); return SELFTOK_EINVAL; }
+    if (N == 0) return SELFTOK_OK;
+    unsigned long long* partial = (unsigned long long*)workspace;
+    int ntiles = (C + V_TILE - 1) / V_TILE;
+    int row_blocks = (N + 4 * V_ROWS - 1) / (4 * V_ROWS);
+    int split = pick_split(row_blocks, ntiles, 64);
+    int tps = (ntiles + split - 1) / split;
+    split = (ntiles + tps - 1) / tps;
+    hipLaunchKernelGGL(vq_valu_kernel, dim3(row_blocks, split), dim3(256), 0, stream, z, codebook, partial, N, C, tps, (flags & 2) ? 0 : 1);
+    int rc = check_launch("vq_valu_kernel");
+    if (rc) return rc;
+    if (flags & 1) hipLaunchKernelGGL(vq_finalize_kernel<int32_t>, dim3((N + 255) / 256), dim3(256), 0, stream, partial, (int32_t*)ids, best, N, split);
+    else hipLaunchKernelGGL(vq_finalize_kernel<long long>, dim3((N + 255) / 256), dim3(256), 0, stream, partial, (long long*)ids, best, N, split);
+    return check_launch("vq_finalize_kernel");
+}
+
+int selftok_vq_encode_packed_f32(const float* z, const float* packed, void* ids, float* best, void* workspace,
+                                 int N, int C, int Dm, int flags, hipStream_t stream)
+{
+    if (Dm != D || C <= 0 || (C & 31) || N < 0 || !z || !packed || !ids || !workspace) { set_last_error("vq_encode_packed: bad argument"); return SELFTOK_EINVAL; }
+    if (N == 0) return SELFTOK_OK;
+    unsigned long long* partial = (unsigned long long*)workspace;
+    const int ntiles = C >> 5;
+    const int norm = (flags & 2) ? 0 : 1;
+    int rt = N >= 32768 ? 4 : (N >= 8192 ? 2 : 1);
+    int row_blocks = (N + 128 * rt - 1) / (128 * rt);
+    int split = pick_split(row_blocks, ntiles, 64);
+    int tps = (ntiles + split - 1) / split;
+    split = (ntiles + tps - 1) / tps;
+    dim3 grid(row_blocks, split), block(256);
+    if (rt == 4) hipLaunchKernelGGL(vq_mfma_kernel<4>, grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
+    else if (rt == 2) hipLaunchKernelGGL(vq_mfma_kernel<2>, grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
+    else hipLaunchKernelGGL(vq_mfma_kernel<1>, grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
+    int rc = check_launch("vq_mfma_kernel");
+    if (rc) return rc;
+    if (flags & 1) hipLaunchKernelGGL(vq_finalize_kernel<int32_t>, dim3((N + 255) / 256), dim3(256), 0, stream, partial, (int32_t*)ids, best, N, split);
+    else hipLaunchKernelGGL(vq_finalize_kernel<long long>, dim3((N + 255) / 256), dim3(256), 0, stream, partial, (long long*)ids, best, N, split);
+    return check_launch("vq_finalize_kernel");
+}
+
+// flags bit0: ids are int32 (default int64).  ln_w/ln_b may be NULL (plain gather).
+int selftok_code_gather_ln_f32(const void* ids, const float* codebook, const float* ln_w, const float* ln_b, float* out,
+                               int n, int C, int Dm, float eps, int flags, hipStream_t stream)
+{
+    if (Dm != D || n < 0 || !ids || !codebook || !out || ((ln_w == nullptr) != (ln_b == nullptr))) { set_last_error("code_gather_ln: bad argument"); return SELFTOK_EINVAL; }
+    if (n == 0) return SELFTOK_OK;
+    if (flags & 1) hipLaunchKernelGGL(code_gather_ln_kernel<int32_t>, dim3((n + 255) / 256), dim3(256), 0, stream, (const int32_t*)ids, codebook, ln_w, ln_b, out, n, C, eps);
+    else hipLaunchKernelGGL(code_gather_ln_kernel<long long>, dim3((n + 255) / 256), dim3(256), 0, stream, (const long long*)ids, codebook, ln_w, ln_b, out, n, C, eps);
+    return check_launch("code_gather_ln_kernel");
+}
+
+}  // extern "C"

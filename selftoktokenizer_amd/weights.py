@@ -1,0 +1,199 @@
+"""State-dict contract of the Selftok hot path + synthetic / real checkpoint loading.
+
+The drop-in pipeline consumes the *reference's* flat checkpoint layout
+(`torch.load(ckpt)` -> {key: tensor}; reference: mimogpt/infer/SelftokPipeline.py:190-195,
+key families listed in SURVEY.md section 3.1).  `expected_shapes()` is our own declaration of
+that contract (pinned against the reference's `state_dict()` by tools/oracle/gen_golden.py ->
+tests/golden/state_dict_keys.json).  `synthetic_state_dict()` fills any {key: shape} table
+with hash-generated values (no weights are reachable offline).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from . import synth
+
+Shape = Tuple[int, ...]
+
+# architecture constants of the two shipped presets (reference model_zoo.py:22-60,177-180)
+ENC_HIDDEN = 64      # latent-stream width of Enc-Qformer-Uni-XL/2
+ENC_HEADS = 4
+ENC_DEPTH = 16
+ENC_QDIM = 512       # query-stream width
+ENC_QHEADS = 8
+DIT_DEPTH = 24
+DIT_HIDDEN = 64 * DIT_DEPTH  # 1536
+DIT_HEADS = DIT_DEPTH
+CODE_DIM = 16
+CODEBOOK = 32768
+POS_MAX_DIT = 192
+FREQ_DIM = 256
+
+
+def _lin(d, name, out_f, in_f, bias=True):
+    d[name + ".weight"] = (out_f, in_f)
+    if bias:
+        d[name + ".bias"] = (out_f,)
+
+
+def encoder_shapes(K: int = 512, latent: int = 32, codebook: int = CODEBOOK) -> Dict[str, Shape]:
+    """`encoder.*` keys: QformerEncoder 'dual' (reference models_ours.py:43-95,268-311)."""
+    d: Dict[str, Shape] = {}
+    pm = 2 * latent
+    d["encoder.pos_embed"] = (1, pm * pm, ENC_HIDDEN)
+    d["encoder.query_tokens"] = (1, K, ENC_QDIM)
+    d["encoder.x_embedder.proj.weight"] = (ENC_HIDDEN, 16, 2, 2)
+    d["encoder.x_embedder.proj.bias"] = (ENC_HIDDEN,)
+    for i in range(ENC_DEPTH):
+        p = f"encoder.blocks.{i}."
+        _lin(d, p + "attn.qkv", 3 * ENC_HIDDEN, ENC_HIDDEN)
+        _lin(d, p + "attn.to_query_kv", 2 * ENC_QDIM, ENC_HIDDEN)
+        _lin(d, p + "attn.query_linear", 3 * ENC_QDIM, ENC_QDIM)
+        _lin(d, p + "attn.proj", ENC_HIDDEN, ENC_HIDDEN)
+        _lin(d, p + "attn.query_proj", ENC_QDIM, ENC_QDIM)
+        _lin(d, p + "mlp.fc1", 4 * ENC_HIDDEN, ENC_HIDDEN)
+        _lin(d, p + "mlp.fc2", ENC_HIDDEN, 4 * ENC_HIDDEN)
+        _lin(d, p + "q_mlp.fc1", 4 * ENC_QDIM, ENC_QDIM)
+        _lin(d, p + "q_mlp.fc2", ENC_QDIM, 4 * ENC_QDIM)
+        _lin(d, p + "adaLN_modulation.1", 6 * ENC_QDIM, ENC_QDIM)
+        _lin(d, p + "t_embedder.mlp.0", ENC_QDIM, FREQ_DIM)
+        _lin(d, p + "t_embedder.mlp.2", ENC_QDIM, ENC_QDIM)
+    for n, w in (("final_layer_norm", ENC_QDIM), ("final_layer_norm2", CODE_DIM), ("final_layer_norm3", CODE_DIM)):
+        d[f"encoder.{n}.weight"] = (w,)
+        d[f"encoder.{n}.bias"] = (w,)
+    q = "encoder.quantizer."
+    _lin(d, q + "project_in", CODE_DIM, ENC_QDIM)
+    d[q + "_codebook.initted"] = (1,)
+    d[q + "_codebook.cluster_size"] = (1, codebook)
+    d[q + "_codebook.cluster_size_wo_react"] = (1, codebook)
+    d[q + "_codebook.embed_avg"] = (1, codebook, CODE_DIM)
+    d[q + "_codebook.timestep_p_over_c"] = (1, K, codebook)
+    d[q + "_codebook.tpc_initted"] = (1,)
+    d[q + "_codebook.embed"] = (1, codebook, CODE_DIM)
+    d[q + "continuous"] = (1,)
+    d[q + "steps"] = (1,)
+    d[q + "count"] = (1, codebook)
+    return d
+
+
+def dit_shapes(K: int = 512, renderer: bool = False, latent: int = 32) -> Dict[str, Shape]:
+    """`model.*` keys: MMDiT_XL / MMDiT_XL_Renderer (reference mmdit.py:648-825,1166-1340)."""
+    d: Dict[str, Shape] = {}
+    H = DIT_HIDDEN
+    if renderer:
+        g = latent // 2
+        d["model.positional_embedding"] = (g * g, H)
+        d["model.mask_token"] = (1, 1, H)
+    else:
+        d["model.x_embedder.proj.weight"] = (H, 16, 2, 2)
+        d["model.x_embedder.proj.bias"] = (H,)
+    d["model.pos_embed"] = (1, POS_MAX_DIT * POS_MAX_DIT, H)
+    d["model.context_pos_embed"] = (1, K, H)
+    _lin(d, "model.t_embedder.mlp.0", H, FREQ_DIM)
+    _lin(d, "model.t_embedder.mlp.2", H, H)
+    _lin(d, "model.y_embedder.mlp.0", H, CODE_DIM)
+    _lin(d, "model.y_embedder.mlp.2", H, H)
+    _lin(d, "model.context_embedder", H, CODE_DIM)
+    for i in range(DIT_DEPTH):
+        last = i == DIT_DEPTH - 1
+        for stream in ("context_block", "x_block"):
+            p = f"model.joint_blocks.{i}.{stream}."
+            pre_only = last and stream == "context_block"
+            _lin(d, p + "attn.qkv", 3 * H, H)
+            if not pre_only:
+                _lin(d, p + "attn.proj", H, H)
+                _lin(d, p + "mlp.fc1", 4 * H, H)
+                _lin(d, p + "mlp.fc2", H, 4 * H)
+            _lin(d, p + "adaLN_modulation.1", (2 if pre_only else 6) * H, H)
+            if stream == "context_block":
+                _lin(d, p + "t_embedder.mlp.0", H, FREQ_DIM)
+                _lin(d, p + "t_embedder.mlp.2", H, H)
+    _lin(d, "model.final_layer.linear", 2 * 2 * 16, H)
+    _lin(d, "model.final_layer.adaLN_modulation.1", 2 * H, H)
+    return d
+
+
+def expected_shapes(K: int = 512, renderer: bool = False, latent: int = 32) -> Dict[str, Shape]:
+    d = encoder_shapes(K, latent)
+    d.update(dit_shapes(K, renderer, latent))
+    return d
+
+
+# ----------------------------------------------------------------------------
+# sin-cos tables (float64 numpy then cast: reference models.py:305-352, mmdit.py:91-135)
+# ----------------------------------------------------------------------------
+
+def sincos_1d(embed_dim: int, pos: np.ndarray) -> np.ndarray:
+    omega = np.arange(embed_dim // 2, dtype=np.float64)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def sincos_2d(embed_dim: int, grid_size: int) -> np.ndarray:
+    gh = np.arange(grid_size, dtype=np.float32)
+    gw = np.arange(grid_size, dtype=np.float32)
+    grid = np.stack(np.meshgrid(gw, gh), axis=0).reshape(2, 1, grid_size, grid_size)
+    eh = sincos_1d(embed_dim // 2, grid[0])
+    ew = sincos_1d(embed_dim // 2, grid[1])
+    return np.concatenate([eh, ew], axis=1)
+
+
+def context_pos_embed(K: int, dim: int = DIT_HIDDEN) -> torch.Tensor:
+    """sin-cos over positions 1000+8k (reference mmdit.py:812-822, diti_utils.py:109)."""
+    pos = 1000 + np.arange(K, dtype=np.float32) * 8
+    return torch.from_numpy(sincos_1d(dim, pos)).float().unsqueeze(0)
+
+
+# ----------------------------------------------------------------------------
+# synthetic state dict
+# ----------------------------------------------------------------------------
+
+def _synth_tensor(name: str, shape: Shape, device) -> torch.Tensor:
+    seed = synth.name_seed(name)
+    leaf = name.rsplit(".", 1)[-1]
+    if name.startswith("diffusion."):
+        return None
+    if name == "encoder.pos_embed":
+        g = int(round(math.sqrt(shape[1])))
+        return torch.from_numpy(sincos_2d(shape[2], g)).float().unsqueeze(0).to(device)
+    if name == "model.context_pos_embed":
+        return context_pos_embed(shape[1], shape[2]).to(device)
+    if name == "model.pos_embed":
+        return synth.hash_uniform(seed, shape, -0.5, 0.5, device)
+    if name == "encoder.query_tokens":
+        return synth.hash_uniform(seed, shape, -1.0, 1.0, device)
+    if name in ("model.positional_embedding", "model.mask_token"):
+        return synth.hash_uniform(seed, shape, -0.5, 0.5, device)
+    if name.endswith("_codebook.embed") or name.endswith("_codebook.embed_avg"):
+        raw = synth.hash_normalish(synth.name_seed("codebook"), shape, "cpu")
+        return torch.nn.functional.normalize(raw, p=2, dim=-1).to(device)
+    if leaf in ("initted", "tpc_initted"):
+        return torch.ones(shape, device=device)
+    if leaf in ("cluster_size", "cluster_size_wo_react", "count", "continuous", "steps"):
+        return torch.zeros(shape, device=device)
+    if leaf == "timestep_p_over_c":
+        return torch.full(shape, 1.0 / shape[-1], device=device)
+    if leaf == "weight" and len(shape) >= 2:
+        fan_in = int(np.prod(shape[1:]))
+        a = math.sqrt(3.0 / fan_in)
+        return synth.hash_uniform(seed, shape, -a, a, device)
+    if leaf == "weight":  # norm scale
+        return synth.hash_uniform(seed, shape, 0.9, 1.1, device)
+    if leaf == "bias":
+        return synth.hash_uniform(seed, shape, -0.1, 0.1, device)
+    raise KeyError(f"no synthetic rule for {name} {shape}")
+
+
+def synthetic_state_dict(shapes: Dict[str, Shape], device="cpu") -> Dict[str, torch.Tensor]:
+    out = {}
+    for name, shape in shapes.items():
+        t = _synth_tensor(name, tuple(shape), device)
+        if t is not None:
+            out[name] = t
+    return out

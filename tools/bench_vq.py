@@ -1,0 +1,24 @@
+"""Quick VQ kernel timing (HIP events) for both kernels at the BASELINE sizes."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from selftoktokenizer_amd import ops, synth, weights as W
+
+cb = W._synth_tensor("encoder.quantizer._codebook.embed", (1, 32768, 16), "cpu")[0].contiguous().cuda()
+pk = ops.vq_pack_codebook(cb)
+for n in (512, 32768, 65536, 131072):
+    z = synth.synthetic_vq_rows(n, device="cuda")
+    for packed, name in ((False, "valu"), (True, "mfma")):
+        c = pk if packed else cb
+        for _ in range(3):
+            ops.vq_encode(z, c, packed=packed)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        iters = 20
+        for _ in range(iters):
+            ops.vq_encode(z, c, packed=packed)
+        e.record(); torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / iters
+        fl = 2.0 * n * 32768 * 16
+        print(json.dumps({"kernel": name, "N": n, "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1)}))
