@@ -60,6 +60,80 @@ int selftok_vq_encode_packed_f32(const float* z, const float* packed, void* ids,
 int selftok_code_gather_ln_f32(const void* ids, const float* codebook, const float* ln_w, const float* ln_b,
                                float* out, int n, int C, int D, float eps, int flags, hipStream_t stream);
 
+/* ---- fused residual + LayerNorm + adaLN modulate ---------------------------------------------
+ *   x' = x + gate*y ;  n = LN(x') * (1 + scale) + shift          (LN: no affine, eps)
+ * Replaces modulate()/gate() and the nn.LayerNorm calls around them:
+ *   encoder  DualBlock.forward               mimogpt/models/selftok/modules.py:321-326 (+ :29-37)
+ *   decoder  DismantledBlock.pre_attention   mimogpt/models/selftok/sd3/mmdit.py:472-483
+ *            DismantledBlock.post_attention  mimogpt/models/selftok/sd3/mmdit.py:485-496
+ *            FinalLayer.forward              mimogpt/models/selftok/sd3/mmdit.py:641-645
+ * x,y,x_out,n_out: [B,T,H] fp32.  shift/scale/gate element (b,t,c) is read at
+ * ptr + b*stride_b + t*stride_t + c  (per-token table: stride_b=0; per-sample table: stride_t=0).
+ * y==NULL: no residual; n_out==NULL: residual only; shift==scale==NULL: plain LN; gate==NULL: x+y.
+ * H in {64,256,512,1024,1536}. */
+int selftok_residual_ln_mod_f32(const float* x, const float* y, const float* gate, const float* shift, const float* scale,
+                                float* x_out, float* n_out, int B, int T, int H,
+                                long mod_stride_b, long mod_stride_t, long gate_stride_b, long gate_stride_t,
+                                float eps, hipStream_t stream);
+
+/* in-place h = gelu_tanh(h + bias); bias may be NULL.  Replaces Mlp.act after fc1
+ * (sd3/other_impls.py:82-90; timm Mlp used at modules.py:109,293). */
+int selftok_bias_gelu_f32(float* h, const float* bias, long rows, int cols, hipStream_t stream);
+/* out = silu(in) (adaLN_modulation[0], TimestepEmbedder.mlp[1]: modules.py:297; sd3/mmdit.py:151,428). */
+int selftok_silu_f32(const float* in, float* out, long n, hipStream_t stream);
+/* out[b,:] = in[b,:] + table[:]  (per_sample floats per b): PatchEmbed bias + cropped pos-embed
+ * (models_ours.py:211-214; sd3/mmdit.py:1000), context pos-embed (sd3/mmdit.py:1026). */
+int selftok_add_rows_f32(const float* in, const float* table, float* out, int B, long per_sample, hipStream_t stream);
+/* out[n,dim] = [cos(t*t_scale*f), sin(...)] ; freqs[dim/2] from the host
+ * (TimestepEmbedder.timestep_embedding: models.py:56-74; sd3/mmdit.py:156-175). */
+int selftok_timestep_embed_f32(const float* t, const float* freqs, float* out, int n, int dim, float t_scale, hipStream_t stream);
+/* x [B,C,H,W] -> patches [B,(H/2)(W/2),4C], feature = c*4+p*2+q: PatchEmbed's k=2,s=2 conv as a GEMM
+ * (sd3/mmdit.py:66-75). */
+int selftok_patchify_f32(const float* x, float* out, int B, int C, int H, int W, hipStream_t stream);
+/* fused unpatchify (sd3/mmdit.py:898-916) + CFG mix v=u+s(c-u) (sd3/rectified_flow.py:289) +
+ * Euler step x_out = x - dt*v (sd3/rectified_flow.py:301-304).  y_* [B,hp*wp,4C]; y_uncond NULL: no CFG;
+ * x_out NULL: only v_out; v_out NULL: only x_out. */
+int selftok_unpatchify_cfg_euler_f32(const float* y_cond, const float* y_uncond, const float* x, float* x_out, float* v_out,
+                                     int B, int C, int hp, int wp, float dt, float cfg_scale, hipStream_t stream);
+/* RMSNorm (modules.py:73-95; only with qk_norm='rms', unused by the shipped configs). */
+int selftok_rmsnorm_f32(const float* x, const float* w, float* out, long rows, int dim, float eps, hipStream_t stream);
+/* rotary embedding (mimogpt/utils/rotary_embedding_torch.py:37-53; no call site in the reference). */
+int selftok_rotary_f32(const float* t, const float* freqs, float* out, long rows, int seq, int dim, hipStream_t stream);
+
+/* ---- two-segment attention with implicit prefix-visibility mask ------------------------------
+ * Replaces attention(q,k,v,heads,mask)=SDPA with a materialised bool mask (sd3/other_impls.py:37-45,
+ * called from block_mixing sd3/mmdit.py:529-530; mask built at sd3/mmdit.py:1041-1094) and the SDPA calls of
+ * DualAttention (modules.py:235-238, 263-266).  fp32 in/out on fp32-input MFMA (head_dim 64) or VALU (16).
+ * Row r of a segment: ptr + b*bs + r*rs + head*head_dim.  seg[0] keys j visible iff j <= kvis[b] (kvis NULL: all);
+ * seg[1] keys visible to seg[1] rows, and to seg[0] rows iff seg0_sees_seg1.  q==NULL: keys/values only.
+ * seg[0] rows beyond kvis[b] are dead in the reference and are not written. */
+typedef struct selftok_attn_seg {
+    const float* q; const float* k; const float* v; float* o;
+    int len;
+    long q_rs, k_rs, v_rs, o_rs;   /* row strides, floats */
+    long q_bs, k_bs, v_bs, o_bs;   /* batch strides, floats */
+} selftok_attn_seg;
+typedef struct selftok_attn_desc {
+    selftok_attn_seg seg[2];
+    int B, H, head_dim;
+    const int* kvis;
+    int seg0_sees_seg1;
+    float scale;
+} selftok_attn_desc;
+int selftok_attn_f32(const selftok_attn_desc* desc, hipStream_t stream);
+
+/* ---- SD3-VAE epilogues (bf16, NCHW) ------------------------------------------------------------
+ * GroupNorm(groups,eps,affine)+SiLU (ResnetBlock/norm_out: sd3/sd3_impls.py:244-253,373-375,440-442). */
+int selftok_groupnorm_silu_bf16(const void* x, const void* weight, const void* bias, void* out, int B, int C, int HW, int groups,
+                                float eps, int apply_silu, hipStream_t stream);
+/* `.mode()` (first c_keep of c_in channels) + SD3LatentFormat.process_in + .to(fp32)
+ * (SelftokPipeline.py:215-218; sd3/sd3_impls.py:140-141). */
+int selftok_latent_process_in(const void* moments_bf16, float* out, int B, int c_in, int c_keep, int HW, float shift, float scale, hipStream_t stream);
+/* SD3LatentFormat.process_out + .to(bf16) (SelftokPipeline.py:285-287; sd3/sd3_impls.py:143-144). */
+int selftok_latent_process_out(const float* z, void* out_bf16, long n, float shift, float scale, hipStream_t stream);
+/* norm_ip(recons,-1,1) in place (SelftokPipeline.py:135-137,290). */
+int selftok_clamp01_bf16(void* img, long n, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libselftok_hip.so")
 
-_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_vp, _i, _f, _sz, _l = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
 
 # name -> (restype, argtypes); must list every symbol declared in include/selftok_hip.h
 SIGNATURES = {
@@ -22,7 +22,32 @@ SIGNATURES = {
     "selftok_vq_pack_codebook": (_i, [_vp, _vp, _i, _i, _vp]),
     "selftok_vq_encode_packed_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "selftok_code_gather_ln_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "selftok_residual_ln_mod_f32": (_i, [_vp] * 7 + [_i, _i, _i, _l, _l, _l, _l, _f, _vp]),
+    "selftok_bias_gelu_f32": (_i, [_vp, _vp, _l, _i, _vp]),
+    "selftok_silu_f32": (_i, [_vp, _vp, _l, _vp]),
+    "selftok_add_rows_f32": (_i, [_vp, _vp, _vp, _i, _l, _vp]),
+    "selftok_timestep_embed_f32": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    "selftok_patchify_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "selftok_unpatchify_cfg_euler_f32": (_i, [_vp] * 5 + [_i, _i, _i, _i, _f, _f, _vp]),
+    "selftok_rmsnorm_f32": (_i, [_vp, _vp, _vp, _l, _i, _f, _vp]),
+    "selftok_rotary_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
+    "selftok_attn_f32": (_i, [_vp, _vp]),
+    "selftok_groupnorm_silu_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "selftok_latent_process_in": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
+    "selftok_latent_process_out": (_i, [_vp, _vp, _l, _f, _f, _vp]),
+    "selftok_clamp01_bf16": (_i, [_vp, _l, _vp]),
 }
+
+
+class AttnSeg(C.Structure):
+    _fields_ = [("q", _vp), ("k", _vp), ("v", _vp), ("o", _vp), ("len", _i),
+                ("q_rs", _l), ("k_rs", _l), ("v_rs", _l), ("o_rs", _l),
+                ("q_bs", _l), ("k_bs", _l), ("v_bs", _l), ("o_bs", _l)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("seg", AttnSeg * 2), ("B", _i), ("H", _i), ("head_dim", _i), ("kvis", _vp),
+                ("seg0_sees_seg1", _i), ("scale", _f)]
 
 _lib = None
 

@@ -1,0 +1,286 @@
+// Two-segment flash attention with an implicit prefix-visibility mask, fp32 in / fp32 out, on the
+// gfx950 fp32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate).
+//
+// Replaces the reference's  attention(q, k, v, heads, mask)  = F.scaled_dot_product_attention with a
+// materialised bool mask [B,1,S,S]  (sd3/other_impls.py:37-45, called from block_mixing sd3/mmdit.py:529-530,
+// mask built at sd3/mmdit.py:1041-1094) and the two SDPA calls of DualAttention's uni branch
+// (modules.py:235-238 latent stream, :263-266 query stream over cat(to_query_kv(x), query_kv)).
+//
+// Keys/values (and optionally queries) live in up to two segments that are never concatenated in memory:
+//   segment 0 = context / latent-kv stream,  segment 1 = image / query stream.
+// Visibility (exactly what the reference's mask encodes):
+//   * a segment-0 key j is visible to every row iff j <= kvis[b]            (kvis == NULL: all visible)
+//   * a segment-1 key is visible to segment-1 rows always, and to segment-0 rows iff seg0_sees_seg1
+// Segment-0 rows beyond kvis[b] are dead in the reference (nobody can attend to them and the model only
+// returns the image stream), so they are skipped here and their outputs are left untouched.
+//
+// Work decomposition: one workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32
+// rows.  Per 32-key tile a wave computes S^T = K Q^T with 32 chained 32x32x2 MFMAs (the "swapped" product
+// puts all scores of one query in one lane pair, so the online-softmax max/sum are per-lane plus one
+// cross-half shuffle), exponentiates in registers, and feeds P^T straight back as the B operand of the
+// O^T += V^T P^T MFMAs -- the accumulator register index IS the k index, no LDS round trip for P.
+// K tiles are staged [key][68] (b128 reads, conflict-free), V tiles [key][64] (b32 reads, conflict-free).
+#include "common.h"
+#include "selftok_hip.h"
+
+namespace selftok {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct AttnSeg {
+    const float* q;   // may be NULL: segment contributes keys/values only
+    const float* k;
+    const float* v;
+    float* o;
+    int len;          // rows in this segment
+    long q_rs, k_rs, v_rs, o_rs;   // row strides (floats)
+    long q_bs, k_bs, v_bs, o_bs;   // batch strides (floats)
+};
+
+struct AttnParams {
+    AttnSeg seg[2];
+    int B, H;
+    const int* kvis;        // [B] or NULL
+    int seg0_sees_seg1;
+    float scale;
+};
+
+constexpr int KT = 32;           // keys per tile
+constexpr int KSTR = 68;         // padded K row stride in LDS (floats)
+constexpr int QROWS = 128;       // query rows per workgroup
+
+__global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
+{
+    __shared__ __attribute__((aligned(16))) float s_k[KT * KSTR];
+    __shared__ __attribute__((aligned(16))) float s_v[KT * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+
+    int n0 = P.seg[0].len;
+    if (P.kvis) { int kv = P.kvis[b] + 1; n0 = kv < n0 ? (kv < 0 ? 0 : kv) : n0; }
+    const int rows0 = P.seg[0].q ? n0 : 0;                  // live query rows of segment 0
+    int s, r0;
+    {
+        const int t0 = P.seg[0].q ? (P.seg[0].len + QROWS - 1) / QROWS : 0;   // grid is sized on len, not on kvis
+        if ((int)blockIdx.x < t0) { s = 0; r0 = blockIdx.x * QROWS; }
+        else { s = 1; r0 = (blockIdx.x - t0) * QROWS; }
+    }
+    const int rows_live = (s == 0) ? rows0 : (P.seg[1].q ? P.seg[1].len : 0);
+    if (r0 >= rows_live) return;                            // dead context rows / empty tile
+
+    const AttnSeg& qs = P.seg[s];
+    const int n1 = (s == 1 || P.seg0_sees_seg1) ? P.seg[1].len : 0;
+
+    // ---- Q fragments: lane (half, col) holds Q[row][dd = m + 32*half], m = 0..31 ----
+    const int my_row = r0 + wave * 32 + col;
+    const bool row_ok = my_row < rows_live;
+    float qf[32];
+    {
+        const float* qp = qs.q + (size_t)b * qs.q_bs + (size_t)(row_ok ? my_row : (rows_live - 1)) * qs.q_rs + h * 64 + 32 * half;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float4 t = *reinterpret_cast<const float4*>(qp + 4 * j);
+            qf[4 * j] = t.x; qf[4 * j + 1] = t.y; qf[4 * j + 2] = t.z; qf[4 * j + 3] = t.w;
+        }
+    }
+
+    f32x16 o0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 o1 = o0;
+    const float c = P.scale * 1.4426950408889634f;   // scores are tracked in the log2 domain
+    float m_run = -__builtin_inff(), l_run = 0.f;
+
+    // staging map: thread -> 2 float4 of K and 2 of V per tile (coalesced: 16 threads cover one 256-B row)
+    const int st_key = tid >> 4, st_part = tid & 15;   // + 16 keys for the second float4
+    float4 rk[2], rv[2];
+
+    auto issue_loads = [&](int seg, int key0, int nkeys) {
+        const AttnSeg& ks = P.seg[seg];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int key = key0 + st_key + 16 * u;
+            if (key < nkeys) {
+                rk[u] = *reinterpret_cast<const float4*>(ks.k + (size_t)b * ks.k_bs + (size_t)key * ks.k_rs + h * 64 + st_part * 4);
+                rv[u] = *reinterpret_cast<const float4*>(ks.v + (size_t)b * ks.v_bs + (size_t)key * ks.v_rs + h * 64 + st_part * 4);
+            } else {
+                rk[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                rv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    // flattened tile list: segment 0 keys [0,n0) then segment 1 keys [0,n1)
+    const int nt0 = (n0 + KT - 1) / KT, nt1 = (n1 + KT - 1) / KT;
+    const int ntiles = nt0 + nt1;
+    if (ntiles == 0) return;
+    issue_loads(nt0 > 0 ? 0 : 1, 0, nt0 > 0 ? n0 : n1);
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int seg = t < nt0 ? 0 : 1;
+        const int key0 = (seg == 0 ? t : t - nt0) * KT;
+        const int nkeys = seg == 0 ? n0 : n1;
+        __syncthreads();                                     // everyone is done reading the previous tile
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int key = st_key + 16 * u;
+            *reinterpret_cast<float4*>(&s_k[key * KSTR + st_part * 4]) = rk[u];
+            *reinterpret_cast<float4*>(&s_v[key * 64 + st_part * 4]) = rv[u];
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) {                                // prefetch the next tile behind this tile's MFMAs
+            const int seg_n = (t + 1) < nt0 ? 0 : 1;
+            issue_loads(seg_n, (seg_n == 0 ? t + 1 : t + 1 - nt0) * KT, seg_n == 0 ? n0 : n1);
+        }
+
+        // ---- S^T[key][q] = sum_dd K[key][dd] Q[q][dd] ----
+        f32x16 sc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float4 kf = *reinterpret_cast<const float4*>(&s_k[col * KSTR + 32 * half + 4 * j]);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[4 * j + 0], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[4 * j + 1], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[4 * j + 2], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[4 * j + 3], sc, 0, 0, 0);
+        }
+        // sc[r] = S[q = col][key = key0 + (r&3) + 8*(r>>2) + 4*half]
+        if (key0 + KT > nkeys) {                             // ragged last tile: mask the padding keys
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= nkeys) sc[r] = -__builtin_inff();
+        }
+        float mx = sc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+        const float m_new = fmaxf(m_run, mx * c);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c, -m_new));
+            sc[r] = p;
+            psum += p;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+
+        // ---- O^T[d][q] += sum_key V[key][d] P[q][key];  MFMA m carries keys (m&3)+8*(m>>2) (+4 for half 1) ----
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int key = (m & 3) + 8 * (m >> 2) + 4 * half;
+            float v0 = s_v[key * 64 + col];
+            float v1 = s_v[key * 64 + 32 + col];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sc[m], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sc[m], o1, 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: O[q][d] = O^T / l ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, WAVE);
+    const float inv = 1.0f / l_tot;
+    if (row_ok) {
+        float* op = qs.o + (size_t)b * qs.o_bs + (size_t)my_row * qs.o_rs + h * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = 8 * g + 4 * half;
+            *reinterpret_cast<float4*>(op + d0) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *reinterpret_cast<float4*>(op + 32 + d0) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// head_dim 16 self-attention of the encoder's latent stream (modules.py:235-238): 4 heads x 256 tokens,
+// 4 MFLOP per (sample, head) -- far too small for matrix cores to matter.  One workgroup per
+// (batch, head): K and V of the head sit in LDS, every thread owns one query row and runs the online
+// softmax over broadcast LDS reads.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn16_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                     float* __restrict__ o, int L, long q_rs, long k_rs, long v_rs, long o_rs,
+                                                     long q_bs, long k_bs, long v_bs, long o_bs, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // K [L][16] then V [L][16]
+    float* s_k = smem;
+    float* s_v = smem + (size_t)L * 16;
+    const int b = blockIdx.y, h = blockIdx.x;
+    for (int i = threadIdx.x; i < L * 4; i += blockDim.x) {
+        int key = i >> 2, part = i & 3;
+        *reinterpret_cast<float4*>(&s_k[key * 16 + part * 4]) = *reinterpret_cast<const float4*>(k + (size_t)b * k_bs + (size_t)key * k_rs + h * 16 + part * 4);
+        *reinterpret_cast<float4*>(&s_v[key * 16 + part * 4]) = *reinterpret_cast<const float4*>(v + (size_t)b * v_bs + (size_t)key * v_rs + h * 16 + part * 4);
+    }
+    __syncthreads();
+    const float c = scale * 1.4426950408889634f;
+    for (int row = threadIdx.x; row < L; row += blockDim.x) {
+        float qq[16], acc[16];
+        const float* qp = q + (size_t)b * q_bs + (size_t)row * q_rs + h * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 t = *reinterpret_cast<const float4*>(qp + 4 * j);
+            qq[4 * j] = t.x; qq[4 * j + 1] = t.y; qq[4 * j + 2] = t.z; qq[4 * j + 3] = t.w;
+        }
+#pragma unroll
+        for (int d = 0; d < 16; ++d) acc[d] = 0.f;
+        float m_run = -__builtin_inff(), l_run = 0.f;
+        for (int key = 0; key < L; ++key) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) s = __builtin_fmaf(qq[d], s_k[key * 16 + d], s);
+            float sl = s * c;
+            float m_new = fmaxf(m_run, sl);
+            float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float p = __builtin_amdgcn_exp2f(sl - m_new);
+            l_run = l_run * alpha + p;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) acc[d] = __builtin_fmaf(p, s_v[key * 16 + d], acc[d] * alpha);
+            m_run = m_new;
+        }
+        const float inv = 1.0f / l_run;
+        float* op = o + (size_t)b * o_bs + (size_t)row * o_rs + h * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(op + 4 * j) = make_float4(acc[4 * j] * inv, acc[4 * j + 1] * inv, acc[4 * j + 2] * inv, acc[4 * j + 3] * inv);
+    }
+}
+
+}  // namespace selftok
+
+using namespace selftok;
+
+extern "C" {
+
+int selftok_attn_f32(const selftok_attn_desc* d, hipStream_t stream)
+{
+    if (!d || d->B < 0 || d->H <= 0) { set_last_error("attn: bad descriptor"); return SELFTOK_EINVAL; }
+    if (d->B == 0) return SELFTOK_OK;
+    if (d->head_dim == 64) {
+        AttnParams P;
+        for (int s = 0; s < 2; ++s) {
+            const selftok_attn_seg& a = d->seg[s];
+            if (a.len < 0 || (a.len > 0 && (!a.k || !a.v)) || (a.q && !a.o)) { set_last_error("attn: bad segment"); return SELFTOK_EINVAL; }
+            if (((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.q_bs | a.k_bs | a.v_bs | a.o_bs) & 3) != 0) { set_last_error("attn: strides must be multiples of 4 floats"); return SELFTOK_EINVAL; }
+            P.seg[s] = AttnSeg{a.len > 0 ? a.q : nullptr, a.k, a.v, a.o, a.len, a.q_rs, a.k_rs, a.v_rs, a.o_rs, a.q_bs, a.k_bs, a.v_bs, a.o_bs};
+        }
+        P.B = d->B; P.H = d->H; P.kvis = d->kvis; P.seg0_sees_seg1 = d->seg0_sees_seg1; P.scale = d->scale;
+        int t0 = P.seg[0].q ? (P.seg[0].len + QROWS - 1) / QROWS : 0;
+        int t1 = P.seg[1].q ? (P.seg[1].len + QROWS - 1) / QROWS : 0;
+        if (t0 + t1 == 0) return SELFTOK_OK;
+        hipLaunchKernelGGL(attn64_kernel, dim3(t0 + t1, d->H, d->B), dim3(256), 0, stream, P);
+        return check_launch("attn64_kernel");
+    }
+    if (d->head_dim == 16) {
+        // single-segment, unmasked self-attention (segment 1 only)
+        const selftok_attn_seg& a = d->seg[1];
+        if (d->seg[0].len != 0 || d->kvis || !a.q || !a.k || !a.v || !a.o || a.len <= 0 || a.len > 1024) { set_last_error("attn(head_dim 16): single unmasked segment of <= 1024 rows only"); return SELFTOK_EINVAL; }
+        size_t lds = (size_t)a.len * 16 * 2 * sizeof(float);
+        hipLaunchKernelGGL(attn16_kernel, dim3(d->H, d->B), dim3(256), lds, stream, a.q, a.k, a.v, a.o, a.len,
+                           a.q_rs, a.k_rs, a.v_rs, a.o_rs, a.q_bs, a.k_bs, a.v_bs, a.o_bs, d->scale);
+        return check_launch("attn16_kernel");
+    }
+    set_last_error("attn: head_dim must be 64 or 16");
+    return SELFTOK_EINVAL;
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+"""Q-Former 'dual' encoder + VQ on MI355X (host orchestration; compute = hipBLASLt GEMMs + our HIP kernels).
+
+Drop-in counterpart of `model.encoder` in the reference (QformerEncoder, mimogpt/models/selftok/
+models_ours.py:204-257, 268-353; DualBlock/DualAttention modules.py:165-327; VectorQuantize eval
+vector_quantize_pytorch.py:811-1080) over the reference's checkpoint keys (`encoder.*`).
+
+What differs from the reference on purpose (results identical):
+  * the per-block adaLN tables depend only on token positions 1000+8k -> computed once at load
+    (the reference recomputes them on every call, modules.py:312-318);
+  * LayerNorm / modulate / gate / residual are fused HIP passes (ops.residual_ln_mod), attention never
+    concatenates [to_query_kv(x), query_kv] (two-segment kernel), the VQ never materialises the [N,C]
+    score / one-hot tensors and skips the perplexity logging (vector_quantize_pytorch.py:561,136,957-975).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .schedule import DiTiCont
+from .weights import ENC_DEPTH, ENC_HEADS, ENC_HIDDEN, ENC_QDIM, ENC_QHEADS, FREQ_DIM
+
+
+def sinusoid_host(t: torch.Tensor, dim: int = FREQ_DIM) -> torch.Tensor:
+    """timestep_embedding on the HOST with torch-CPU ops, i.e. the reference's own arithmetic
+    (models.py:56-74).  Used for input-independent tables (positions, the 50 scheduled timesteps)."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+class _Quantizer:
+    """`model.encoder.quantizer` surface used by the pipeline: get_output_from_indices."""
+
+    def __init__(self, enc: "QformerEncoderGPU"):
+        self._enc = enc
+
+    @property
+    def codebook(self):
+        return self._enc.codebook
+
+    def get_output_from_indices(self, indices: torch.Tensor) -> torch.Tensor:
+        return ops.code_gather_ln(indices, self._enc.codebook)   # project_out is Identity (dim 16 == 16)
+
+
+class QformerEncoderGPU:
+    def __init__(self, sd: Dict[str, torch.Tensor], device, K: int):
+        g = lambda k: sd[k].to(device=device, dtype=torch.float32).contiguous()
+        self.device, self.K = device, K
+        self.post_norm = True
+        self.w = {k: g(k) for k in sd if k.startswith("encoder.") and "_codebook" not in k and "quantizer.c" not in k and "quantizer.s" not in k}
+        self.codebook = g("encoder.quantizer._codebook.embed")[0].contiguous()
+        self.codebook_packed = ops.vq_pack_codebook(self.codebook)
+        # patch embed as a GEMM: weight [64,16,2,2] -> [64(in: c*4+p*2+q), 64(out)]
+        self.pe_w = self.w["encoder.x_embedder.proj.weight"].reshape(ENC_HIDDEN, -1).t().contiguous()
+        self._pos_cache = {}
+        # input-independent adaLN tables: Linear(SiLU(t_embedder(1000+8k)))  [K, 6*512] per block
+        pos_emb = sinusoid_host(torch.from_numpy(DiTiCont.get_position(__import__("numpy").arange(K))).to(torch.int64)).to(device)
+        self.tables = []
+        for i in range(ENC_DEPTH):
+            p = f"encoder.blocks.{i}"
+            h = F.linear(pos_emb, self.w[p + ".t_embedder.mlp.0.weight"], self.w[p + ".t_embedder.mlp.0.bias"])
+            h = F.linear(ops.silu(h), self.w[p + ".t_embedder.mlp.2.weight"], self.w[p + ".t_embedder.mlp.2.bias"])
+            self.tables.append(F.linear(ops.silu(h), self.w[p + ".adaLN_modulation.1.weight"], self.w[p + ".adaLN_modulation.1.bias"]).contiguous())
+        self.quantizer = _Quantizer(self)
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def _pos_bias(self, h: int, w: int) -> torch.Tensor:
+        """centre-cropped sin-cos table (cropped_pos_embed, models_ours.py:183-202) + conv bias -> [h*w, 64]"""
+        key = (h, w)
+        if key not in self._pos_cache:
+            pe = self.w["encoder.pos_embed"]
+            grid = int(round(math.sqrt(pe.shape[1])))
+            top, left = (grid - h) // 2, (grid - w) // 2
+            crop = pe.reshape(grid, grid, -1)[top:top + h, left:left + w].reshape(h * w, -1)
+            self._pos_cache[key] = (crop + self.w["encoder.x_embedder.proj.bias"]).contiguous()
+        return self._pos_cache[key]
+
+    def lin(self, name, x):
+        return F.linear(x, self.w[name + ".weight"], self.w[name + ".bias"])
+
+    def final_layer_norm3(self, codes: torch.Tensor) -> torch.Tensor:
+        return F.layer_norm(codes, (16,), self.w["encoder.final_layer_norm3.weight"], self.w["encoder.final_layer_norm3.bias"], 1e-6)
+
+    def codes_ln(self, ids: torch.Tensor) -> torch.Tensor:
+        """fused codebook[ids] -> final_layer_norm3 (SelftokPipeline.py:236-240)"""
+        return ops.code_gather_ln(ids, self.codebook, self.w["encoder.final_layer_norm3.weight"], self.w["encoder.final_layer_norm3.bias"])
+
+    def get_encoder_mask(self, x, d, single_token=False):
+        """arange(K) <= d (models_ours.py:345-353)"""
+        ar = torch.arange(self.K, device=d.device)[None, :].expand(x.shape[0], self.K)
+        return (ar == d.unsqueeze(1)) if single_token else (ar <= d.unsqueeze(1))
+
+    # ---- forward -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def features(self, x0: torch.Tensor) -> torch.Tensor:
+        """x0 [B,16,h,w] fp32 -> pre-quantizer features z [B,K,16] (incl. quantizer.project_in)"""
+        B, _, Hh, Ww = x0.shape
+        H, Q, K = ENC_HIDDEN, ENC_QDIM, self.K
+        x = torch.matmul(ops.patchify(x0), self.pe_w)
+        ops.add_rows_(x, self._pos_bias(Hh // 2, Ww // 2))
+        N = x.shape[1]
+        q = self.w["encoder.query_tokens"].expand(B, -1, -1).contiguous()
+        tab = self.tables
+        _, xn = ops.residual_ln_mod(x)
+        _, qn = ops.residual_ln_mod(q, shift=tab[0][:, 0:Q], scale=tab[0][:, Q:2 * Q])
+        for i in range(ENC_DEPTH):
+            p = f"encoder.blocks.{i}"
+            t = tab[i]
+            qkv = self.lin(p + ".attn.qkv", xn)                    # [B,N,3*64]  (q|k|v, each 4 heads x 16)
+            kvx = self.lin(p + ".attn.to_query_kv", xn)            # [B,N,2*512]
+            qq = self.lin(p + ".attn.query_linear", qn)            # [B,K,3*512]
+            xa = torch.empty(B, N, H, device=x.device)
+            qa = torch.empty(B, K, Q, device=x.device)
+            ops.attention(None, (qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], xa), ENC_HEADS, H // ENC_HEADS)
+            ops.attention((None, kvx[..., :Q], kvx[..., Q:], None), (qq[..., :Q], qq[..., Q:2 * Q], qq[..., 2 * Q:], qa),
+                          ENC_QHEADS, Q // ENC_QHEADS)
+            # latent stream: x += proj(attn); x += mlp(LN(x))
+            x, xn2 = ops.residual_ln_mod(x, y=self.lin(p + ".attn.proj", xa))
+            h = torch.matmul(xn2, self.w[p + ".mlp.fc1.weight"].t())
+            ops.bias_gelu_(h, self.w[p + ".mlp.fc1.bias"])
+            last = i == ENC_DEPTH - 1
+            x, xn = ops.residual_ln_mod(x, y=self.lin(p + ".mlp.fc2", h), want_n=not last)
+            # query stream: q += g1*proj(attn); q += g2*mlp(mod(LN(q)))
+            q, qn2 = ops.residual_ln_mod(q, y=self.lin(p + ".attn.query_proj", qa), gate=t[:, 2 * Q:3 * Q],
+                                         shift=t[:, 3 * Q:4 * Q], scale=t[:, 4 * Q:5 * Q])
+            h = torch.matmul(qn2, self.w[p + ".q_mlp.fc1.weight"].t())
+            ops.bias_gelu_(h, self.w[p + ".q_mlp.fc1.bias"])
+            m = self.lin(p + ".q_mlp.fc2", h)
+            if last:
+                q, _ = ops.residual_ln_mod(q, y=m, gate=t[:, 5 * Q:6 * Q], want_n=False)
+            else:
+                tn = tab[i + 1]
+                q, qn = ops.residual_ln_mod(q, y=m, gate=t[:, 5 * Q:6 * Q], shift=tn[:, 0:Q], scale=tn[:, Q:2 * Q])
+        return self.lin("encoder.quantizer.project_in", q)
+
+    @torch.no_grad()
+    def __call__(self, x=None, hidden_states=None, d=None, kwargs=None):
+        """`outs_q, indices = encoder(x_0, d=None)` (models_ours.py:204-251).  With d given, returns the
+        7-tuple of the reference (only `attn_mask` is ever consumed, rectified_flow.py:215)."""
+        z = self.features(x)
+        ids = ops.vq_encode(z, self.codebook_packed, packed=True)          # int64 [B,K]
+        outs_q = self.codes_ln(ids)
+        if d is None:
+            return outs_q, ids
+        mask = self.get_encoder_mask(x, d)
+        return outs_q * mask[..., None], z, outs_q, mask, 0.0, {}, ids

@@ -1,0 +1,184 @@
+"""SD3-style MMDiT decoder (2.09 B params) of Selftok on MI355X: host orchestration of hipBLASLt fp32 GEMMs
+and our HIP kernels (fused residual+LayerNorm+adaLN, bias+GELU, MFMA two-segment attention, patchify,
+unpatchify+CFG+Euler).
+
+Counterpart of the reference's `MMDiT.forward` / `MMDiT_Renderer.forward` / `cfg_inference`
+(mimogpt/models/selftok/sd3/mmdit.py:992-1101, 1511-1620, 1117-1163) with `JointBlock` ->
+`block_mixing` -> `DismantledBlock` (:441-606) and `FinalLayer` (:609-645), over the reference's
+checkpoint keys (`model.*`).
+
+Design points (none changes a result):
+  * context-stream adaLN tables are functions of token position only -> computed once per model
+    (the reference recomputes 23 x [K,1536]->[K,9216] GEMMs every call: 27 % of a step);
+  * the attention mask of the reference is `context key j visible iff j <= k_b`; within one sampler
+    step k is the same for the whole batch, so the context stream is simply TRUNCATED to its k+1 live
+    tokens (dead rows can be read by nobody and the model returns only the image stream) and no mask
+    exists at all; a per-sample `kvis` path remains for callers that mix timesteps in a batch;
+  * context embedding (Linear 16->1536 + pos-embed) does not depend on the step -> once per decode.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .encoder import sinusoid_host
+from .schedule import DiTiCont
+from .weights import DIT_DEPTH, DIT_HEADS, DIT_HIDDEN, POS_MAX_DIT
+
+
+class MMDiTGPU:
+    def __init__(self, sd: Dict[str, torch.Tensor], device, K: int, renderer: bool = False):
+        self.device, self.K, self.renderer = device, K, renderer
+        self.w = {k: v.to(device=device, dtype=torch.float32).contiguous() for k, v in sd.items() if k.startswith("model.")}
+        H = DIT_HIDDEN
+        if not renderer:
+            self.pe_w = self.w["model.x_embedder.proj.weight"].reshape(H, -1).t().contiguous()      # [64,1536]
+        self._pos_cache = {}
+        half = 128
+        self.freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(device)
+        # context adaLN tables [K, 6H] for blocks 0..22 (block 23's context stream is pre_only: modulated by c)
+        pos_emb = sinusoid_host(torch.from_numpy(DiTiCont.get_position(np.arange(K))).to(torch.int64)).to(device)
+        self.ctx_tables = []
+        for i in range(DIT_DEPTH - 1):
+            p = f"model.joint_blocks.{i}.context_block"
+            h = self.lin(p + ".t_embedder.mlp.0", pos_emb)
+            h = self.lin(p + ".t_embedder.mlp.2", ops.silu(h))
+            self.ctx_tables.append(self.lin(p + ".adaLN_modulation.1", ops.silu(h)).contiguous())
+        self.context_pos_embed = self.w["model.context_pos_embed"][0].contiguous()                    # [K,H]
+
+    def lin(self, name, x):
+        return F.linear(x, self.w[name + ".weight"], self.w[name + ".bias"])
+
+    def _pos_bias(self, h: int, w: int) -> torch.Tensor:
+        key = (h, w)
+        if key not in self._pos_cache:
+            pe = self.w["model.pos_embed"]
+            top, left = (POS_MAX_DIT - h) // 2, (POS_MAX_DIT - w) // 2
+            crop = pe.reshape(POS_MAX_DIT, POS_MAX_DIT, -1)[top:top + h, left:left + w].reshape(h * w, -1)
+            self._pos_cache[key] = (crop + self.w["model.x_embedder.proj.bias"]).contiguous()
+        return self._pos_cache[key]
+
+    # ---- conditioning ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def embed_context(self, ehs: torch.Tensor) -> torch.Tensor:
+        """context_embedder(ehs) + context_pos_embed  (sd3/mmdit.py:1026) -> [B,K,1536]; step independent"""
+        ctx = self.lin("model.context_embedder", ehs.contiguous())
+        return ops.add_rows_(ctx, self.context_pos_embed[: ctx.shape[1]].contiguous())
+
+    @torch.no_grad()
+    def time_embed(self, t_freq: torch.Tensor) -> torch.Tensor:
+        """c = t_embedder.mlp(sinusoid)  (sd3/mmdit.py:177-183, 1022) ; t_freq [B,256]"""
+        h = self.lin("model.t_embedder.mlp.0", t_freq)
+        return self.lin("model.t_embedder.mlp.2", ops.silu(h))
+
+    # ---- the 24 joint blocks + final layer ---------------------------------------------------------
+    @torch.no_grad()
+    def core(self, xe: torch.Tensor, c: torch.Tensor, ctx: Optional[torch.Tensor], seg0_sees_seg1: bool = True,
+             kvis: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """xe [B,n_x,H] embedded image tokens, c [B,H], ctx [B,n_ctx,H] live context tokens (or None / n_ctx = 0)
+        -> FinalLayer output [B,n_x,64] (before unpatchify)."""
+        H, NH = DIT_HIDDEN, DIT_HEADS
+        B, nx, _ = xe.shape
+        n = 0 if ctx is None else ctx.shape[1]
+        has_ctx = n > 0
+        sc = ops.silu(c)                                     # every adaLN_modulation starts with SiLU(c)
+        mods_x = [self.lin(f"model.joint_blocks.{i}.x_block.adaLN_modulation.1", sc) for i in range(DIT_DEPTH)]   # [B,6H]
+        mods_c_last = self.lin(f"model.joint_blocks.{DIT_DEPTH - 1}.context_block.adaLN_modulation.1", sc) if has_ctx else None  # [B,2H]
+        mods_f = self.lin("model.final_layer.adaLN_modulation.1", sc)                                              # [B,2H]
+        tab = [t[:n] for t in self.ctx_tables]
+        x = xe
+        _, xn = ops.residual_ln_mod(x, shift=mods_x[0][:, 0:H], scale=mods_x[0][:, H:2 * H], per_sample=True)
+        if has_ctx:
+            _, cn = ops.residual_ln_mod(ctx, shift=tab[0][:, 0:H], scale=tab[0][:, H:2 * H])
+        for i in range(DIT_DEPTH):
+            pc, px = f"model.joint_blocks.{i}.context_block", f"model.joint_blocks.{i}.x_block"
+            last = i == DIT_DEPTH - 1
+            xqkv = self.lin(px + ".attn.qkv", xn)                                  # [B,nx,3H]
+            ox = torch.empty(B, nx, H, device=x.device)
+            seg1 = (xqkv[..., :H], xqkv[..., H:2 * H], xqkv[..., 2 * H:], ox)
+            if has_ctx:
+                cqkv = self.lin(pc + ".attn.qkv", cn)                              # [B,n,3H]
+                if last:   # pre_only context block: keys/values only, its attention output is discarded (sd3/mmdit.py:544-547)
+                    seg0 = (None, cqkv[..., H:2 * H], cqkv[..., 2 * H:], None)
+                else:
+                    oc = (torch.zeros if kvis is not None else torch.empty)(B, n, H, device=x.device)
+                    seg0 = (cqkv[..., :H], cqkv[..., H:2 * H], cqkv[..., 2 * H:], oc)
+                ops.attention(seg0, seg1, NH, 64, kvis=kvis, seg0_sees_seg1=seg0_sees_seg1)
+            else:
+                ops.attention(None, seg1, NH, 64)
+            # ---- context stream post-attention (sd3/mmdit.py:485-496, 'pos_emb') ----
+            if has_ctx and not last:
+                t = tab[i]
+                ctx, cn2 = ops.residual_ln_mod(ctx, y=self.lin(pc + ".attn.proj", oc), gate=t[:, 2 * H:3 * H],
+                                               shift=t[:, 3 * H:4 * H], scale=t[:, 4 * H:5 * H])
+                h = torch.matmul(cn2, self.w[pc + ".mlp.fc1.weight"].t())
+                ops.bias_gelu_(h, self.w[pc + ".mlp.fc1.bias"])
+                m = self.lin(pc + ".mlp.fc2", h)
+                if i + 1 < DIT_DEPTH - 1:
+                    tn = tab[i + 1]
+                    ctx, cn = ops.residual_ln_mod(ctx, y=m, gate=t[:, 5 * H:6 * H], shift=tn[:, 0:H], scale=tn[:, H:2 * H])
+                else:      # next block is the pre_only one: modulated per sample by c (sd3/mmdit.py:476-483)
+                    ctx, cn = ops.residual_ln_mod(ctx, y=m, gate=t[:, 5 * H:6 * H], gate_per_sample=False,
+                                                  shift=mods_c_last[:, 0:H], scale=mods_c_last[:, H:2 * H], per_sample=True)
+            # ---- image stream post-attention ('t_emb') ----
+            mx = mods_x[i]
+            x, xn2 = ops.residual_ln_mod(x, y=self.lin(px + ".attn.proj", ox), gate=mx[:, 2 * H:3 * H],
+                                         shift=mx[:, 3 * H:4 * H], scale=mx[:, 4 * H:5 * H], per_sample=True)
+            h = torch.matmul(xn2, self.w[px + ".mlp.fc1.weight"].t())
+            ops.bias_gelu_(h, self.w[px + ".mlp.fc1.bias"])
+            m = self.lin(px + ".mlp.fc2", h)
+            if not last:
+                mn = mods_x[i + 1]
+                x, xn = ops.residual_ln_mod(x, y=m, gate=mx[:, 5 * H:6 * H], shift=mn[:, 0:H], scale=mn[:, H:2 * H], per_sample=True)
+            else:          # FinalLayer: LN + modulate(shift, scale = adaLN(c).chunk(2)) + Linear (sd3/mmdit.py:641-645)
+                x, xn = ops.residual_ln_mod(x, y=m, gate=mx[:, 5 * H:6 * H], shift=mods_f[:, 0:H], scale=mods_f[:, H:2 * H], per_sample=True)
+        return self.lin("model.final_layer.linear", xn)
+
+    # ---- reference-shaped entry points ---------------------------------------------------------------
+    @torch.no_grad()
+    def embed_image(self, x: torch.Tensor) -> torch.Tensor:
+        """x_embedder(x) + cropped_pos_embed (sd3/mmdit.py:1000)"""
+        B, _, Hh, Ww = x.shape
+        xe = torch.matmul(ops.patchify(x), self.pe_w)
+        return ops.add_rows_(xe, self._pos_bias(Hh // 2, Ww // 2))
+
+    @torch.no_grad()
+    def velocity_tokens(self, x, t_freq, ctx0, n_live: int, context_see_xt: bool = True):
+        """one model evaluation inside the sampler: returns the FinalLayer tokens [B,256,64]"""
+        c = self.time_embed(t_freq)
+        ctx = ctx0[:, :n_live].contiguous() if n_live < ctx0.shape[1] else ctx0
+        return self.core(self.embed_image(x), c, ctx if n_live > 0 else None, context_see_xt)
+
+    @torch.no_grad()
+    def __call__(self, x=None, t=None, y=None, encoder_hidden_states=None, **kwargs):
+        """MMDiT.forward(x, t, y=None, encoder_hidden_states, mask=, context_see_xt=) -> (v [B,16,h,w], drop_ids)
+        and MMDiT_Renderer.forward(y=None, encoder_hidden_states=) -> (latent, drop_ids)."""
+        ehs = encoder_hidden_states
+        B = ehs.shape[0]
+        if self.renderer:
+            g = int(round(math.sqrt(self.w["model.positional_embedding"].shape[0])))
+            xe = (self.w["model.mask_token"].expand(B, g * g, -1) + self.w["model.positional_embedding"]).contiguous()
+            t_freq = sinusoid_host(torch.full((B,), 1000.0)).to(self.device)       # t = ones*1000 (sd3/mmdit.py:1525)
+            out = self.core(xe, self.time_embed(t_freq), self.embed_context(ehs), kwargs.get("context_see_xt", False))
+            _, v = ops.unpatchify_cfg_euler(out, C=16, hp=g, wp=g)
+            return v, torch.zeros(B, dtype=torch.bool)
+        mask = kwargs.get("mask", None)
+        see = kwargs.get("context_see_xt", False)
+        Hh, Ww = x.shape[-2:]
+        t_freq = ops.timestep_embed(t.to(self.device).float(), self.freqs, 1000.0)
+        ctx = self.embed_context(ehs)
+        kvis = None
+        if mask is not None:
+            m = mask.to(self.device).bool()
+            # the reference's masks are prefixes (arange(K) <= k); anything else is outside the hot path
+            cnt = m.sum(dim=1)
+            assert bool((m == (torch.arange(m.shape[1], device=m.device)[None] < cnt[:, None])).all()), "non-prefix mask"
+            kvis = (cnt - 1).to(torch.int32).contiguous()
+        out = self.core(self.embed_image(x.to(self.device).float()), self.time_embed(t_freq), ctx, see, kvis)
+        _, v = ops.unpatchify_cfg_euler(out, C=16, hp=Hh // 2, wp=Ww // 2)
+        return v, torch.zeros(B, dtype=torch.bool)

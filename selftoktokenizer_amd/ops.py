@@ -69,3 +69,188 @@ def code_gather_ln(ids: torch.Tensor, codebook: torch.Tensor, ln_w=None, ln_b=No
     _lib.check(_lib.load().selftok_code_gather_ln_f32(_p(flat), _p(codebook), _p(ln_w), _p(ln_b), _p(out), n, C, D,
                                                       eps, flags, _stream()), "selftok_code_gather_ln_f32")
     return out.reshape(*ids.shape, D)
+
+
+# ----------------------------------------------------------------------------------------------
+# fused epilogues (csrc/elementwise.hip)
+# ----------------------------------------------------------------------------------------------
+
+def residual_ln_mod(x, *, y=None, gate=None, shift=None, scale=None, per_sample=False, gate_per_sample=None,
+                    want_x=True, want_n=True, eps=1e-6):
+    """x' = x + gate*y ; n = LN(x')*(1+scale)+shift.   x,y [B,T,H].  shift/scale/gate are 2-D views
+    [T,H] (per token, default) or [B,H] (per_sample=True) -- typically column slices of a [*,6H] table.
+    Returns (x', n) (either may be None)."""
+    _need_cuda(x)
+    B, T, H = x.shape
+    assert x.is_contiguous() and x.dtype == torch.float32
+
+    def strides(t, ps):
+        if t is None:
+            return 0, 0
+        assert t.dim() == 2 and t.stride(1) == 1 and t.shape[1] == H and t.shape[0] == (B if ps else T)
+        return (t.stride(0), 0) if ps else (0, t.stride(0))
+
+    if shift is not None:
+        assert scale is not None and shift.stride(0) == scale.stride(0)
+    msb, mst = strides(shift, per_sample)
+    gsb, gst = strides(gate, per_sample if gate_per_sample is None else gate_per_sample)
+    if y is not None:
+        assert y.is_contiguous() and y.shape == x.shape
+    x_out = torch.empty_like(x) if (y is not None and want_x) else None
+    n_out = torch.empty_like(x) if want_n else None
+    _lib.check(_lib.load().selftok_residual_ln_mod_f32(_p(x), _p(y), _p(gate), _p(shift), _p(scale), _p(x_out), _p(n_out),
+                                                       B, T, H, msb, mst, gsb, gst, eps, _stream()), "selftok_residual_ln_mod_f32")
+    return (x_out if y is not None else x), n_out
+
+
+def bias_gelu_(h, bias=None):
+    _need_cuda(h)
+    assert h.is_contiguous() and h.dtype == torch.float32
+    cols = h.shape[-1]
+    _lib.check(_lib.load().selftok_bias_gelu_f32(_p(h), _p(bias), h.numel() // cols, cols, _stream()), "selftok_bias_gelu_f32")
+    return h
+
+
+def silu(x):
+    _need_cuda(x)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().selftok_silu_f32(_p(x), _p(out), x.numel(), _stream()), "selftok_silu_f32")
+    return out
+
+
+def add_rows_(x, table):
+    """x[b] += table for every b (in place). x [B,...], table [...] contiguous."""
+    _need_cuda(x, table)
+    assert x.is_contiguous() and table.is_contiguous() and x[0].numel() == table.numel()
+    _lib.check(_lib.load().selftok_add_rows_f32(_p(x), _p(table), _p(x), x.shape[0], table.numel(), _stream()), "selftok_add_rows_f32")
+    return x
+
+
+def timestep_embed(t, freqs, t_scale=1.0):
+    _need_cuda(t, freqs)
+    t = t.contiguous().float()
+    n, half = t.numel(), freqs.numel()
+    out = torch.empty(n, 2 * half, dtype=torch.float32, device=t.device)
+    _lib.check(_lib.load().selftok_timestep_embed_f32(_p(t), _p(freqs), _p(out), n, 2 * half, float(t_scale), _stream()), "selftok_timestep_embed_f32")
+    return out
+
+
+def patchify(x):
+    _need_cuda(x)
+    x = x.contiguous().float()
+    B, C, H, W = x.shape
+    out = torch.empty(B, (H // 2) * (W // 2), 4 * C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().selftok_patchify_f32(_p(x), _p(out), B, C, H, W, _stream()), "selftok_patchify_f32")
+    return out
+
+
+def unpatchify_cfg_euler(y_cond, x=None, dt=0.0, y_uncond=None, cfg_scale=1.0, C=16, hp=16, wp=16, want_v=False):
+    """returns (x_new or None, v or None)"""
+    _need_cuda(y_cond)
+    B = y_cond.shape[0]
+    assert y_cond.is_contiguous() and y_cond.shape[1] == hp * wp and y_cond.shape[2] == 4 * C
+    x_out = torch.empty(B, C, 2 * hp, 2 * wp, dtype=torch.float32, device=y_cond.device) if x is not None else None
+    v_out = torch.empty(B, C, 2 * hp, 2 * wp, dtype=torch.float32, device=y_cond.device) if (want_v or x is None) else None
+    if x is not None:
+        assert x.is_contiguous()
+    _lib.check(_lib.load().selftok_unpatchify_cfg_euler_f32(_p(y_cond), _p(y_uncond), _p(x), _p(x_out), _p(v_out), B, C, hp, wp,
+                                                            float(dt), float(cfg_scale), _stream()), "selftok_unpatchify_cfg_euler_f32")
+    return x_out, v_out
+
+
+def rmsnorm(x, w=None, eps=1e-6):
+    _need_cuda(x)
+    x = x.contiguous().float()
+    out = torch.empty_like(x)
+    dim = x.shape[-1]
+    _lib.check(_lib.load().selftok_rmsnorm_f32(_p(x), _p(w), _p(out), x.numel() // dim, dim, eps, _stream()), "selftok_rmsnorm_f32")
+    return out
+
+
+def rotary(t, freqs):
+    """t [..., seq, dim], freqs [seq, dim]"""
+    _need_cuda(t, freqs)
+    t = t.contiguous().float()
+    freqs = freqs.contiguous().float()
+    seq, dim = freqs.shape
+    out = torch.empty_like(t)
+    _lib.check(_lib.load().selftok_rotary_f32(_p(t), _p(freqs), _p(out), t.numel() // dim, seq, dim, _stream()), "selftok_rotary_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# attention (csrc/attention.hip)
+# ----------------------------------------------------------------------------------------------
+
+def _seg(q, k, v, o):
+    """q/k/v/o: 3-D views [B, L, H*Dh] with unit inner stride (slices of a fused qkv buffer are fine)."""
+    s = _lib.AttnSeg()
+    if k is None:
+        return s
+    for name, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+        if t is None:
+            continue
+        assert t.dim() == 3 and t.stride(2) == 1 and t.dtype == torch.float32
+        setattr(s, name, t.data_ptr())
+        setattr(s, name + "_rs", t.stride(1))
+        setattr(s, name + "_bs", t.stride(0))
+    s.len = k.shape[1]
+    return s
+
+
+def attention(seg0, seg1, heads, head_dim, kvis=None, seg0_sees_seg1=True, scale=None):
+    """seg = (q, k, v, o) tuples of [B,L,heads*head_dim] views (q and o None: keys/values only; seg None: empty).
+    Writes into the `o` views.  kvis: int32 [B] or None."""
+    lib = _lib.load()
+    d = _lib.AttnDesc()
+    ref = seg1 if seg1 is not None else seg0
+    _need_cuda(ref[1])
+    d.seg[0] = _seg(*seg0) if seg0 is not None else _lib.AttnSeg()
+    d.seg[1] = _seg(*seg1) if seg1 is not None else _lib.AttnSeg()
+    d.B, d.H, d.head_dim = ref[1].shape[0], heads, head_dim
+    if kvis is not None:
+        assert kvis.dtype == torch.int32 and kvis.is_cuda and kvis.numel() == d.B
+        d.kvis = kvis.data_ptr()
+    d.seg0_sees_seg1 = 1 if seg0_sees_seg1 else 0
+    d.scale = float(scale if scale is not None else head_dim ** -0.5)
+    import ctypes
+    _lib.check(lib.selftok_attn_f32(ctypes.byref(d), _stream()), "selftok_attn_f32")
+
+
+# ----------------------------------------------------------------------------------------------
+# VAE epilogues (csrc/vae.hip)
+# ----------------------------------------------------------------------------------------------
+
+def groupnorm_silu(x, weight, bias, groups=32, eps=1e-6, silu_act=True):
+    _need_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().selftok_groupnorm_silu_bf16(_p(x), _p(weight), _p(bias), _p(out), B, C, H * W, groups, eps,
+                                                       1 if silu_act else 0, _stream()), "selftok_groupnorm_silu_bf16")
+    return out
+
+
+def latent_process_in(moments, c_keep=16, shift=0.0609, scale=1.5305):
+    _need_cuda(moments)
+    assert moments.dtype == torch.bfloat16 and moments.is_contiguous()
+    B, Cin, H, W = moments.shape
+    out = torch.empty(B, c_keep, H, W, dtype=torch.float32, device=moments.device)
+    _lib.check(_lib.load().selftok_latent_process_in(_p(moments), _p(out), B, Cin, c_keep, H * W, shift, scale, _stream()), "selftok_latent_process_in")
+    return out
+
+
+def latent_process_out(z, shift=0.0609, scale=1.5305):
+    _need_cuda(z)
+    z = z.contiguous().float()
+    out = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device)
+    _lib.check(_lib.load().selftok_latent_process_out(_p(z), _p(out), z.numel(), shift, scale, _stream()), "selftok_latent_process_out")
+    return out
+
+
+def clamp01_(img):
+    _need_cuda(img)
+    assert img.dtype == torch.bfloat16 and img.is_contiguous()
+    _lib.check(_lib.load().selftok_clamp01_bf16(_p(img), img.numel(), _stream()), "selftok_clamp01_bf16")
+    return img

@@ -1,0 +1,207 @@
+"""`SelftokPipeline` -- the drop-in host API of the reference (mimogpt/infer/SelftokPipeline.py:153-322),
+re-authored for MI355X: same constructor, `encoding`, `decoding`, `decoding_with_renderer`,
+`NormalizeToTensor`, same checkpoint layouts, same dtypes at every hand-off (bf16 VAE <-> fp32 tokenizer),
+same RNG source for the decode noise (global CPU torch generator, :264).
+
+Public attributes users touch in the reference are kept: `.model` (with `.encoder`, `.model`, `.diti`),
+`.vae`, `.flow`, `.diti`, `.K`, `._steps`, `.cfg_scale`, `.start`.
+
+Nothing here falls back to a CPU path: without libselftok_hip.so / a GPU the constructor raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, ops, weights as W
+from .encoder import QformerEncoderGPU, sinusoid_host
+from .mmdit import MMDiTGPU
+from .schedule import DiTiCont, FlowSchedule
+from .vae import AutoencoderKLGPU
+
+SD3_SCALE, SD3_SHIFT = 1.5305, 0.0609     # SD3LatentFormat (sd3/sd3_impls.py:136-138)
+
+
+class NormalizeToTensor(object):
+    """PIL/ndarray HWC uint8 -> float tensor CHW in [-1,1] (reference SelftokPipeline.py:85-97)."""
+
+    def __init__(self, reshape=True):
+        self.reshape = reshape
+
+    def __call__(self, image):
+        image = np.array(image).astype(np.float32)
+        image = (image / 127.5 - 1.0).astype(np.float32)
+        if self.reshape:
+            image = np.reshape(image, (image.shape[0], image.shape[1], -1))
+        return torch.from_numpy(image.transpose((2, 0, 1)))
+
+
+def norm_ip(img, low=-1, high=1):
+    """in-place clamp + rescale to [0,1] (reference :135-137); bf16 device tensors use the HIP kernel."""
+    assert (low, high) == (-1, 1)
+    return ops.clamp01_(img)
+
+
+class _Tokenizer:
+    """`pipe.model` : the ImageTokenizer surface (image_tokenizer.py:58-159) the pipeline and users touch."""
+
+    def __init__(self, encoder, model, diti):
+        self.encoder, self.model, self.diti = encoder, model, diti
+        self.k = diti.K
+
+    def set_eval(self):
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+
+class _Flow(FlowSchedule):
+    """`pipe.flow`: RectifiedFlow(50, start, cut_of_k, val_schedule='uniform', shift=1.0, ...) buffers as numpy,
+    plus the device-side sampler (p_sample_loop / sample_one_step / euler_step, sd3/rectified_flow.py:165-309)."""
+
+    def __init__(self, num_steps, start, device):
+        super().__init__(num_steps, start)
+        self.device = device
+        # sinusoidal embedding of t*1000 for the scheduled timesteps, evaluated with the reference's CPU arithmetic
+        t1000 = torch.from_numpy(self.scheduled_t) * 1000.0
+        self.t_freq = sinusoid_host(t1000).to(device)                        # [steps,256]
+        # cfg_inference embeds floor(t*1000).int().clamp(0,999) instead (sd3/mmdit.py:1126)
+        t_unc = torch.floor(torch.from_numpy(self.scheduled_t) * 1000).int().clamp(0, 999)
+        self.t_freq_uncond = sinusoid_host(t_unc).to(device)
+
+    @torch.no_grad()
+    def p_sample_loop(self, dit: MMDiTGPU, noise: torch.Tensor, ehs: torch.Tensor, k_table: np.ndarray,
+                      context_see_xt: bool = True, uncond_scale: float = 1.0, max_steps: Optional[int] = None,
+                      trace: Optional[list] = None) -> torch.Tensor:
+        B = noise.shape[0]
+        x = noise.to(self.device).float().contiguous()
+        hp, wp = x.shape[-2] // 2, x.shape[-1] // 2
+        ctx0 = dit.embed_context(ehs)                                         # step independent
+        steps = self.num_timesteps if max_steps is None else min(max_steps, self.num_timesteps)
+        for i in range(steps):
+            n_live = int(k_table[i]) + 1                                      # mask = arange(K) <= k  (models_ours.py:353)
+            tf = self.t_freq[i:i + 1].expand(B, -1).contiguous()
+            if uncond_scale == 1.0:
+                y = dit.velocity_tokens(x, tf, ctx0, n_live, context_see_xt)
+                yu = None
+            else:
+                # CFG branch (rectified_flow.py:280-289): the conditional call omits context_see_xt (-> False) and
+                # the unconditional one sees no context token at all
+                y = dit.velocity_tokens(x, tf, ctx0, n_live, False)
+                tfu = self.t_freq_uncond[i:i + 1].expand(B, -1).contiguous()
+                yu = dit.velocity_tokens(x, tfu, ctx0, 0, False)
+            x, _ = ops.unpatchify_cfg_euler(y, x, float(self.dt[i]), y_uncond=yu, cfg_scale=uncond_scale, C=x.shape[1], hp=hp, wp=wp)
+            if trace is not None:
+                trace.append(x.clone())
+        return x
+
+
+class SelftokPipeline():
+    def __init__(self, cfg, ckpt_path, sd3_path, datasize=256, start=1.0, cfg_scale=1, model_type='sd3',
+                 dtype=torch.bfloat16, ema_decoder=False, device=None, state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 vae_state_dict: Optional[Dict[str, torch.Tensor]] = None):
+        """cfg: parse_args_from_yaml(...) ; ckpt_path: tokenizer .pth ; sd3_path: diffusers SD3 folder (…/vae/…).
+        `state_dict` / `vae_state_dict` (extensions) bypass the files, e.g. with weights.synthetic_state_dict()."""
+        _lib.load()                                                           # fail loudly if the HIP library is missing
+        if device is None:
+            device = "cuda"
+        if not torch.cuda.is_available():
+            raise _lib.SelftokHipError("SelftokPipeline needs an MI355X (ROCm) device; there is no CPU path")
+        if model_type != 'sd3':
+            raise ValueError(f"Unsupported MODEL_TYPE: {model_type}. Expected 'sd3'")
+        self.cfg, self.datasize, self.model_type, self.dtype = cfg, datasize, model_type, dtype
+        self.device = torch.device(device)
+        p = cfg.tokenizer.params
+        p.noise_schedule_config.is_eval = cfg.common.is_eval
+        assert p.get("diffusion_type", "flow") == "flow"
+        K = int(p.k)
+        renderer = "Renderer" in str(p.model)
+        self.diti = DiTiCont(1000, K, p.stages, p.k_per_stage)
+        self.K = K
+        self.context_see_xt = bool(p.get("context_see_xt", False))
+
+        vsd = vae_state_dict if vae_state_dict is not None else W.load_vae_checkpoint(sd3_path)
+        self.vae = AutoencoderKLGPU(vsd, self.device, dtype)
+
+        print("Loading all...")
+        sd = state_dict if state_dict is not None else W.load_tokenizer_checkpoint(ckpt_path)
+        self.ema_decoder = ema_decoder
+        dit_sd = sd
+        if ema_decoder:   # reference :193-194: EMA copy of the DiT under 'ema_state_dict' (keys without the 'model.' prefix)
+            dit_sd = {("model." + k if not k.startswith("model.") else k): v for k, v in sd["ema_state_dict"].items()}
+        encoder = QformerEncoderGPU(sd, self.device, K)
+        dit = MMDiTGPU(dit_sd, self.device, K, renderer=renderer)
+        self.model = _Tokenizer(encoder, dit, self.diti)
+
+        self.count = 0
+        self.count_cfg = 0
+        self.start = start
+        self.cfg_scale = cfg_scale
+        self.cut_of_k = p.get("cut_of_k", None) or None
+        self._steps = 50
+        self.flow = _Flow(self._steps, self.start, self.device)
+        self.k_table = self.diti.to_indices(self.flow.t_long)                # k for each of the 50 steps
+        self.cond_vary = True
+        self.saved_images = 8
+
+    # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_latents(self, images: torch.Tensor) -> torch.Tensor:
+        """VAE mean -> SD3LatentFormat.process_in -> fp32 (reference :214-218)"""
+        moments = self.vae.encode_moments(images.to(dtype=self.dtype, device=self.device))
+        return ops.latent_process_in(moments.contiguous(), moments.shape[1] // 2, SD3_SHIFT, SD3_SCALE)
+
+    @torch.no_grad()
+    def encoding(self, images, device=None):
+        print("Begin encoding.")
+        x_0 = self.encode_latents(images)
+        _, tokens = self.model.encoder(x_0, d=None)
+        print('End encoding.')
+        return tokens
+
+    @torch.no_grad()
+    def _codes(self, idx) -> torch.Tensor:
+        token_idx = torch.from_numpy(np.ascontiguousarray(idx)).to(self.device) if isinstance(idx, np.ndarray) else idx.to(self.device)
+        B = token_idx.shape[0]
+        return self.model.encoder.codes_ln(token_idx.reshape(B, -1))          # get_output_from_indices + final_layer_norm3
+
+    @torch.no_grad()
+    def _to_pixels(self, pred_x0: torch.Tensor) -> torch.Tensor:
+        z = ops.latent_process_out(pred_x0, SD3_SHIFT, SD3_SCALE)             # process_out + .to(bf16) (:285-287)
+        recons = self.vae.decode(z)[0].contiguous()
+        return norm_ip(recons, -1, 1)
+
+    @torch.no_grad()
+    def decoding(self, idx, device=None, noise: Optional[torch.Tensor] = None, return_latent: bool = False,
+                 max_steps: Optional[int] = None, uncond_scale: float = 1.0):
+        """idx: np.ndarray int64 [B,K] -> bf16 [B,3,H,W] in [0,1] (reference :227-294).  `noise` (extension) replaces the
+        `torch.randn` draw from the global CPU generator (:264); `uncond_scale` exposes the dormant CFG branch."""
+        print("Begin decoding.")
+        outs_q = self._codes(idx)
+        B = outs_q.shape[0]
+        # t_mapped = timestep_map[0] -> k = K-1 -> enc_mask all true -> encoder_hidden_states = outs_q (:243-252)
+        k0 = int(self.diti.to_indices(self.flow.t_long[:1])[0])
+        ehs = outs_q if k0 >= self.K - 1 else outs_q * (torch.arange(self.K, device=self.device) <= k0)[None, :, None]
+        latent_dim = self.datasize // 8
+        xt = noise if noise is not None else torch.randn(B, 16, latent_dim, latent_dim)
+        pred_x0 = self.flow.p_sample_loop(self.model.model, xt, ehs, self.k_table, context_see_xt=True,
+                                          uncond_scale=uncond_scale, max_steps=max_steps)
+        recons = self._to_pixels(pred_x0)
+        print('End decoding.')
+        return (recons, pred_x0) if return_latent else recons
+
+    @torch.no_grad()
+    def decoding_with_renderer(self, idx, device=None, return_latent: bool = False):
+        """one MMDiT_Renderer pass instead of the 50-step loop (reference :296-322)"""
+        print("Begin decoding with Renderer.")
+        outs_q = self._codes(idx)
+        pred_x0, _ = self.model.model(y=None, encoder_hidden_states=outs_q)
+        recons = self._to_pixels(pred_x0)
+        print('End decoding with Renderer.')
+        return (recons, pred_x0) if return_latent else recons

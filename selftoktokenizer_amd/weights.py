@@ -197,3 +197,116 @@ def synthetic_state_dict(shapes: Dict[str, Shape], device="cpu") -> Dict[str, to
         if t is not None:
             out[name] = t
     return out
+
+
+# ----------------------------------------------------------------------------
+# SD3 VAE (diffusers AutoencoderKL key names; reference SelftokPipeline.py:162-163)
+# ----------------------------------------------------------------------------
+
+def _res(d, p, cin, cout):
+    d[p + ".norm1.weight"] = (cin,); d[p + ".norm1.bias"] = (cin,)
+    d[p + ".conv1.weight"] = (cout, cin, 3, 3); d[p + ".conv1.bias"] = (cout,)
+    d[p + ".norm2.weight"] = (cout,); d[p + ".norm2.bias"] = (cout,)
+    d[p + ".conv2.weight"] = (cout, cout, 3, 3); d[p + ".conv2.bias"] = (cout,)
+    if cin != cout:
+        d[p + ".conv_shortcut.weight"] = (cout, cin, 1, 1); d[p + ".conv_shortcut.bias"] = (cout,)
+
+
+def _mid(d, p, c):
+    _res(d, p + ".resnets.0", c, c)
+    a = p + ".attentions.0"
+    d[a + ".group_norm.weight"] = (c,); d[a + ".group_norm.bias"] = (c,)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        d[f"{a}.{n}.weight"] = (c, c); d[f"{a}.{n}.bias"] = (c,)
+    _res(d, p + ".resnets.1", c, c)
+
+
+def vae_shapes() -> Dict[str, Shape]:
+    """stabilityai SD3 VAE: block_out_channels (128,256,512,512), 2 layers/block, latent 16, no quant convs."""
+    d: Dict[str, Shape] = {}
+    ch = (128, 256, 512, 512)
+    d["encoder.conv_in.weight"] = (128, 3, 3, 3); d["encoder.conv_in.bias"] = (128,)
+    cin = 128
+    for L, cout in enumerate(ch):
+        for j in range(2):
+            _res(d, f"encoder.down_blocks.{L}.resnets.{j}", cin, cout)
+            cin = cout
+        if L != 3:
+            d[f"encoder.down_blocks.{L}.downsamplers.0.conv.weight"] = (cout, cout, 3, 3)
+            d[f"encoder.down_blocks.{L}.downsamplers.0.conv.bias"] = (cout,)
+    _mid(d, "encoder.mid_block", 512)
+    d["encoder.conv_norm_out.weight"] = (512,); d["encoder.conv_norm_out.bias"] = (512,)
+    d["encoder.conv_out.weight"] = (32, 512, 3, 3); d["encoder.conv_out.bias"] = (32,)
+    d["decoder.conv_in.weight"] = (512, 16, 3, 3); d["decoder.conv_in.bias"] = (512,)
+    _mid(d, "decoder.mid_block", 512)
+    cin = 512
+    for L, cout in enumerate((512, 512, 256, 128)):
+        for j in range(3):
+            _res(d, f"decoder.up_blocks.{L}.resnets.{j}", cin, cout)
+            cin = cout
+        if L != 3:
+            d[f"decoder.up_blocks.{L}.upsamplers.0.conv.weight"] = (cout, cout, 3, 3)
+            d[f"decoder.up_blocks.{L}.upsamplers.0.conv.bias"] = (cout,)
+    d["decoder.conv_norm_out.weight"] = (128,); d["decoder.conv_norm_out.bias"] = (128,)
+    d["decoder.conv_out.weight"] = (3, 128, 3, 3); d["decoder.conv_out.bias"] = (3,)
+    return d
+
+
+def synthetic_vae_state_dict(device="cpu", dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    sd = {}
+    for name, shape in vae_shapes().items():
+        sd[name] = _synth_tensor("vae." + name, shape, device).to(dtype)
+    return sd
+
+
+def diffusers_to_ldm_key(key: str) -> str:
+    """diffusers AutoencoderKL key -> the ldm/SDVAE-mirror key (reference sd3_impls.py:215-474 module names;
+    mapping hints at SelftokPipeline.py:48-53).  Attention q/k/v/out are 1x1 convs there ([C,C,1,1])."""
+    import re
+    k = key
+    k = re.sub(r"^encoder\.down_blocks\.(\d)\.resnets\.(\d)\.", r"encoder.down.\1.block.\2.", k)
+    k = re.sub(r"^encoder\.down_blocks\.(\d)\.downsamplers\.0\.conv\.", r"encoder.down.\1.downsample.conv.", k)
+    m = re.match(r"^decoder\.up_blocks\.(\d)\.(resnets\.(\d)|upsamplers\.0\.conv)\.(.*)$", k)
+    if m:
+        lvl = 3 - int(m.group(1))
+        if m.group(3) is not None:
+            k = f"decoder.up.{lvl}.block.{m.group(3)}.{m.group(4)}"
+        else:
+            k = f"decoder.up.{lvl}.upsample.conv.{m.group(4)}"
+    k = k.replace("mid_block.resnets.0.", "mid.block_1.").replace("mid_block.resnets.1.", "mid.block_2.")
+    k = k.replace("mid_block.attentions.0.group_norm.", "mid.attn_1.norm.")
+    k = k.replace("mid_block.attentions.0.to_q.", "mid.attn_1.q.").replace("mid_block.attentions.0.to_k.", "mid.attn_1.k.")
+    k = k.replace("mid_block.attentions.0.to_v.", "mid.attn_1.v.").replace("mid_block.attentions.0.to_out.0.", "mid.attn_1.proj_out.")
+    k = k.replace("conv_norm_out.", "norm_out.").replace("conv_shortcut.", "nin_shortcut.")
+    return k
+
+
+# ----------------------------------------------------------------------------
+# real checkpoints
+# ----------------------------------------------------------------------------
+
+def load_tokenizer_checkpoint(path: str) -> Dict[str, torch.Tensor]:
+    """`torch.load(ckpt, map_location='cpu')` flat state dict (reference SelftokPipeline.py:190)."""
+    sd = torch.load(path, map_location="cpu")
+    if isinstance(sd, dict) and "state_dict" in sd and not any(k.startswith("encoder.") for k in sd):
+        sd = sd["state_dict"]
+    return sd
+
+
+def load_vae_checkpoint(sd3_path: str) -> Dict[str, torch.Tensor]:
+    """<sd3_path>/vae/diffusion_pytorch_model.safetensors in diffusers layout (reference SelftokPipeline.py:162),
+    or a single-file ldm checkpoint with `first_stage_model.` keys (reference set_sd3_vae, :115-121)."""
+    import os
+    cand = os.path.join(sd3_path, "vae", "diffusion_pytorch_model.safetensors")
+    if os.path.exists(cand):
+        from safetensors.torch import load_file
+        return load_file(cand)
+    raw = torch.load(sd3_path, map_location="cpu")
+    inv = {diffusers_to_ldm_key(k): k for k in vae_shapes()}
+    out = {}
+    for k, v in raw.items():
+        k2 = k.replace("first_stage_model.", "")
+        if k2 in inv:
+            tgt = inv[k2]
+            out[tgt] = v.reshape(vae_shapes()[tgt])
+    return out

@@ -1,0 +1,124 @@
+"""-m gpu: the MI355X product path (HIP kernels + hipBLASLt GEMMs) against the golden vectors captured from
+the reference (tests/golden/, see tools/oracle/gen_golden.py) on the same hash-generated weights/inputs.
+
+Tolerances (floating point, stated per BASELINE north_star): token ids bit-exact at the VQ kernel boundary
+(tests/test_vq_gpu.py); end to end ids are reported as a match fraction because the upstream fp32 GEMMs of two
+different BLAS libraries differ at ~1e-6 and a token whose top-1/top-2 gap is below that may flip -- every
+mismatching token must have a golden gap below GAP_TOL.  Velocities/latents: 2e-3 absolute on O(4) values.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from selftoktokenizer_amd import ops, synth, weights as W
+from selftoktokenizer_amd.config import default_config
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+GAP_TOL = 2e-4
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return W.synthetic_state_dict(W.expected_shapes(512), device="cuda")
+
+
+@pytest.fixture(scope="module")
+def encoder(sd):
+    from selftoktokenizer_amd.encoder import QformerEncoderGPU
+    return QformerEncoderGPU(sd, torch.device("cuda"), 512)
+
+
+@pytest.fixture(scope="module")
+def dit(sd):
+    from selftoktokenizer_amd.mmdit import MMDiTGPU
+    return MMDiTGPU(sd, torch.device("cuda"), 512)
+
+
+def test_encoder_features_and_ids(encoder):
+    g = gold("encoder_b2.npz")
+    x0 = synth.synthetic_latents(2, device="cuda")
+    z = encoder.features(x0)
+    err = float((z.cpu() - torch.from_numpy(g["z"])).abs().max())
+    print("encoder z max abs err", err)
+    assert err < 2e-4
+    outs_q, ids = encoder(x0, d=None)
+    assert ids.dtype == torch.int64 and tuple(ids.shape) == (2, 512)
+    ids = ids.cpu().numpy()
+    mism = ids != g["ids"]
+    print("e2e token match", 1.0 - mism.mean(), "gaps of mismatches", g["gap"][mism])
+    assert mism.mean() <= 0.01
+    assert (g["gap"][mism] < GAP_TOL).all()
+    # kernel boundary: feeding the reference's own features must give the reference's ids exactly
+    ids_k = ops.vq_encode(torch.from_numpy(g["z"]).cuda(), encoder.codebook_packed, packed=True).cpu().numpy()
+    np.testing.assert_array_equal(ids_k, g["ids"])
+    torch.testing.assert_close(outs_q.cpu()[~torch.from_numpy(mism)], torch.from_numpy(g["outs_q"])[~torch.from_numpy(mism)], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_dit_forward_vs_reference(dit, encoder, case):
+    g = gold("dit_forward_b1.npz")
+    ids = torch.from_numpy(synth.synthetic_token_ids(1)).cuda()
+    ehs = encoder.codes_ln(ids)
+    torch.testing.assert_close(ehs.cpu(), torch.from_numpy(g["ehs"]), rtol=1e-5, atol=1e-5)
+    x = synth.synthetic_noise(1, device="cuda")
+    t = torch.full((1,), float(g[f"t_{case}"]), device="cuda")
+    k = int(g[f"k_{case}"])
+    mask = (torch.arange(512, device="cuda")[None] <= k)
+    v, _ = dit(x, t, encoder_hidden_states=ehs, mask=mask, context_see_xt=True)
+    ref = torch.from_numpy(g[f"v_{case}"])
+    err = float((v.cpu() - ref).abs().max())
+    print(f"dit case {case} (k={k}) max abs err {err:.3e} of absmax {float(ref.abs().max()):.2f}")
+    assert err < 2e-3
+
+
+def test_dit_truncated_context_equals_masked(dit, encoder):
+    """sampler fast path (context truncated to k+1 tokens, no mask) == per-sample kvis path"""
+    ids = torch.from_numpy(synth.synthetic_token_ids(2)).cuda()
+    ehs = encoder.codes_ln(ids)
+    x = synth.synthetic_noise(2, device="cuda")
+    from selftoktokenizer_amd.encoder import sinusoid_host
+    tf = sinusoid_host(torch.tensor([620.0, 620.0])).cuda()
+    ctx0 = dit.embed_context(ehs)
+    y_fast = dit.velocity_tokens(x, tf, ctx0, 376, True)
+    kvis = torch.tensor([375, 375], dtype=torch.int32, device="cuda")
+    y_mask = dit.core(dit.embed_image(x), dit.time_embed(tf), ctx0, True, kvis)
+    torch.testing.assert_close(y_fast, y_mask, rtol=1e-4, atol=1e-4)
+
+
+def test_renderer_vs_reference():
+    g = gold("renderer_b1.npz")
+    from selftoktokenizer_amd.encoder import QformerEncoderGPU
+    from selftoktokenizer_amd.mmdit import MMDiTGPU
+    sd = W.synthetic_state_dict(W.expected_shapes(512, renderer=True), device="cuda")
+    enc = QformerEncoderGPU(sd, torch.device("cuda"), 512)
+    dit = MMDiTGPU(sd, torch.device("cuda"), 512, renderer=True)
+    ids = torch.from_numpy(g["ids"]).cuda()
+    out, _ = dit(y=None, encoder_hidden_states=enc.codes_ln(ids))
+    err = float((out.cpu() - torch.from_numpy(g["latent"])).abs().max())
+    print("renderer max abs err", err)
+    assert err < 2e-3
+
+
+def test_vae_vs_mirror():
+    """bf16 VAE: the reference arithmetic of record (diffusers) is unavailable; golden = in-repo mirror on CPU.
+    bf16 convolutions are not bit-reproducible across libraries, so compare at bf16 resolution."""
+    g = gold("vae_b1.npz")
+    from selftoktokenizer_amd.vae import AutoencoderKLGPU
+    vae = AutoencoderKLGPU(W.synthetic_vae_state_dict(), torch.device("cuda"))
+    img = synth.synthetic_images(1).to(torch.bfloat16)
+    mean = vae.encode(img.cuda())[0].mode().float().cpu()
+    ref = torch.from_numpy(g["mean"])
+    e1 = float((mean - ref).abs().max())
+    rec = vae.decode(synth.synthetic_latents(1).to(torch.bfloat16).cuda())[0].float().cpu()
+    ref2 = torch.from_numpy(g["rec"])
+    e2 = float((rec - ref2).abs().max())
+    mse = float(((rec - ref2) ** 2).mean())
+    print("vae enc err", e1, "dec err", e2, "dec psnr vs mirror (range 2)", 10 * np.log10(4.0 / mse))
+    assert e1 < 0.05 * float(ref.abs().max()) and e2 < 0.05 * float(ref2.abs().max())

@@ -1,0 +1,323 @@
+"""Generate tests/golden/*.npz by running the REFERENCE (read-only import, build container only) on the
+hash-generated synthetic weights/inputs, and report how oracle/ compares on the same inputs.
+
+    python tools/oracle/gen_golden.py [stage ...]      stages: keys vq schedule encoder dit vae pipeline renderer
+
+A golden file holds only data: inputs that cannot be regenerated from a seed, and the reference's
+outputs.  Weights/images/noise are regenerated from selftoktokenizer_amd.synth by name/seed.
+The generator's findings are appended to tests/golden/PINNING.json (max abs diffs oracle vs reference).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_harness as H  # noqa: E402
+from selftoktokenizer_amd import synth, weights as W  # noqa: E402
+from oracle import clib, model as OM, schedule as OS  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+CFG_256 = "/root/reference/configs/res256/256-eval.yml"
+CFG_RND = "/root/reference/configs/renderer/renderer-eval.yml"
+REPORT = {}
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def report(name, **kv):
+    REPORT[name] = {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in kv.items()}
+    print(f"[pin] {name}: {REPORT[name]}", flush=True)
+
+
+def maxdiff(a, b):
+    a = torch.as_tensor(a).float()
+    b = torch.as_tensor(b).float()
+    return float((a - b).abs().max())
+
+
+_tok = {}
+
+
+def tokenizer(cfg_path=CFG_256):
+    if cfg_path not in _tok:
+        _tok.clear()
+        t0 = time.time()
+        cfg = H.load_cfg(cfg_path)
+        model, ref_sd = H.build_tokenizer(cfg)
+        sd = {k: v for k, v in model.state_dict().items()}
+        print(f"[ref] built {cfg_path} in {time.time() - t0:.1f}s", flush=True)
+        _tok[cfg_path] = (cfg, model, sd)
+    return _tok[cfg_path]
+
+
+# ---------------------------------------------------------------------------------------------
+def stage_keys():
+    out = {}
+    for name, path, rnd in (("k512", CFG_256, False), ("renderer", CFG_RND, True)):
+        cfg, model, sd = tokenizer(path)
+        ref = {k: list(v.shape) for k, v in sd.items()}
+        mine = W.expected_shapes(512, renderer=rnd)
+        ref_nd = {k: v for k, v in ref.items() if not k.startswith("diffusion.")}
+        assert set(ref_nd) == set(mine), (set(ref_nd) ^ set(mine))
+        assert all(tuple(ref_nd[k]) == tuple(mine[k]) for k in mine)
+        out[name] = ref
+    with open(os.path.join(GOLD, "state_dict_keys.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    report("state_dict_keys", k512=len(out["k512"]), renderer=len(out["renderer"]))
+
+
+def stage_vq():
+    """reference VectorQuantize eval forward on small inputs incl. edge rows"""
+    cfg, model, sd = tokenizer(CFG_256)
+    vq = model.encoder.quantizer
+    cb = sd["encoder.quantizer._codebook.embed"][0]
+    z = synth.synthetic_vq_rows(1024, seed=0x901D).reshape(2, 512, 16).clone()
+    z[0, 0] = cb[77] * 3.0
+    z[0, 1] = 0.0
+    z[0, 2, 5] = float("nan")
+    z[0, 3, 0] = float("inf")
+    z[0, 4] = -cb[0]
+    z[0, 5] = cb[31000] * 0.5 + cb[12] * 1e-4
+    # feed z *after* project_in: call the codebook path the way VectorQuantize.forward does (:854, :876)
+    from mimogpt.models.selftok.vector_quantize_pytorch import l2norm
+    with torch.no_grad():
+        xn = l2norm(z)
+        quantize, ids, dist, _ = vq._codebook(xn)
+        best = dist.reshape(2, 512, -1).max(-1).values
+    ids_o, best_o = clib.vq_encode(z.reshape(-1, 16).numpy(), cb.numpy())
+    ok_ids = bool(np.array_equal(ids_o.reshape(2, 512), ids.numpy()))
+    nan = np.isnan(best.numpy().reshape(-1))
+    ok_best = bool(np.array_equal(bits(best_o)[~nan], bits(best.numpy().reshape(-1))[~nan]))
+    report("vq", ids_equal=ok_ids, best_bits_equal=ok_best, n=1024)
+    assert ok_ids and ok_best
+    # full VectorQuantize.forward (project_in + logging path) must return the same ids from features
+    feats = synth.hash_uniform(0xFEA7, (2, 512, 512), -1.0, 1.0)
+    with torch.no_grad():
+        q2, ids2, _, _ = vq(feats)
+        z2 = vq.project_in(feats)
+    ids2_o, _ = clib.vq_encode(z2.reshape(-1, 16).numpy(), cb.numpy())
+    assert np.array_equal(ids2_o.reshape(2, 512), ids2.numpy())
+    np.savez_compressed(os.path.join(GOLD, "vq_small.npz"), z=z.numpy(), ids=ids.numpy(), best_bits=bits(best.numpy()),
+                        z_proj=z2.numpy(), ids_proj=ids2.numpy())
+
+
+def stage_schedule():
+    from mimogpt.models.selftok.sd3.rectified_flow import RectifiedFlow
+    from mimogpt.models.selftok.diti_utils import DiTi_cont
+    out = {}
+    for steps in (50, 100):
+        flow = RectifiedFlow(steps, 1.0, None, val_schedule="uniform", shift=1.0, schedule="log_norm",
+                             parameterization="velocity", m=0.0, s=1.0, force_recon=False, is_eval=True)
+        mine = OS.make_schedule(steps)
+        for k in ("scheduled_t", "scheduled_t_prev", "timestep_map"):
+            assert np.array_equal(bits(getattr(flow, k).numpy()), bits(mine[k])), (steps, k)
+        t_long = torch.stack([torch.tensor([flow.timestep_map[i]]).long()[0] for i in range(steps)]).numpy()
+        assert np.array_equal(t_long, mine["t_long"])
+        out[f"scheduled_t_{steps}"] = bits(flow.scheduled_t.numpy())
+        out[f"scheduled_t_prev_{steps}"] = bits(flow.scheduled_t_prev.numpy())
+        out[f"timestep_map_{steps}"] = bits(flow.timestep_map.numpy())
+        out[f"t_long_{steps}"] = t_long
+    configs = {"k512": ("200,400,600,800,1000", "192,184,72,48,16", 512), "renderer": ("1000", "512", 512),
+               "k1024_assumed": ("200,400,600,800,1000", "384,368,144,96,32", 1024)}
+    all_t = torch.arange(0, 1001).long()
+    for name, (st, kp, K) in configs.items():
+        diti = DiTi_cont(1000, K, st, kp)
+        ref_all = diti.to_indices(all_t).numpy()
+        stg, kps = OS.parse_stages(st, kp)
+        mine_all = OS.diti_indices(all_t.numpy(), stg, kps, K)
+        assert np.array_equal(ref_all, mine_all), name
+        out[f"diti_{name}"] = ref_all
+        k50 = diti.to_indices(torch.from_numpy(out["t_long_50"])).numpy()
+        out[f"k50_{name}"] = k50
+        assert np.array_equal(k50, OS.k_table(50, stg, kps, K))
+    np.savez_compressed(os.path.join(GOLD, "schedule.npz"), **out)
+    report("schedule", ok=True, k50_k512=out["k50_k512"].tolist())
+
+
+def stage_encoder():
+    cfg, model, sd = tokenizer(CFG_256)
+    x0 = synth.synthetic_latents(2)
+    cap = {}
+    hk = model.encoder.quantizer.project_in.register_forward_hook(lambda m, i, o: cap.__setitem__("z", o.detach().clone()))
+    with torch.no_grad():
+        outs_q, ids = model.encoder(x0, d=None)
+    hk.remove()
+    z_o = OM.encoder_features(sd, x0)
+    ids_o = OM.vq_ids(sd, z_o)
+    match = float((ids_o == ids).float().mean())
+    report("encoder", z_maxdiff=maxdiff(z_o, cap["z"]), ids_match=match, z_absmax=float(cap["z"].abs().max()))
+    # gap (top1-top2) of the reference for every token: tells how fragile each id is
+    cb = sd["encoder.quantizer._codebook.embed"][0]
+    xn = torch.nn.functional.normalize(cap["z"].reshape(-1, 16), dim=-1)
+    top2 = (xn @ cb.T).topk(2, dim=-1).values
+    gap = (top2[:, 0] - top2[:, 1]).reshape(2, 512)
+    np.savez_compressed(os.path.join(GOLD, "encoder_b2.npz"), z=cap["z"].numpy(), ids=ids.numpy(),
+                        outs_q=outs_q.numpy(), gap=gap.numpy())
+
+
+def stage_dit():
+    cfg, model, sd = tokenizer(CFG_256)
+    ids = torch.from_numpy(synth.synthetic_token_ids(1))
+    with torch.no_grad():
+        codes = model.encoder.quantizer.get_output_from_indices(ids)
+        ehs = model.encoder.final_layer_norm3(codes.reshape(1, -1, 16))
+    assert maxdiff(OM.codes_from_ids(sd, ids), ehs) < 1e-6
+    x = synth.synthetic_noise(1)
+    out = {"ehs": ehs.numpy()}
+    for name, tval, k in (("a", 0.62, 375), ("b", 0.02, 19), ("c", 1.0, 511)):
+        t = torch.full((1,), tval)
+        mask = torch.arange(512)[None] <= k
+        with torch.no_grad():
+            v, _ = model.model(x, t, encoder_hidden_states=ehs, mask=mask, context_see_xt=True)
+        v_o = OM.dit_forward(sd, x, t, ehs, mask, True)
+        report(f"dit_{name}", v_maxdiff=maxdiff(v, v_o), v_absmax=float(v.abs().max()))
+        out[f"v_{name}"] = v.numpy()
+        out[f"t_{name}"] = np.float32(tval)
+        out[f"k_{name}"] = np.int64(k)
+    np.savez_compressed(os.path.join(GOLD, "dit_forward_b1.npz"), **out)
+
+
+class _MirrorVAE:
+    """diffusers' AutoencoderKL surface (`encode(x)[0].mode()`, `decode(z)[0]`) over the in-repo SDVAE mirror."""
+
+    def __init__(self, vae):
+        self.vae = vae
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None):
+        from mimogpt.models.selftok.sd3.sd3_impls import SDVAE
+        with H.fast_init():
+            vae = SDVAE(dtype=torch.bfloat16, device="cpu")
+        vsd = W.synthetic_vae_state_dict()
+        ldm = {}
+        ref_sd = vae.state_dict()
+        for k, v in vsd.items():
+            k2 = W.diffusers_to_ldm_key(k)
+            ldm[k2] = v.reshape(ref_sd[k2].shape)
+        vae.load_state_dict(ldm, strict=True)
+        return cls(vae)
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def encode(self, x, return_dict=False):
+        class _D:
+            def __init__(s, h):
+                s.h = h
+
+            def mode(s):
+                return s.h.chunk(2, dim=1)[0]
+        with torch.no_grad():
+            return (_D(self.vae.encoder(x)),)
+
+    def decode(self, z, return_dict=False):
+        with torch.no_grad():
+            return (self.vae.decoder(z),)
+
+
+def stage_vae():
+    H.install()
+    vae = _MirrorVAE.from_pretrained(None)
+    vsd = W.synthetic_vae_state_dict()
+    img = synth.synthetic_images(1).to(torch.bfloat16)
+    mean = vae.encode(img)[0].mode()
+    mean_o = OM.vae_encode_mean(vsd, img)
+    z = synth.synthetic_latents(1).to(torch.bfloat16)
+    rec = vae.decode(z)[0]
+    rec_o = OM.vae_decode(vsd, z)
+    report("vae", enc_maxdiff=maxdiff(mean, mean_o), dec_maxdiff=maxdiff(rec, rec_o),
+           enc_absmax=float(mean.float().abs().max()), dec_absmax=float(rec.float().abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "vae_b1.npz"), mean=mean.float().numpy(), rec=rec.float().numpy())
+
+
+def stage_pipeline():
+    """the real SelftokPipeline class end to end, B=1, 50 steps (takes a few minutes on 8 cores)"""
+    H.install()
+    import mimogpt.infer.SelftokPipeline as SP
+    cfg = H.load_cfg(CFG_256)
+    SP.AutoencoderKL = _MirrorVAE
+    shapes = W.expected_shapes(512)
+    real_load = torch.load
+    torch.load = lambda *a, **k: W.synthetic_state_dict(shapes)
+    try:
+        with H.fast_init():
+            pipe = SP.SelftokPipeline(cfg=cfg, ckpt_path="synthetic", sd3_path="synthetic", datasize=256, device="cpu")
+    finally:
+        torch.load = real_load
+    sd = dict(pipe.model.state_dict())
+    vsd = W.synthetic_vae_state_dict()
+    images = synth.synthetic_images(1)
+    t0 = time.time()
+    tokens = pipe.encoding(images, device="cpu")
+    print(f"[ref] encoding {time.time() - t0:.1f}s", flush=True)
+    tok_o = OM.pipeline_encode(sd, vsd, images)
+    report("pipeline_encode", ids_match=float((tok_o == tokens).float().mean()))
+    # decode with hash noise instead of torch.randn, capturing the DiT input latent of a few steps
+    noise = synth.synthetic_noise(1)
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: noise.clone()
+    xs = []
+    hk = pipe.model.model.register_forward_pre_hook(lambda m, args: xs.append(args[0].detach().clone()))
+    t0 = time.time()
+    try:
+        rec = pipe.decoding(tokens.numpy(), device="cpu")
+    finally:
+        torch.randn = real_randn
+        hk.remove()
+    print(f"[ref] decoding {time.time() - t0:.1f}s", flush=True)
+    assert len(xs) == 50
+    stg, kps = OS.parse_stages(cfg.tokenizer.params.stages, cfg.tokenizer.params.k_per_stage)
+    trace = []
+    t0 = time.time()
+    rec_o, lat_o = OM.pipeline_decode(sd, vsd, tokens.numpy(), noise, stg, kps, 50)
+    print(f"[oracle] decoding {time.time() - t0:.1f}s", flush=True)
+    mse = float(((rec.float() - rec_o.float()) ** 2).mean())
+    report("pipeline_decode", pix_maxdiff=maxdiff(rec, rec_o), psnr_oracle_vs_ref=(10 * np.log10(1.0 / mse) if mse > 0 else 999.0))
+    keep = [1, 2, 5, 10, 25, 49]
+    np.savez_compressed(os.path.join(GOLD, "pipeline_b1.npz"), tokens=tokens.numpy(),
+                        rec_bf16=rec.view(torch.int16).numpy(), lat_steps=np.array(keep),
+                        lats=np.stack([xs[i].numpy() for i in keep]))
+
+
+def stage_renderer():
+    cfg, model, sd = tokenizer(CFG_RND)
+    ids = torch.from_numpy(synth.synthetic_token_ids(1, first_index=7))
+    with torch.no_grad():
+        codes = model.encoder.quantizer.get_output_from_indices(ids)
+        ehs = model.encoder.final_layer_norm3(codes.reshape(1, -1, 16))
+        out, _ = model.model(y=None, encoder_hidden_states=ehs)
+    out_o = OM.renderer_forward(sd, ehs)
+    report("renderer", maxdiff=maxdiff(out, out_o), absmax=float(out.abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "renderer_b1.npz"), ids=ids.numpy(), latent=out.numpy())
+
+
+STAGES = dict(keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
+              vae=stage_vae, pipeline=stage_pipeline, renderer=stage_renderer)
+
+if __name__ == "__main__":
+    torch.set_grad_enabled(False)
+    os.makedirs(GOLD, exist_ok=True)
+    names = sys.argv[1:] or ["vq", "schedule", "encoder", "dit", "vae", "pipeline", "keys", "renderer"]
+    for n in names:
+        t0 = time.time()
+        STAGES[n]()
+        print(f"[stage] {n} done in {time.time() - t0:.1f}s", flush=True)
+    path = os.path.join(GOLD, "PINNING.json")
+    old = json.load(open(path)) if os.path.exists(path) else {}
+    old.update(REPORT)
+    json.dump(old, open(path, "w"), indent=1, sort_keys=True)
