@@ -53,6 +53,12 @@ int selftok_vq_pack_codebook(const float* codebook, float* packed, int C, int D,
 int selftok_vq_encode_packed_f32(const float* z, const float* packed, void* ids, float* best, void* workspace,
                                  int N, int C, int D, int flags, hipStream_t stream);
 
+/* The two launches of selftok_vq_encode_packed_f32, separately callable (bench.py times the main kernel alone):
+ * partial = per-(code split,row) 64-bit keys (orderable(best)<<32 | ~idx) in `workspace`; finalize = max over splits. */
+int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, void* workspace, int* nsplit_out,
+                                         int N, int C, int D, int flags, hipStream_t stream);
+int selftok_vq_finalize(const void* workspace, void* ids, float* best, int N, int nsplit, int flags, hipStream_t stream);
+
 /* ---- code gather + LayerNorm(16) ----------------------------------------------------------
  * Replaces quantizer.get_output_from_indices (vector_quantize_pytorch.py:787-809) followed by
  * encoder.final_layer_norm3 (SelftokPipeline.py:236-240; models_ours.py:88).  out [n,16].

@@ -430,10 +430,12 @@ int selftok_vq_encode_f32(const float* z, const float* codebook, void* ids, floa
     return check_launch("vq_finalize_kernel");
 }
 
-int selftok_vq_encode_packed_f32(const float* z, const float* packed, void* ids, float* best, void* workspace,
-                                 int N, int C, int Dm, int flags, hipStream_t stream)
+// Main kernel only: per-(split,row) keys into `workspace`; *nsplit_out receives the number of code splits.
+int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, void* workspace, int* nsplit_out,
+                                         int N, int C, int Dm, int flags, hipStream_t stream)
 {
-    if (Dm != D || C <= 0 || (C & 31) || N < 0 || !z || !packed || !ids || !workspace) { set_last_error("vq_encode_packed: bad argument"); return SELFTOK_EINVAL; }
+    if (Dm != D || C <= 0 || (C & 31) || N < 0 || !z || !packed || !workspace || !nsplit_out) { set_last_error("vq_argmax_partial_packed: bad argument"); return SELFTOK_EINVAL; }
+    *nsplit_out = 0;
     if (N == 0) return SELFTOK_OK;
     unsigned long long* partial = (unsigned long long*)workspace;
     const int ntiles = C >> 5;
@@ -443,15 +445,33 @@ int selftok_vq_encode_packed_f32(const float* z, const float* packed, void* ids,
     int split = pick_split(row_blocks, ntiles, 64);
     int tps = (ntiles + split - 1) / split;
     split = (ntiles + tps - 1) / tps;
+    *nsplit_out = split;
     dim3 grid(row_blocks, split), block(256);
     if (rt == 4) hipLaunchKernelGGL(vq_mfma_kernel<4>, grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
     else if (rt == 2) hipLaunchKernelGGL(vq_mfma_kernel<2>, grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
     else hipLaunchKernelGGL(vq_mfma_kernel<1>, grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
-    int rc = check_launch("vq_mfma_kernel");
-    if (rc) return rc;
-    if (flags & 1) hipLaunchKernelGGL(vq_finalize_kernel<int32_t>, dim3((N + 255) / 256), dim3(256), 0, stream, partial, (int32_t*)ids, best, N, split);
-    else hipLaunchKernelGGL(vq_finalize_kernel<long long>, dim3((N + 255) / 256), dim3(256), 0, stream, partial, (long long*)ids, best, N, split);
+    return check_launch("vq_mfma_kernel");
+}
+
+// Reduce the code splits of a partial pass: ids (int64, or int32 with SELFTOK_IDS_I32) and optional top-1 score.
+int selftok_vq_finalize(const void* workspace, void* ids, float* best, int N, int nsplit, int flags, hipStream_t stream)
+{
+    if (!workspace || !ids || N < 0 || nsplit <= 0) { set_last_error("vq_finalize: bad argument"); return SELFTOK_EINVAL; }
+    if (N == 0) return SELFTOK_OK;
+    const unsigned long long* partial = (const unsigned long long*)workspace;
+    if (flags & 1) hipLaunchKernelGGL(vq_finalize_kernel<int32_t>, dim3((N + 255) / 256), dim3(256), 0, stream, partial, (int32_t*)ids, best, N, nsplit);
+    else hipLaunchKernelGGL(vq_finalize_kernel<long long>, dim3((N + 255) / 256), dim3(256), 0, stream, partial, (long long*)ids, best, N, nsplit);
     return check_launch("vq_finalize_kernel");
+}
+
+int selftok_vq_encode_packed_f32(const float* z, const float* packed, void* ids, float* best, void* workspace,
+                                 int N, int C, int Dm, int flags, hipStream_t stream)
+{
+    if (!ids) { set_last_error("vq_encode_packed: bad argument"); return SELFTOK_EINVAL; }
+    int split = 0;
+    int rc = selftok_vq_argmax_partial_packed_f32(z, packed, workspace, &split, N, C, Dm, flags, stream);
+    if (rc || N == 0) return rc;
+    return selftok_vq_finalize(workspace, ids, best, N, split, flags, stream);
 }
 
 // flags bit0: ids are int32 (default int64).  ln_w/ln_b may be NULL (plain gather).

@@ -1,0 +1,70 @@
+"""Batch sharding of the encode/decode path across the GPUs of one node (one process per GPU).
+
+Images are independent units on the eval path (no cross-sample op anywhere; weights and codebook are
+read-only replicas), so the path shards by batch with NO data-path collective inside encode or decode.
+The single exchange is an all-gather of the token ids after encode ([B_local,K] int32: 128 KiB per
+rank at B_local=64) so that every rank holds the full id matrix -- RCCL over xGMI through
+torch.distributed's "nccl" backend on ROCm; "gloo" on CPU for the world_size-2 tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from torchrun's env; initialises the default process group if world > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """contiguous slice [lo, hi) of `total` images owned by `rank` (remainder spread over the first ranks)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_ids(ids_local: torch.Tensor) -> torch.Tensor:
+    """[B_local,K] token ids (any int dtype) -> [B_total,K] on every rank, in rank order.
+    The payload travels as int32 (ids < 2^15); uneven shards are padded to the largest shard."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return ids_local
+    world = dist.get_world_size()
+    K = ids_local.shape[1]
+    n_local = torch.tensor([ids_local.shape[0]], dtype=torch.int64, device=ids_local.device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local)
+    counts = [int(c.item()) for c in counts]
+    nmax = max(counts)
+    send = torch.zeros(nmax, K, dtype=torch.int32, device=ids_local.device)
+    send[: ids_local.shape[0]] = ids_local.to(torch.int32)
+    bufs = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(bufs, send)                       # ncclAllGather over xGMI on the GPU box
+    return torch.cat([bufs[r][: counts[r]] for r in range(world)]).to(ids_local.dtype)
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -254,3 +254,26 @@ def clamp01_(img):
     assert img.dtype == torch.bfloat16 and img.is_contiguous()
     _lib.check(_lib.load().selftok_clamp01_bf16(_p(img), img.numel(), _stream()), "selftok_clamp01_bf16")
     return img
+
+
+def vq_encode_split_launch(z, packed_codebook, ids_dtype=torch.int64):
+    """Same result as vq_encode(packed=True) but returns (ids, launch_main, launch_finalize) closures so a
+    benchmark can time the main argmax kernel alone (HIP events around launch_main on the current stream)."""
+    import ctypes
+    lib = _lib.load()
+    zz = z.contiguous().float().reshape(-1, z.shape[-1])
+    N, D = zz.shape
+    C = packed_codebook.shape[0]
+    ids = torch.empty(N, dtype=ids_dtype, device=z.device)
+    ws = torch.empty(lib.selftok_vq_workspace_bytes(N, C), dtype=torch.uint8, device=z.device)
+    flags = IDS_I32 if ids_dtype == torch.int32 else 0
+    nsplit = ctypes.c_int(0)
+
+    def launch_main():
+        _lib.check(lib.selftok_vq_argmax_partial_packed_f32(_p(zz), _p(packed_codebook), _p(ws), ctypes.addressof(nsplit), N, C, D,
+                                                            flags, _stream()), "selftok_vq_argmax_partial_packed_f32")
+
+    def launch_finalize():
+        _lib.check(lib.selftok_vq_finalize(_p(ws), _p(ids), None, N, nsplit.value, flags, _stream()), "selftok_vq_finalize")
+
+    return ids.reshape(z.shape[:-1]), launch_main, launch_finalize

@@ -129,7 +129,8 @@ class SelftokPipeline():
         vsd = vae_state_dict if vae_state_dict is not None else W.load_vae_checkpoint(sd3_path)
         self.vae = AutoencoderKLGPU(vsd, self.device, dtype)
 
-        print("Loading all...")
+        self.verbose = True
+        self._say("Loading all...")
         sd = state_dict if state_dict is not None else W.load_tokenizer_checkpoint(ckpt_path)
         self.ema_decoder = ema_decoder
         dit_sd = sd
@@ -150,6 +151,10 @@ class SelftokPipeline():
         self.cond_vary = True
         self.saved_images = 8
 
+    def _say(self, msg):
+        if self.verbose:          # the reference prints these progress lines unconditionally (:192,212,223,230,292,299,320)
+            print(msg)
+
     # ------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def encode_latents(self, images: torch.Tensor) -> torch.Tensor:
@@ -159,10 +164,10 @@ class SelftokPipeline():
 
     @torch.no_grad()
     def encoding(self, images, device=None):
-        print("Begin encoding.")
+        self._say("Begin encoding.")
         x_0 = self.encode_latents(images)
         _, tokens = self.model.encoder(x_0, d=None)
-        print('End encoding.')
+        self._say('End encoding.')
         return tokens
 
     @torch.no_grad()
@@ -182,7 +187,7 @@ class SelftokPipeline():
                  max_steps: Optional[int] = None, uncond_scale: float = 1.0):
         """idx: np.ndarray int64 [B,K] -> bf16 [B,3,H,W] in [0,1] (reference :227-294).  `noise` (extension) replaces the
         `torch.randn` draw from the global CPU generator (:264); `uncond_scale` exposes the dormant CFG branch."""
-        print("Begin decoding.")
+        self._say("Begin decoding.")
         outs_q = self._codes(idx)
         B = outs_q.shape[0]
         # t_mapped = timestep_map[0] -> k = K-1 -> enc_mask all true -> encoder_hidden_states = outs_q (:243-252)
@@ -193,15 +198,15 @@ class SelftokPipeline():
         pred_x0 = self.flow.p_sample_loop(self.model.model, xt, ehs, self.k_table, context_see_xt=True,
                                           uncond_scale=uncond_scale, max_steps=max_steps)
         recons = self._to_pixels(pred_x0)
-        print('End decoding.')
+        self._say('End decoding.')
         return (recons, pred_x0) if return_latent else recons
 
     @torch.no_grad()
     def decoding_with_renderer(self, idx, device=None, return_latent: bool = False):
         """one MMDiT_Renderer pass instead of the 50-step loop (reference :296-322)"""
-        print("Begin decoding with Renderer.")
+        self._say("Begin decoding with Renderer.")
         outs_q = self._codes(idx)
         pred_x0, _ = self.model.model(y=None, encoder_hidden_states=outs_q)
         recons = self._to_pixels(pred_x0)
-        print('End decoding with Renderer.')
+        self._say('End decoding with Renderer.')
         return (recons, pred_x0) if return_latent else recons

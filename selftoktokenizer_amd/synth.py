@@ -49,7 +49,7 @@ def hash_uniform(seed: int, shape, lo=-1.0, hi=1.0, device="cpu") -> torch.Tenso
     """fp32 tensor ~ U[lo, hi): u = (h>>8)*2^-24 is exact; one rounding in the affine map."""
     n = int(np.prod(shape)) if len(shape) else 1
     out = torch.empty(n, dtype=torch.float32, device=device)
-    chunk = 1 << 24
+    chunk = (1 << 24) if str(device).startswith("cuda") else (1 << 18)   # cache-resident chunks on CPU (8x faster)
     for s in range(0, n, chunk):
         m = min(chunk, n - s)
         h = hash_u32(seed, m, device=device, offset=s)

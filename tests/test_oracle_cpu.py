@@ -1,0 +1,134 @@
+"""not gpu: the CPU oracle (oracle/) against the golden vectors captured from the reference itself
+(tools/oracle/gen_golden.py, tests/golden/).  This is what pins the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clib, model as OM, schedule as OS
+from selftoktokenizer_amd import synth, weights as W
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def codebook():
+    return W._synth_tensor("encoder.quantizer._codebook.embed", (1, 32768, 16), "cpu")[0].contiguous()
+
+
+def test_vq_oracle_matches_reference_bits(codebook):
+    """reference CosineSimCodebook.forward (eval) on 1024 rows incl. tie / zero / NaN / inf rows"""
+    g = gold("vq_small.npz")
+    z = g["z"].reshape(-1, 16)
+    ids, best = clib.vq_encode(z, codebook.numpy())
+    np.testing.assert_array_equal(ids.reshape(2, 512), g["ids"])
+    ref = g["best_bits"].reshape(-1).view(np.float32)
+    nan = np.isnan(ref)
+    assert nan.sum() >= 2                                     # the NaN and inf rows
+    np.testing.assert_array_equal(np.isnan(best), nan)
+    np.testing.assert_array_equal(bits(best)[~nan], bits(ref)[~nan])
+    assert ids[0] == 77 and ids[1] == 0 and ids[2] == 0 and ids[3] == 0   # duplicate code -> lowest; zero row; NaN rows
+    # through project_in (full VectorQuantize.forward of the reference)
+    ids2, _ = clib.vq_encode(g["z_proj"].reshape(-1, 16), codebook.numpy())
+    np.testing.assert_array_equal(ids2.reshape(2, 512), g["ids_proj"])
+
+
+def test_l2norm_and_scores_match_torch_cpu(codebook):
+    z = synth.synthetic_vq_rows(777, seed=42)
+    xn = torch.nn.functional.normalize(z, p=2, dim=-1)
+    np.testing.assert_array_equal(bits(clib.l2norm16(z.numpy())), bits(xn.numpy()))
+    cb = codebook[:4096]
+    dist = torch.einsum("hnd,hcd->hnc", xn[None], cb[None])[0]
+    np.testing.assert_array_equal(bits(clib.vq_scores(xn.numpy(), cb.numpy())), bits(dist.numpy()))
+
+
+def test_vq_edge_cases(codebook):
+    cb = codebook.numpy().copy()
+    ids, _ = clib.vq_encode(np.zeros((0, 16), np.float32), cb)
+    assert ids.shape == (0,)
+    cb[5] = np.nan
+    ids, best = clib.vq_encode(synth.synthetic_vq_rows(9).numpy(), cb)
+    assert (ids == 5).all() and np.isnan(best).all()          # a NaN score is the maximum
+    assert np.array_equal(clib.code_gather(np.array([[3, 1]]), cb)[0, 1], cb[1])
+
+
+def test_schedule_matches_reference():
+    g = gold("schedule.npz")
+    for n in (50, 100):
+        s = OS.make_schedule(n)
+        np.testing.assert_array_equal(bits(s["scheduled_t"]), g[f"scheduled_t_{n}"])
+        np.testing.assert_array_equal(bits(s["scheduled_t_prev"]), g[f"scheduled_t_prev_{n}"])
+        np.testing.assert_array_equal(bits(s["timestep_map"]), g[f"timestep_map_{n}"])
+        np.testing.assert_array_equal(s["t_long"], g[f"t_long_{n}"])
+    assert 459 in g["t_long_50"] and 460 not in g["t_long_50"]          # the float-fragile truncation
+    for name, st, kp, K in (("k512", "200,400,600,800,1000", "192,184,72,48,16", 512), ("renderer", "1000", "512", 512),
+                            ("k1024_assumed", "200,400,600,800,1000", "384,368,144,96,32", 1024)):
+        stg, kps = OS.parse_stages(st, kp)
+        np.testing.assert_array_equal(OS.diti_indices(np.arange(1001), stg, kps, K), g[f"diti_{name}"])
+        np.testing.assert_array_equal(OS.k_table(50, stg, kps, K), g[f"k50_{name}"])
+    assert g["k50_k512"][0] == 511 and g["k50_k512"][-1] == 19
+
+
+def test_encoder_oracle_matches_reference():
+    g = gold("encoder_b2.npz")
+    shapes = {k: v for k, v in W.expected_shapes(512).items() if k.startswith("encoder.")}
+    sd = W.synthetic_state_dict(shapes)
+    x0 = synth.synthetic_latents(2)
+    z = OM.encoder_features(sd, x0)
+    assert float((z - torch.from_numpy(g["z"])).abs().max()) <= 1e-6
+    ids = OM.vq_ids(sd, z)
+    np.testing.assert_array_equal(ids.numpy(), g["ids"])
+    torch.testing.assert_close(OM.codes_from_ids(sd, ids), torch.from_numpy(g["outs_q"]), rtol=0, atol=1e-6)
+    m = OM.joint_mask(torch.arange(512)[None] <= 19, 256, True)
+    assert m.shape == (1, 1, 768, 768) and int(m[0, 0, 0].sum()) == 20 + 256
+    assert int(OM.joint_mask(torch.arange(512)[None] <= 19, 256, False)[0, 0, 0].sum()) == 20
+
+
+def test_vae_oracle_close_to_mirror():
+    """bf16: not bit-reproducible between formulations (conv1x1 vs linear attention), compare at bf16 resolution"""
+    g = gold("vae_b1.npz")
+    vsd = W.synthetic_vae_state_dict()
+    mean = OM.vae_encode_mean(vsd, synth.synthetic_images(1).to(torch.bfloat16)).float()
+    assert float((mean - torch.from_numpy(g["mean"])).abs().max()) < 0.05
+    # process_in / process_out / norm_ip dtype hand-offs
+    z = OM.process_in(mean.to(torch.bfloat16))
+    assert z.dtype == torch.bfloat16
+    img = OM.norm_ip(torch.tensor([-2.0, -1.0, 0.0, 0.5, 3.0], dtype=torch.bfloat16))
+    assert img.tolist() == [0.0, 0.0, 0.5, 0.75, 1.0]
+
+
+@pytest.mark.slow
+def test_dit_oracle_matches_reference():
+    """2.09 B synthetic parameters on CPU (~1-2 min): MMDiT.forward of the reference for three (t, k) pairs"""
+    g = gold("dit_forward_b1.npz")
+    shapes = W.expected_shapes(512)
+    sd = W.synthetic_state_dict({k: v for k, v in shapes.items() if k.startswith("model.") or "final_layer_norm3" in k or "_codebook.embed" == k[-15:]})
+    ids = torch.from_numpy(synth.synthetic_token_ids(1))
+    ehs = OM.codes_from_ids(sd, ids)
+    torch.testing.assert_close(ehs, torch.from_numpy(g["ehs"]), rtol=0, atol=1e-6)
+    x = synth.synthetic_noise(1)
+    tables = OM.dit_ctx_tables(sd, 512)
+    for case in "abc":
+        t = torch.full((1,), float(g[f"t_{case}"]))
+        mask = torch.arange(512)[None] <= int(g[f"k_{case}"])
+        v = OM.dit_forward(sd, x, t, ehs, mask, True, tables)
+        assert float((v - torch.from_numpy(g[f"v_{case}"])).abs().max()) <= 1e-5
+
+
+def test_pinning_report_is_committed():
+    rep = json.load(open(os.path.join(GOLD, "PINNING.json")))
+    assert rep["vq"]["ids_equal"] and rep["vq"]["best_bits_equal"]
+    assert rep["encoder"]["z_maxdiff"] == 0.0 and rep["encoder"]["ids_match"] == 1.0
+    for k in ("dit_a", "dit_b", "dit_c"):
+        assert rep[k]["v_maxdiff"] == 0.0
+    assert rep["renderer"]["maxdiff"] == 0.0

@@ -1,0 +1,85 @@
+"""-m gpu: SelftokPipeline (drop-in API, through the `mimogpt.infer` import path) end to end against the
+reference's own pipeline run on the same synthetic weights (tests/golden/pipeline_b1.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from selftoktokenizer_amd import synth, weights as W
+from selftoktokenizer_amd.config import default_config
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    from mimogpt.infer.SelftokPipeline import SelftokPipeline
+    sd = W.synthetic_state_dict(W.expected_shapes(512), device="cuda")
+    p = SelftokPipeline(default_config(512), ckpt_path=None, sd3_path=None, device="cuda", state_dict=sd,
+                        vae_state_dict=W.synthetic_vae_state_dict(device="cuda"))
+    p.verbose = False
+    return p
+
+
+def test_api_surface(pipe):
+    assert pipe.K == 512 and pipe._steps == 50
+    assert hasattr(pipe, "vae") and hasattr(pipe, "flow") and hasattr(pipe.model, "encoder") and hasattr(pipe.model, "model")
+    assert pipe.flow.timestep_map.shape == (50,)
+    with pytest.raises(ValueError):
+        from mimogpt.infer.SelftokPipeline import SelftokPipeline
+        SelftokPipeline(default_config(512), None, None, model_type="sdxl", device="cuda")
+
+
+def test_encoding_vs_reference(pipe):
+    g = np.load(os.path.join(GOLD, "pipeline_b1.npz"))
+    tokens = pipe.encoding(synth.synthetic_images(1), device="cuda")
+    assert tokens.dtype == torch.int64 and tokens.is_cuda and tuple(tokens.shape) == (1, 512)
+    match = float((tokens.cpu().numpy() == g["tokens"]).mean())
+    print("e2e token-id exact match vs reference pipeline (bf16 VAE upstream):", match)
+    assert match >= 0.98
+
+
+def test_decoding_vs_reference(pipe):
+    g = np.load(os.path.join(GOLD, "pipeline_b1.npz"))
+    noise = synth.synthetic_noise(1)
+    trace = []
+    real = pipe.flow.p_sample_loop
+
+    def traced(*a, **k):
+        return real(*a, trace=trace, **k)
+    pipe.flow.p_sample_loop = traced
+    try:
+        rec = pipe.decoding(g["tokens"], device="cuda", noise=noise)
+    finally:
+        pipe.flow.p_sample_loop = real
+    assert rec.dtype == torch.bfloat16 and tuple(rec.shape) == (1, 3, 256, 256)
+    assert float(rec.min()) >= 0.0 and float(rec.max()) <= 1.0
+    for j, step in enumerate(g["lat_steps"]):          # golden lats[j] = DiT input at step `step` = latent after `step` Euler steps
+        err = float((trace[int(step) - 1].cpu() - torch.from_numpy(g["lats"][j])).abs().max())
+        print(f"latent after {int(step)} steps: max abs err {err:.3e}")
+        assert err < 5e-3
+    ref = torch.from_numpy(g["rec_bf16"]).view(torch.bfloat16).float()
+    mse = float(((rec.float().cpu() - ref) ** 2).mean())
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-12))
+    print("pixel PSNR vs reference pipeline output:", psnr)
+    assert psnr > 38.0
+
+
+def test_decode_is_deterministic_and_batch_independent(pipe):
+    ids = synth.synthetic_token_ids(3)
+    noise = synth.synthetic_noise(3)
+    a, la = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=3)
+    b, lb = pipe.decoding(ids[1:2], noise=noise[1:2], return_latent=True, max_steps=3)
+    torch.testing.assert_close(la[1:2], lb, rtol=1e-4, atol=1e-4)
+    a2, la2 = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=3)
+    assert torch.equal(la, la2)                      # tokenizer/DiT path is bit-deterministic run to run
+    # the bf16 VAE convolutions (MIOpen) are not: allow bf16-ulp noise on the pixels
+    assert float((a.float() - a2.float()).abs().max()) < 0.05
+
+
+def test_cfg_branch_runs(pipe):
+    ids = synth.synthetic_token_ids(1)
+    rec, lat = pipe.decoding(ids, noise=synth.synthetic_noise(1), return_latent=True, max_steps=2, uncond_scale=2.0)
+    assert torch.isfinite(lat).all()
