@@ -47,17 +47,21 @@ const char* selftok_last_error(void);
 size_t selftok_vq_workspace_bytes(int N, int C);
 int selftok_vq_encode_f32(const float* z, const float* codebook, void* ids, float* best, void* workspace,
                           int N, int C, int D, int flags, hipStream_t stream);
-/* One-time re-layout of the (constant) codebook into MFMA fragment order, C % 32 == 0. */
+/* One-time re-layout of the (constant) codebook into MFMA fragment order, C % 32 == 0.  `packed` must hold
+ * selftok_vq_packed_bytes(C,D) bytes (= the codebook + one metadata line: a "non-finite code present" flag). */
+size_t selftok_vq_packed_bytes(int C, int D);
 int selftok_vq_pack_codebook(const float* codebook, float* packed, int C, int D, hipStream_t stream);
 /* Same contract as selftok_vq_encode_f32 on the packed codebook (v_mfma_f32_32x32x2_f32 path). */
 int selftok_vq_encode_packed_f32(const float* z, const float* packed, void* ids, float* best, void* workspace,
                                  int N, int C, int D, int flags, hipStream_t stream);
 
 /* The two launches of selftok_vq_encode_packed_f32, separately callable (bench.py times the main kernel alone):
- * partial = per-(code split,row) 64-bit keys (orderable(best)<<32 | ~idx) in `workspace`; finalize = max over splits. */
+ * partial = per-(code split, wave half, row) candidates (orderable(best)<<32 | winning tile) in `workspace`;
+ * finalize = max over candidates + exact slot recovery inside the winning tile (needs z and the packed codebook). */
 int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, void* workspace, int* nsplit_out,
                                          int N, int C, int D, int flags, hipStream_t stream);
-int selftok_vq_finalize(const void* workspace, void* ids, float* best, int N, int nsplit, int flags, hipStream_t stream);
+int selftok_vq_finalize_packed(const void* workspace, const float* z, const float* packed, void* ids, float* best,
+                               int N, int C, int D, int nsplit, int flags, hipStream_t stream);
 
 /* ---- code gather + LayerNorm(16) ----------------------------------------------------------
  * Replaces quantizer.get_output_from_indices (vector_quantize_pytorch.py:787-809) followed by

@@ -27,6 +27,7 @@
 //
 // This file is compiled with -ffp-contract=off: every FMA below is explicit.
 #include "common.h"
+#include <stdlib.h>
 
 namespace selftok {
 
@@ -238,13 +239,71 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // packed layout: tile t (32 codes) = 512 floats; lane l = (h = l>>5, i = l&31) owns 8 consecutive
 // floats e[t*32+i][2m+h], m = 0..7  -- exactly the A fragments of the 8 chained 32x32x2 MFMAs.
+// The word after the last tile (packed[C*16], zeroed by the caller) becomes non-zero if any code element could make a
+// score non-finite; the MFMA kernel then runs its exact NaN-aware scan instead of the fast one.
 __global__ void vq_pack_kernel(const float* __restrict__ cb, float* __restrict__ packed, int C)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (code, k)
     if (g >= C * D) return;
     int c = g >> 4, k = g & 15;
     int t = c >> 5, i = c & 31, h = k & 1, m = k >> 1;
-    packed[(size_t)t * 512 + (h * 32 + i) * 8 + m] = cb[g];
+    const float v = cb[g];
+    packed[(size_t)t * 512 + (h * 32 + i) * 8 + m] = v;
+    if (suspicious(v)) atomicOr(reinterpret_cast<unsigned int*>(packed) + (size_t)C * D, 1u);
+}
+
+// running best of one lane for one x-row, MFMA flavour: the index is kept as (tile, register slot) so that the
+// per-score update is cmp + 2 cndmask with inline constants; code = tile*32 + (slot&3) + 8*(slot>>2) + 4*half.
+struct BestT {
+    float v;     // +inf once the best is a NaN
+    int tile;
+    int slot;
+    bool nan;
+};
+
+// fast scan: only (max value, tile) are tracked -- 7 v_max3 + cmp + 2 cndmask per 16 scores instead of 48 ops.
+// On gfx950 the fp32-input MFMA runs on the fp32 VALU lanes (measured: every VALU op costs ~3-4 MFMA-pipe cycles,
+// tools/microbench/mfma_valu.hip), so scan instructions are not free: the slot inside the winning tile is
+// recovered later by vq_finalize_packed_kernel, which recomputes the 16 candidate scores of that (tile, half).
+__device__ __forceinline__ void scanmax(BestT& b, const f32x16& acc, int tile)
+{
+    float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
+    float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
+    float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]);
+    float m3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
+    float m4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
+    float m5 = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2);
+    float m6 = __builtin_fmaxf(__builtin_fmaxf(m3, m4), acc[15]);
+    const float m = __builtin_fmaxf(m5, m6);
+    const bool g = m > b.v;              // strict: the earliest tile holding the maximum wins
+    b.v = g ? m : b.v;
+    b.tile = g ? tile : b.tile;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void scan16(BestT& b, const f32x16& acc, int tile)
+{
+    const float before = b.v;
+    const bool nan_before = b.nan;
+    int slot = b.slot;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float s = acc[r];
+        if (EXACT) {
+            if (!b.nan) {
+                if (s != s) { b.nan = true; b.v = __builtin_inff(); slot = r; }
+                else if (s > b.v) { b.v = s; slot = r; }
+            }
+        } else {
+            const bool g = s > b.v;
+            b.v = g ? s : b.v;
+            slot = g ? r : slot;
+        }
+    }
+    // strict '>' means the value changed iff some slot of this tile won (or the first NaN appeared)
+    const bool changed = EXACT ? ((b.v != before) || (b.nan != nan_before)) : (b.v != before);
+    b.tile = changed ? tile : b.tile;
+    b.slot = slot;
 }
 
 template <int RT>
@@ -263,11 +322,8 @@ __global__ __launch_bounds__(256) void vq_mfma_kernel(const float* __restrict__ 
     for (int t = 0; t < RT; ++t) {
         float zz[D], xx[D];
         int r = row0 + t * 32 + col;
-        if (r < N) load_row16(z + (size_t)r * D, zz);
-        else {
-#pragma unroll
-            for (int k = 0; k < D; ++k) zz[k] = 0.f;
-        }
+        r = r < N ? r : N - 1;                       // clamp: out-of-range lanes redo the last row, never stored
+        load_row16(z + (size_t)r * D, zz);
         if (normalize) l2norm16(zz, xx);
         else {
 #pragma unroll
@@ -278,56 +334,156 @@ __global__ __launch_bounds__(256) void vq_mfma_kernel(const float* __restrict__ 
 #pragma unroll
         for (int m = 0; m < 8; ++m) b[t][m] = half ? xx[2 * m + 1] : xx[2 * m];
     }
-    const bool wave_xbad = __any(xbad);
+    // exact (NaN-aware) scan only if this wave holds a non-finite row or the pack step flagged the codebook
+    const bool slow = __any(xbad) || (reinterpret_cast<const uint32_t*>(packed)[(size_t)C * D] != 0u);
 
     const int ntiles_total = C >> 5;
     const int tile_first = blockIdx.y * tiles_per_split;
     int tile_last = tile_first + tiles_per_split;
     if (tile_last > ntiles_total) tile_last = ntiles_total;
 
-    Best best[RT];
+    BestT best[RT];
 #pragma unroll
-    for (int t = 0; t < RT; ++t) best_init(best[t], tile_first * 32 + 4 * half);
+    for (int t = 0; t < RT; ++t) { best[t].v = -__builtin_inff(); best[t].tile = tile_first; best[t].slot = 0; best[t].nan = false; }
 
     const float4* ap = reinterpret_cast<const float4*>(packed) + (size_t)tile_first * 128 + lane * 2;
-    float4 a_lo = make_float4(0, 0, 0, 0), a_hi = a_lo;
-    if (tile_first < tile_last) { a_lo = ap[0]; a_hi = ap[1]; }
 
-    for (int tile = tile_first; tile < tile_last; ++tile) {
-        float a[8] = {a_lo.x, a_lo.y, a_lo.z, a_lo.w, a_hi.x, a_hi.y, a_hi.z, a_hi.w};
-        // prefetch next tile's A fragments
-        ap += 128;
-        if (tile + 1 < tile_last) { a_lo = ap[0]; a_hi = ap[1]; }
-        bool ebad = false;
+    auto mfma_tile = [&](const float4& lo, const float4& hi, f32x16 (&acc)[RT]) {
+        const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-        for (int m = 0; m < 8; ++m) ebad |= suspicious(a[m]);
-        const bool slow = wave_xbad || __any(ebad);
-        const int code_base = tile * 32 + 4 * half;
+        for (int t = 0; t < RT; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < 8; ++m)       // k = 2m (lanes 0-31), 2m+1 (lanes 32-63): k-ordered chain per accumulator
+#pragma unroll
+            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[t][m], acc[t], 0, 0, 0);
+    };
 
+    if (tile_first < tile_last) {
+        if (!slow) {
+            // software pipeline: tile i+1's MFMAs are issued before tile i's accumulators are scanned, so a wave never
+            // waits on the latency of its last MFMA before it has more matrix work queued.
+            // (ping-pong between two accumulator sets: no register copies in the loop)
+            f32x16 accA[RT], accB[RT];
+            float4 lo = ap[0], hi = ap[1];
+            mfma_tile(lo, hi, accA);                                     // tile_first
+            int tile = tile_first;
+            const int nt = tile_last - tile_first;
+            if (nt > 1) { lo = ap[128]; hi = ap[129]; }
+            // invariant at loop top: accA holds `tile`, (lo,hi) hold the fragments of tile+1 (if it exists)
+            while (tile + 2 < tile_last) {
+                float4 l1 = lo, h1 = hi;
+                lo = ap[256]; hi = ap[257];                              // tile+2 exists
+                mfma_tile(l1, h1, accB);                                 // tile+1
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile);
+                float4 l2 = lo, h2 = hi;
+                ap += 256;
+                if (tile + 3 < tile_last) { lo = ap[128]; hi = ap[129]; }
+                mfma_tile(l2, h2, accA);                                 // tile+2
 #pragma unroll
-            for (int m = 0; m < 8; ++m)   // k = 2m (lanes 0-31), 2m+1 (lanes 32-63): k-ordered chain
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[t][m], acc, 0, 0, 0);
-            // acc[r] = score(code = tile*32 + (r&3) + 8*(r>>2) + 4*half, row = col); increasing in r
-            if (!slow) {
+                for (int t = 0; t < RT; ++t) scanmax(best[t], accB[t], tile + 1);
+                tile += 2;
+            }
+            if (tile + 1 < tile_last) {                                  // one more pair: tile (in accA) and tile+1
+                mfma_tile(lo, hi, accB);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) best_upd_fast(best[t], acc[r], code_base + (r & 3) + 8 * (r >> 2));
+                for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) scanmax(best[t], accB[t], tile + 1);
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) best_upd_exact(best[t], acc[r], code_base + (r & 3) + 8 * (r >> 2));
+                for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile);
+            }
+        } else {
+            for (int tile = tile_first; tile < tile_last; ++tile) {
+                f32x16 acc[RT];
+                mfma_tile(ap[0], ap[1], acc);
+                ap += 128;
+#pragma unroll
+                for (int t = 0; t < RT; ++t) scan16<true>(best[t], acc[t], tile);
             }
         }
     }
 
+    // one entry per (split, half, row): hi = orderable(best) (NaN -> 0xFFFFFFFF); lo = winning tile (fast path) or
+    // 0x80000000 | exact code index (NaN-aware path)
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-        unsigned long long k = best_key(best[t]);
-        unsigned long long other = shfl_xor_u64(k, 32);   // the other half holds the other 16 codes of each tile
-        k = other > k ? other : k;
+        float v = best[t].v;
+        if (v == 0.0f) v = 0.0f;
+        const uint32_t hi = best[t].nan ? KEY_NAN : f32_orderable(v);
+        uint32_t lo = (uint32_t)best[t].tile;
+        if (slow) lo = 0x80000000u | (uint32_t)(best[t].tile * 32 + (best[t].slot & 3) + 8 * (best[t].slot >> 2) + 4 * half);
         int r = row0 + t * 32 + col;
-        if (half == 0 && r < N) partial[(size_t)blockIdx.y * N + r] = k;
+        if (r < N) partial[((size_t)blockIdx.y * 2 + half) * N + r] = ((unsigned long long)hi << 32) | lo;
+    }
+}
+
+// Reduce the (split, half) candidates of every row and recover the exact code index: among the candidates that hold
+// the row's maximum, fast-path entries only know the winning tile, so the 16 scores of that (tile, half) are recomputed
+// with the same k-ordered FMA chain (bit-identical to the MFMA result) and the first slot equal to the maximum is taken.
+template <typename IdT>
+__global__ __launch_bounds__(256) void vq_finalize_packed_kernel(const unsigned long long* __restrict__ partial, const float* __restrict__ z,
+                                                                 const float* __restrict__ packed, IdT* __restrict__ ids, float* __restrict__ best,
+                                                                 int N, int nentries, int normalize)
+{
+    // 16 lanes per row: lane j reduces entries j, j+16, ... and later evaluates slot j of a candidate tile
+    const int gl = threadIdx.x & 15;
+    const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool live = r < N;
+    const int rr = live ? r : N - 1;
+    uint32_t gmax = 0;
+    for (int s = gl; s < nentries; s += 16) {
+        uint32_t hi = (uint32_t)(partial[(size_t)s * N + rr] >> 32);
+        gmax = hi > gmax ? hi : gmax;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { uint32_t other = __shfl_xor(gmax, o, 16); gmax = other > gmax ? other : gmax; }
+    const float vmax = f32_from_orderable(gmax);
+    float x[D];
+    {
+        float zz[D];
+        load_row16(z + (size_t)rr * D, zz);
+        if (normalize) l2norm16(zz, x);
+        else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) x[k] = zz[k];
+        }
+    }
+    uint32_t idx_best = 0xFFFFFFFFu;
+    for (int s0 = 0; s0 < nentries; s0 += 16) {
+        // each lane looks at one entry; candidates (== gmax) are then resolved one at a time by the whole group
+        const int s_mine = s0 + gl;
+        unsigned long long e = s_mine < nentries ? partial[(size_t)s_mine * N + rr] : 0ull;
+        const bool cand = s_mine < nentries && (uint32_t)(e >> 32) == gmax;
+        // group-local ballot (the 16 lanes of a row are contiguous inside the wave)
+        unsigned long long bal = __ballot(cand);
+        uint32_t mask = (uint32_t)((bal >> ((threadIdx.x & 63) & ~15)) & 0xFFFFu);
+        while (mask) {
+            const int j = __ffs(mask) - 1;
+            mask &= mask - 1;
+            const uint32_t lo = (uint32_t)__shfl(e, j, 16);
+            uint32_t idx;
+            if (lo & 0x80000000u) idx = lo & 0x7FFFFFFFu;
+            else {
+                const int tile = (int)lo, half = (s0 + j) & 1;
+                const float* pt = packed + (size_t)tile * 512;
+                const int slot = gl;
+                const int i = (slot & 3) + 8 * (slot >> 2) + 4 * half;      // code inside the tile
+                float sc = 0.f;
+#pragma unroll
+                for (int k = 0; k < D; ++k) sc = __builtin_fmaf(x[k], pt[((k & 1) * 32 + i) * 8 + (k >> 1)], sc);
+                unsigned long long beq = __ballot(sc == vmax);
+                uint32_t meq = (uint32_t)((beq >> ((threadIdx.x & 63) & ~15)) & 0xFFFFu);
+                const int win = meq ? (__ffs(meq) - 1) : 0;               // first slot equal to the maximum
+                idx = (uint32_t)(tile * 32 + (win & 3) + 8 * (win >> 2) + 4 * half);
+            }
+            idx_best = idx < idx_best ? idx : idx_best;
+        }
+    }
+    if (live && gl == 0) {
+        ids[r] = (IdT)idx_best;
+        if (best) best[r] = (gmax == KEY_NAN) ? __uint_as_float(0x7FC00000u) : vmax;
     }
 }
 
@@ -383,6 +539,45 @@ __global__ void code_gather_ln_kernel(const IdT* __restrict__ ids, const float* 
 
 using namespace selftok;
 
+static int pick_split(int row_blocks, int ntiles, int max_split)
+{
+    // aim for >= ~1024 workgroups (4 per CU) while keeping >= 8 tiles per split
+    int split = 1;
+    while (row_blocks * split < 1024 && split * 2 <= max_split && ntiles / (split * 2) >= 8) split *= 2;
+    return split;
+}
+
+// Code-split count such that row_blocks*split fills the chip in whole "rounds" of resident workgroups
+// (slots = CUs x workgroups per CU from the occupancy query): a grid of 1.33 rounds runs at 67 % of a grid of 1.0.
+static int pick_split_balanced(int row_blocks, int ntiles, int max_split, int slots)
+{
+    if (slots <= 0) return pick_split(row_blocks, ntiles, max_split);
+    int best = 1;
+    double best_eff = 0.0;
+    for (int split = 1; split <= max_split && split <= ntiles; ++split) {
+        int tps = (ntiles + split - 1) / split;
+        if (tps < 4 && split > 1) break;
+        int eff_split = (ntiles + tps - 1) / tps;
+        long blocks = (long)row_blocks * eff_split;
+        long rounds = (blocks + slots - 1) / slots;
+        // time ~ rounds * tps (every block scans tps tiles); ideal = total tiles / slots
+        double eff = ((double)row_blocks * ntiles / slots) / ((double)rounds * tps);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = eff_split; }
+    }
+    return best;
+}
+
+template <typename K>
+static int resident_slots(K kernel)
+{
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess) return 0;
+    return cus * per_cu;
+}
+
+
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
@@ -391,23 +586,18 @@ extern "C" {
 size_t selftok_vq_workspace_bytes(int N, int C)
 {
     (void)C;
-    return (size_t)64 * (size_t)(N > 0 ? N : 1) * sizeof(unsigned long long);   // up to 64 code splits
+    return (size_t)128 * (size_t)(N > 0 ? N : 1) * sizeof(unsigned long long);   // up to 64 code splits x 2 wave halves
 }
+
+size_t selftok_vq_packed_bytes(int C, int Dm) { return ((size_t)C * Dm + 64) * sizeof(float); }
 
 int selftok_vq_pack_codebook(const float* codebook, float* packed, int C, int Dm, hipStream_t stream)
 {
     if (!codebook || !packed || Dm != D || C <= 0 || (C & 31)) { set_last_error("vq_pack: need D==16 and C%32==0"); return SELFTOK_EINVAL; }
     int total = C * D;
+    if (hipMemsetAsync(packed + (size_t)C * D, 0, 64 * sizeof(float), stream) != hipSuccess) return check_launch("vq_pack memset");
     hipLaunchKernelGGL(vq_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, codebook, packed, C);
     return check_launch("vq_pack_kernel");
-}
-
-static int pick_split(int row_blocks, int ntiles, int max_split)
-{
-    // aim for >= ~1024 workgroups (4 per CU) while keeping >= 8 tiles per split
-    int split = 1;
-    while (row_blocks * split < 1024 && split * 2 <= max_split && ntiles / (split * 2) >= 8) split *= 2;
-    return split;
 }
 
 // flags: bit0 = ids are int32 (default int64), bit1 = z is already unit-norm (skip l2norm)
@@ -440,9 +630,16 @@ int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, vo
     unsigned long long* partial = (unsigned long long*)workspace;
     const int ntiles = C >> 5;
     const int norm = (flags & 2) ? 0 : 1;
-    int rt = N >= 32768 ? 4 : (N >= 8192 ? 2 : 1);
+    int rt = N >= 8192 ? 2 : 1;
+    {   // tuning override (bench/debug): SELFTOK_VQ_RT=1|2|4
+        static int env_rt = -1;
+        if (env_rt < 0) { const char* e = getenv("SELFTOK_VQ_RT"); env_rt = e ? atoi(e) : 0; }
+        if (env_rt == 1 || env_rt == 2 || env_rt == 4) rt = env_rt;
+    }
     int row_blocks = (N + 128 * rt - 1) / (128 * rt);
-    int split = pick_split(row_blocks, ntiles, 64);
+    static int slots4 = -1, slots2 = -1, slots1 = -1;      // resident workgroups on this device, queried once
+    if (slots4 < 0) { slots4 = resident_slots(vq_mfma_kernel<4>); slots2 = resident_slots(vq_mfma_kernel<2>); slots1 = resident_slots(vq_mfma_kernel<1>); }
+    int split = pick_split_balanced(row_blocks, ntiles, 64, rt == 4 ? slots4 : (rt == 2 ? slots2 : slots1));
     int tps = (ntiles + split - 1) / split;
     split = (ntiles + tps - 1) / tps;
     *nsplit_out = split;
@@ -453,15 +650,18 @@ int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, vo
     return check_launch("vq_mfma_kernel");
 }
 
-// Reduce the code splits of a partial pass: ids (int64, or int32 with SELFTOK_IDS_I32) and optional top-1 score.
-int selftok_vq_finalize(const void* workspace, void* ids, float* best, int N, int nsplit, int flags, hipStream_t stream)
+// Reduce the candidates of a partial pass: ids (int64, or int32 with SELFTOK_IDS_I32) and optional top-1 score.
+// Needs z and the packed codebook again to pin down the slot inside the winning tile (see the kernel).
+int selftok_vq_finalize_packed(const void* workspace, const float* z, const float* packed, void* ids, float* best,
+                               int N, int C, int Dm, int nsplit, int flags, hipStream_t stream)
 {
-    if (!workspace || !ids || N < 0 || nsplit <= 0) { set_last_error("vq_finalize: bad argument"); return SELFTOK_EINVAL; }
+    if (!workspace || !z || !packed || !ids || N < 0 || nsplit <= 0 || Dm != D || (C & 31)) { set_last_error("vq_finalize_packed: bad argument"); return SELFTOK_EINVAL; }
     if (N == 0) return SELFTOK_OK;
     const unsigned long long* partial = (const unsigned long long*)workspace;
-    if (flags & 1) hipLaunchKernelGGL(vq_finalize_kernel<int32_t>, dim3((N + 255) / 256), dim3(256), 0, stream, partial, (int32_t*)ids, best, N, nsplit);
-    else hipLaunchKernelGGL(vq_finalize_kernel<long long>, dim3((N + 255) / 256), dim3(256), 0, stream, partial, (long long*)ids, best, N, nsplit);
-    return check_launch("vq_finalize_kernel");
+    const int norm = (flags & 2) ? 0 : 1;
+    if (flags & 1) hipLaunchKernelGGL(vq_finalize_packed_kernel<int32_t>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (int32_t*)ids, best, N, 2 * nsplit, norm);
+    else hipLaunchKernelGGL(vq_finalize_packed_kernel<long long>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (long long*)ids, best, N, 2 * nsplit, norm);
+    return check_launch("vq_finalize_packed_kernel");
 }
 
 int selftok_vq_encode_packed_f32(const float* z, const float* packed, void* ids, float* best, void* workspace,
@@ -471,7 +671,7 @@ int selftok_vq_encode_packed_f32(const float* z, const float* packed, void* ids,
     int split = 0;
     int rc = selftok_vq_argmax_partial_packed_f32(z, packed, workspace, &split, N, C, Dm, flags, stream);
     if (rc || N == 0) return rc;
-    return selftok_vq_finalize(workspace, ids, best, N, split, flags, stream);
+    return selftok_vq_finalize_packed(workspace, z, packed, ids, best, N, C, Dm, split, flags, stream);
 }
 
 // flags bit0: ids are int32 (default int64).  ln_w/ln_b may be NULL (plain gather).

@@ -32,8 +32,9 @@ def vq_pack_codebook(codebook: torch.Tensor) -> torch.Tensor:
     _need_cuda(codebook)
     cb = codebook.contiguous().float()
     C, D = cb.shape
-    packed = torch.empty_like(cb)
-    _lib.check(_lib.load().selftok_vq_pack_codebook(_p(cb), _p(packed), C, D, _stream()), "selftok_vq_pack_codebook")
+    lib = _lib.load()
+    packed = torch.empty(lib.selftok_vq_packed_bytes(C, D) // 4, dtype=torch.float32, device=cb.device)
+    _lib.check(lib.selftok_vq_pack_codebook(_p(cb), _p(packed), C, D, _stream()), "selftok_vq_pack_codebook")
     return packed
 
 
@@ -44,7 +45,7 @@ def vq_encode(z: torch.Tensor, codebook: torch.Tensor, *, packed: bool = False, 
     lib = _lib.load()
     zz = z.contiguous().float().reshape(-1, z.shape[-1])
     N, D = zz.shape
-    C = codebook.shape[0]
+    C = (codebook.numel() - 64) // D if packed else codebook.shape[0]
     ids = torch.empty(N, dtype=ids_dtype, device=z.device)
     best = torch.empty(N, dtype=torch.float32, device=z.device) if return_best else None
     ws = torch.empty(lib.selftok_vq_workspace_bytes(N, C), dtype=torch.uint8, device=z.device)
@@ -263,7 +264,7 @@ def vq_encode_split_launch(z, packed_codebook, ids_dtype=torch.int64):
     lib = _lib.load()
     zz = z.contiguous().float().reshape(-1, z.shape[-1])
     N, D = zz.shape
-    C = packed_codebook.shape[0]
+    C = (packed_codebook.numel() - 64) // D
     ids = torch.empty(N, dtype=ids_dtype, device=z.device)
     ws = torch.empty(lib.selftok_vq_workspace_bytes(N, C), dtype=torch.uint8, device=z.device)
     flags = IDS_I32 if ids_dtype == torch.int32 else 0
@@ -274,6 +275,7 @@ def vq_encode_split_launch(z, packed_codebook, ids_dtype=torch.int64):
                                                             flags, _stream()), "selftok_vq_argmax_partial_packed_f32")
 
     def launch_finalize():
-        _lib.check(lib.selftok_vq_finalize(_p(ws), _p(ids), None, N, nsplit.value, flags, _stream()), "selftok_vq_finalize")
+        _lib.check(lib.selftok_vq_finalize_packed(_p(ws), _p(zz), _p(packed_codebook), _p(ids), None, N, C, D, nsplit.value, flags,
+                                                  _stream()), "selftok_vq_finalize_packed")
 
     return ids.reshape(z.shape[:-1]), launch_main, launch_finalize

@@ -51,11 +51,17 @@ def test_vq_edge_rows(cb, packed):
     z[2, 5] = float("nan")
     z[3, 0] = float("inf")
     z[4] = -cb2[0]                  # negative scores around
+    cb2[64 + 5] = cb2[64 + 2]       # duplicates inside ONE 32-code tile, held by different wave halves
+    cb2[64 + 30] = cb2[64 + 2]
+    z[5] = cb2[64 + 2] * 0.7        # -> 66
+    cb2[20000 + 9] = cb2[20000 + 12]   # same tile, the higher slot sits in the lower half
+    z[6] = cb2[20000 + 12] * 2.0    # -> 20009
     _check(z, cb2, packed)
     zc = z.cuda()
     cbk = ops.vq_pack_codebook(cb2.cuda()) if packed else cb2.cuda()
     ids = ops.vq_encode(zc, cbk, packed=packed).cpu()
     assert ids[0].item() == 77 and ids[1].item() == 0 and ids[2].item() == 0 and ids[3].item() == 0
+    assert ids[5].item() == 66 and ids[6].item() == 20009
 
 
 @pytest.mark.parametrize("packed", [False, True])

@@ -21,4 +21,14 @@ for n in (512, 32768, 65536, 131072):
         e.record(); torch.cuda.synchronize()
         ms = s.elapsed_time(e) / iters
         fl = 2.0 * n * 32768 * 16
-        print(json.dumps({"kernel": name, "N": n, "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1)}))
+        rec = {"kernel": name, "N": n, "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1)}
+        if packed:
+            ids, lm, lf = ops.vq_encode_split_launch(z, pk)
+            lm(); lf(); torch.cuda.synchronize()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            tm = tf = 0.0
+            for _ in range(iters):
+                ev[0].record(); lm(); ev[1].record(); lf(); ev[2].record(); torch.cuda.synchronize()
+                tm += ev[0].elapsed_time(ev[1]); tf += ev[1].elapsed_time(ev[2])
+            rec.update(main_ms=round(tm / iters, 4), finalize_ms=round(tf / iters, 4), main_TFLOPs=round(fl / (tm / iters) / 1e9, 1))
+        print(json.dumps(rec))
