@@ -92,6 +92,23 @@ def cpu_baseline(sd_gpu, vsd_gpu, cfg, K):
                       "(no redundant encoder passes / table recomputes of the reference)"}
 
 
+def fp32_flops_per_image(K: int, k_table, renderer: bool) -> float:
+    """analytic fp32 matrix FLOPs of one image through encode + decode as THIS implementation executes them
+    (context truncated to k+1 live tokens, adaLN tables precomputed); the bf16 VAE (0.89 TFLOP/img) is not included."""
+    H, Hq, Hx, nx = 1536, 512, 64, 256
+    enc_blk = (nx * (Hx * 3 * Hx + Hx * 2 * Hq + Hx * Hx + 2 * Hx * 4 * Hx) + K * (Hq * 3 * Hq + Hq * Hq + 2 * Hq * 4 * Hq)) * 2 \
+        + 2 * 2 * 4 * nx * nx * 16 + 2 * 2 * 8 * K * (nx + K) * 64
+    enc = 16 * enc_blk + K * Hq * 16 * 2 + 2.0 * K * 32768 * 16
+
+    def dit_pass(n):
+        lin = 23 * n * 12 * H * H * 2 + n * 2 * H * H * 2 + 24 * nx * 12 * H * H * 2
+        ada = (24 * 6 + 2 + 2) * H * H * 2 + 2 * H * H * 2
+        att = 23 * 4 * 24 * 64 * (n + nx) * (n + nx) + 4 * 24 * 64 * nx * (n + nx)
+        return lin + ada + att + nx * H * 64 * 2 + nx * 64 * H * 2
+    dec = dit_pass(K) if renderer else sum(dit_pass(int(k) + 1) for k in k_table)
+    return float(enc + dec)
+
+
 def main():
     args = parse()
     from selftoktokenizer_amd import dist as D, ops, synth, weights as W
@@ -181,6 +198,13 @@ def main():
                    "weights": "hash-generated, architecture of tokenizer_512_ckpt"},
         "roofline": roof,
     }
+    fl_img = fp32_flops_per_image(K, pipe.k_table[: (args.decode_steps or 50)], renderer)
+    job_tf = fl_img * world * B * args.steps / elapsed / 1e12
+    line["job_roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "fp32_tflop_per_image": round(fl_img / 1e12, 2),
+                            "achieved": round(job_tf, 1), "peak": FP32_MFMA_PEAK_TFLOPS * world,
+                            "frac": round(job_tf / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+                            "note": "fp32 matrix FLOPs actually executed (encoder + MMDiT, context truncated to live tokens) / wall time; "
+                                    "bf16 VAE work (0.89 TFLOP/img) excluded"}
     if args.decode_steps is not None and not renderer:
         line["config"]["INVALID"] = "decode loop truncated with --decode-steps (debug run)"
     if world == 1 and not args.no_cpu_baseline:

@@ -362,37 +362,37 @@ __global__ __launch_bounds__(256) void vq_mfma_kernel(const float* __restrict__ 
         if (!slow) {
             // software pipeline: tile i+1's MFMAs are issued before tile i's accumulators are scanned, so a wave never
             // waits on the latency of its last MFMA before it has more matrix work queued.
-            // (ping-pong between two accumulator sets: no register copies in the loop)
+            // (two accumulator sets and two fragment sets ping-pong: no register copies, loads run 2 tiles ahead)
             f32x16 accA[RT], accB[RT];
-            float4 lo = ap[0], hi = ap[1];
-            mfma_tile(lo, hi, accA);                                     // tile_first
-            int tile = tile_first;
             const int nt = tile_last - tile_first;
-            if (nt > 1) { lo = ap[128]; hi = ap[129]; }
-            // invariant at loop top: accA holds `tile`, (lo,hi) hold the fragments of tile+1 (if it exists)
-            while (tile + 2 < tile_last) {
-                float4 l1 = lo, h1 = hi;
-                lo = ap[256]; hi = ap[257];                              // tile+2 exists
-                mfma_tile(l1, h1, accB);                                 // tile+1
+            // fragment of tile (tile_first + i); past the end the last tile is re-read (unconditional loads: a
+            // load-or-zero select makes hipcc branch around every dword) and those MFMA results are never scanned
+            auto frag = [&](int i, int part) -> float4 { return ap[(size_t)(i < nt ? i : nt - 1) * 128 + part]; };
+            float4 f0lo = frag(0, 0), f0hi = frag(0, 1);                 // even tiles
+            float4 f1lo = frag(1, 0), f1hi = frag(1, 1);                 // odd tiles
+            mfma_tile(f0lo, f0hi, accA);                                 // tile 0 -> accA
+            f0lo = frag(2, 0); f0hi = frag(2, 1);
+            int i = 0;                                                   // accA holds tile i (even), f1 = tile i+1, f0 = tile i+2
+            for (; i + 2 < nt; i += 2) {
+                mfma_tile(f1lo, f1hi, accB);                             // tile i+1
+                f1lo = frag(i + 3, 0); f1hi = frag(i + 3, 1);
 #pragma unroll
-                for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile);
-                float4 l2 = lo, h2 = hi;
-                ap += 256;
-                if (tile + 3 < tile_last) { lo = ap[128]; hi = ap[129]; }
-                mfma_tile(l2, h2, accA);                                 // tile+2
+                for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile_first + i);
+                mfma_tile(f0lo, f0hi, accA);                             // tile i+2
+                f0lo = frag(i + 4, 0); f0hi = frag(i + 4, 1);
 #pragma unroll
-                for (int t = 0; t < RT; ++t) scanmax(best[t], accB[t], tile + 1);
-                tile += 2;
+                for (int t = 0; t < RT; ++t) scanmax(best[t], accB[t], tile_first + i + 1);
             }
-            if (tile + 1 < tile_last) {                                  // one more pair: tile (in accA) and tile+1
-                mfma_tile(lo, hi, accB);
+            // tail: accA holds tile i; tile i+1 may exist (fragments in f1)
+            if (i + 1 < nt) {
+                mfma_tile(f1lo, f1hi, accB);
 #pragma unroll
-                for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile);
+                for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile_first + i);
 #pragma unroll
-                for (int t = 0; t < RT; ++t) scanmax(best[t], accB[t], tile + 1);
+                for (int t = 0; t < RT; ++t) scanmax(best[t], accB[t], tile_first + i + 1);
             } else {
 #pragma unroll
-                for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile);
+                for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile_first + i);
             }
         } else {
             for (int tile = tile_first; tile < tile_last; ++tile) {
@@ -640,6 +640,11 @@ int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, vo
     static int slots4 = -1, slots2 = -1, slots1 = -1;      // resident workgroups on this device, queried once
     if (slots4 < 0) { slots4 = resident_slots(vq_mfma_kernel<4>); slots2 = resident_slots(vq_mfma_kernel<2>); slots1 = resident_slots(vq_mfma_kernel<1>); }
     int split = pick_split_balanced(row_blocks, ntiles, 64, rt == 4 ? slots4 : (rt == 2 ? slots2 : slots1));
+    {   // tuning override (bench/debug): SELFTOK_VQ_SPLIT=n
+        static int env_split = -1;
+        if (env_split < 0) { const char* e = getenv("SELFTOK_VQ_SPLIT"); env_split = e ? atoi(e) : 0; }
+        if (env_split > 0 && env_split <= 64) split = env_split;
+    }
     int tps = (ntiles + split - 1) / split;
     split = (ntiles + tps - 1) / tps;
     *nsplit_out = split;

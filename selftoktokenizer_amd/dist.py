@@ -59,7 +59,10 @@ def all_gather_ids(ids_local: torch.Tensor) -> torch.Tensor:
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value: float, device) -> float:

@@ -125,3 +125,48 @@ def test_normalize_to_tensor():
     t = NormalizeToTensor()(img)
     assert t.shape == (3, 4, 6) and t.dtype == torch.float32
     assert float(t[0, 0, 0]) == -1.0 and abs(float(t[1, 0, 0]) - (1 / 127.5 - 1)) < 1e-7
+
+
+def test_token_wire_formats_roundtrip(tmp_path):
+    from selftoktokenizer_amd import tokens as T
+    ids = synth.synthetic_token_ids(3, 512)
+    ids[0, 0], ids[0, 1] = 0, 32767
+    p = str(tmp_path / "token.npy")
+    T.save_reference_npy(p, ids)
+    back = T.load_reference_npy(p)
+    assert back.dtype == np.int64 and np.array_equal(back, ids)
+    assert np.array_equal(T.to_uint16(ids).astype(np.int64), ids)
+    buf = T.pack15(ids)
+    assert len(buf) == (ids.size * 15 + 7) // 8
+    assert np.array_equal(T.unpack15(buf, ids.shape), ids)
+    with pytest.raises(ValueError):
+        T.pack15(np.array([[32768]]))
+    assert np.array_equal(T.reverse_for_ar(ids)[:, 0], ids[:, -1])
+    m = T.prefix_mask(512, [19, 511])
+    assert m.shape == (2, 512) and m[0].sum() == 20 and m[1].all()
+
+
+def test_checkpoint_loaders(tmp_path):
+    """the reference's on-disk layouts: flat .pth state dict; diffusers VAE safetensors folder; single-file ldm VAE"""
+    from safetensors.torch import save_file
+    sd = {"encoder.query_tokens": torch.zeros(1, 4, 8), "model.context_pos_embed": torch.ones(1, 4, 8)}
+    torch.save(sd, str(tmp_path / "tok.pth"))
+    back = W.load_tokenizer_checkpoint(str(tmp_path / "tok.pth"))
+    assert set(back) == set(sd) and torch.equal(back["model.context_pos_embed"], sd["model.context_pos_embed"])
+    torch.save({"state_dict": sd}, str(tmp_path / "wrapped.pth"))
+    assert set(W.load_tokenizer_checkpoint(str(tmp_path / "wrapped.pth"))) == set(sd)
+    # diffusers layout: <sd3_path>/vae/diffusion_pytorch_model.safetensors
+    shapes = W.vae_shapes()
+    some = {k: torch.full(shapes[k], 0.5) for k in list(shapes)[:6]}
+    (tmp_path / "sd3" / "vae").mkdir(parents=True)
+    save_file(some, str(tmp_path / "sd3" / "vae" / "diffusion_pytorch_model.safetensors"))
+    got = W.load_vae_checkpoint(str(tmp_path / "sd3"))
+    assert set(got) == set(some)
+    # single-file ldm checkpoint with first_stage_model.* keys and conv1x1 attention weights
+    k_lin = "decoder.mid_block.attentions.0.to_q.weight"
+    ldm = {"first_stage_model." + W.diffusers_to_ldm_key(k_lin): torch.arange(512 * 512, dtype=torch.float32).reshape(512, 512, 1, 1),
+           "first_stage_model." + W.diffusers_to_ldm_key("encoder.conv_in.bias"): torch.ones(128),
+           "model.diffusion_model.something": torch.zeros(1)}
+    torch.save(ldm, str(tmp_path / "sd3_medium.pt"))
+    got = W.load_vae_checkpoint(str(tmp_path / "sd3_medium.pt"))
+    assert set(got) == {k_lin, "encoder.conv_in.bias"} and got[k_lin].shape == (512, 512)

@@ -83,3 +83,45 @@ def test_cfg_branch_runs(pipe):
     ids = synth.synthetic_token_ids(1)
     rec, lat = pipe.decoding(ids, noise=synth.synthetic_noise(1), return_latent=True, max_steps=2, uncond_scale=2.0)
     assert torch.isfinite(lat).all()
+
+
+def test_k1024_and_renderer_configs_run():
+    """BASELINE configs[2] (1024-token tokenizer, assumed stage split) and configs[3] (one-step renderer): shapes,
+    finiteness, and the encoder against the CPU oracle at K=1024 (the reference ships no 1024 config/weights)."""
+    from mimogpt.infer.SelftokPipeline import SelftokPipeline
+    from oracle import model as OM
+    vsd = W.synthetic_vae_state_dict(device="cuda")
+    sd = W.synthetic_state_dict(W.expected_shapes(1024), device="cuda")
+    p = SelftokPipeline(default_config(1024), None, None, device="cuda", state_dict=sd, vae_state_dict=vsd)
+    p.verbose = False
+    assert p.K == 1024 and int(p.k_table[0]) == 1023
+    x0 = synth.synthetic_latents(1, device="cuda")
+    z = p.model.encoder.features(x0).cpu()
+    enc_sd = {k: v.cpu() for k, v in sd.items() if k.startswith("encoder.")}
+    z_ref = OM.encoder_features(enc_sd, x0.cpu())
+    assert float((z - z_ref).abs().max()) < 3e-4
+    tok = p.encoding(synth.synthetic_images(2))
+    assert tuple(tok.shape) == (2, 1024)
+    rec, lat = p.decoding(tok.cpu().numpy(), noise=synth.synthetic_noise(2), max_steps=2, return_latent=True)
+    assert tuple(rec.shape) == (2, 3, 256, 256) and bool(torch.isfinite(lat).all())
+    del p, sd
+    torch.cuda.empty_cache()
+    sd = W.synthetic_state_dict(W.expected_shapes(512, renderer=True), device="cuda")
+    r = SelftokPipeline(default_config(512, renderer=True), None, None, device="cuda", state_dict=sd, vae_state_dict=vsd)
+    r.verbose = False
+    rec = r.decoding_with_renderer(synth.synthetic_token_ids(2))
+    assert tuple(rec.shape) == (2, 3, 256, 256) and float(rec.min()) >= 0 and float(rec.max()) <= 1
+
+
+def test_ema_decoder_option(pipe):
+    """ema_decoder=True takes the DiT from state_dict['ema_state_dict'] (keys without the 'model.' prefix), reference :193-198"""
+    from mimogpt.infer.SelftokPipeline import SelftokPipeline
+    sd = {k: v for k, v in pipe.model.encoder.w.items()}
+    sd["encoder.quantizer._codebook.embed"] = pipe.model.encoder.codebook[None]
+    sd["ema_state_dict"] = {k[len("model."):]: v for k, v in pipe.model.model.w.items()}
+    p2 = SelftokPipeline(default_config(512), None, None, device="cuda", state_dict=sd, vae_state_dict=pipe.vae.w, ema_decoder=True)
+    p2.verbose = False
+    ids, noise = synth.synthetic_token_ids(1), synth.synthetic_noise(1)
+    _, la = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=2)
+    _, lb = p2.decoding(ids, noise=noise, return_latent=True, max_steps=2)
+    assert torch.equal(la, lb)
