@@ -22,6 +22,7 @@
 // K tiles are staged [key][68] (b128 reads, conflict-free), V tiles [key][64] (b32 reads, conflict-free).
 #include "common.h"
 #include "selftok_hip.h"
+#include <stdlib.h>
 
 namespace selftok {
 
@@ -43,6 +44,8 @@ struct AttnParams {
     const int* kvis;        // [B] or NULL
     int seg0_sees_seg1;
     float scale;
+    int qtiles;             // 128-row query tiles per (sample, head), both segments
+    int xcd_remap;
 };
 
 constexpr int KT = 32;           // keys per tile
@@ -56,7 +59,18 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y;
+    // XCD-aware work mapping: workgroup `orig` runs on XCD orig % 8 (observed dispatch order; speed only, never
+    // correctness).  Give every XCD a contiguous range of work items so that the q-tiles of one (sample, head), which
+    // re-read the same K/V, share one L2 instead of pulling K/V through the fabric once per XCD.
+    int qt, h, b;
+    {
+        const int T = gridDim.x, orig = blockIdx.x;
+        const int q8 = T >> 3, r8 = T & 7, xcd = orig & 7, idx = orig >> 3;
+        const int w = P.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx : orig;
+        qt = w % P.qtiles;
+        h = (w / P.qtiles) % P.H;
+        b = w / (P.qtiles * P.H);
+    }
 
     int n0 = P.seg[0].len;
     if (P.kvis) { int kv = P.kvis[b] + 1; n0 = kv < n0 ? (kv < 0 ? 0 : kv) : n0; }
@@ -64,8 +78,8 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
     int s, r0;
     {
         const int t0 = P.seg[0].q ? (P.seg[0].len + QROWS - 1) / QROWS : 0;   // grid is sized on len, not on kvis
-        if ((int)blockIdx.x < t0) { s = 0; r0 = blockIdx.x * QROWS; }
-        else { s = 1; r0 = (blockIdx.x - t0) * QROWS; }
+        if (qt < t0) { s = 0; r0 = qt * QROWS; }
+        else { s = 1; r0 = (qt - t0) * QROWS; }
     }
     const int rows_live = (s == 0) ? rows0 : (P.seg[1].q ? P.seg[1].len : 0);
     if (r0 >= rows_live) return;                            // dead context rows / empty tile
@@ -267,7 +281,9 @@ int selftok_attn_f32(const selftok_attn_desc* d, hipStream_t stream)
         int t0 = P.seg[0].q ? (P.seg[0].len + QROWS - 1) / QROWS : 0;
         int t1 = P.seg[1].q ? (P.seg[1].len + QROWS - 1) / QROWS : 0;
         if (t0 + t1 == 0) return SELFTOK_OK;
-        hipLaunchKernelGGL(attn64_kernel, dim3(t0 + t1, d->H, d->B), dim3(256), 0, stream, P);
+        P.qtiles = t0 + t1;
+        { static int no = -1; if (no < 0) { const char* e = getenv("SELFTOK_ATTN_NOXCD"); no = e ? atoi(e) : 0; } P.xcd_remap = no ? 0 : 1; }
+        hipLaunchKernelGGL(attn64_kernel, dim3((t0 + t1) * d->H * d->B), dim3(256), 0, stream, P);
         return check_launch("attn64_kernel");
     }
     if (d->head_dim == 16) {
