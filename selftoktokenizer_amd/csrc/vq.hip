@@ -604,8 +604,8 @@ int selftok_vq_pack_codebook(const float* codebook, float* packed, int C, int Dm
 int selftok_vq_encode_f32(const float* z, const float* codebook, void* ids, float* best, void* workspace,
                           int N, int C, int Dm, int flags, hipStream_t stream)
 {
+    if (N == 0 && Dm == D && C > 0) return SELFTOK_OK;     // empty batch: nothing to do (pointers may be null)
     if (Dm != D || C <= 0 || N < 0 || !z || !codebook || !ids || !workspace) { set_last_error("vq_encode: bad argument"); return SELFTOK_EINVAL; }
-    if (N == 0) return SELFTOK_OK;
     unsigned long long* partial = (unsigned long long*)workspace;
     int ntiles = (C + V_TILE - 1) / V_TILE;
     int row_blocks = (N + 4 * V_ROWS - 1) / (4 * V_ROWS);
@@ -624,9 +624,9 @@ int selftok_vq_encode_f32(const float* z, const float* codebook, void* ids, floa
 int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, void* workspace, int* nsplit_out,
                                          int N, int C, int Dm, int flags, hipStream_t stream)
 {
+    if (nsplit_out) *nsplit_out = 0;
+    if (N == 0 && Dm == D && C > 0 && !(C & 31) && nsplit_out) return SELFTOK_OK;     // empty batch
     if (Dm != D || C <= 0 || (C & 31) || N < 0 || !z || !packed || !workspace || !nsplit_out) { set_last_error("vq_argmax_partial_packed: bad argument"); return SELFTOK_EINVAL; }
-    *nsplit_out = 0;
-    if (N == 0) return SELFTOK_OK;
     unsigned long long* partial = (unsigned long long*)workspace;
     const int ntiles = C >> 5;
     const int norm = (flags & 2) ? 0 : 1;
@@ -660,8 +660,8 @@ int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, vo
 int selftok_vq_finalize_packed(const void* workspace, const float* z, const float* packed, void* ids, float* best,
                                int N, int C, int Dm, int nsplit, int flags, hipStream_t stream)
 {
-    if (!workspace || !z || !packed || !ids || N < 0 || nsplit <= 0 || Dm != D || (C & 31)) { set_last_error("vq_finalize_packed: bad argument"); return SELFTOK_EINVAL; }
     if (N == 0) return SELFTOK_OK;
+    if (!workspace || !z || !packed || !ids || N < 0 || nsplit <= 0 || Dm != D || (C & 31)) { set_last_error("vq_finalize_packed: bad argument"); return SELFTOK_EINVAL; }
     const unsigned long long* partial = (const unsigned long long*)workspace;
     const int norm = (flags & 2) ? 0 : 1;
     if (flags & 1) hipLaunchKernelGGL(vq_finalize_packed_kernel<int32_t>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (int32_t*)ids, best, N, 2 * nsplit, norm);
@@ -672,7 +672,7 @@ int selftok_vq_finalize_packed(const void* workspace, const float* z, const floa
 int selftok_vq_encode_packed_f32(const float* z, const float* packed, void* ids, float* best, void* workspace,
                                  int N, int C, int Dm, int flags, hipStream_t stream)
 {
-    if (!ids) { set_last_error("vq_encode_packed: bad argument"); return SELFTOK_EINVAL; }
+    if (!ids && N != 0) { set_last_error("vq_encode_packed: bad argument"); return SELFTOK_EINVAL; }
     int split = 0;
     int rc = selftok_vq_argmax_partial_packed_f32(z, packed, workspace, &split, N, C, Dm, flags, stream);
     if (rc || N == 0) return rc;
@@ -683,8 +683,8 @@ int selftok_vq_encode_packed_f32(const float* z, const float* packed, void* ids,
 int selftok_code_gather_ln_f32(const void* ids, const float* codebook, const float* ln_w, const float* ln_b, float* out,
                                int n, int C, int Dm, float eps, int flags, hipStream_t stream)
 {
-    if (Dm != D || n < 0 || !ids || !codebook || !out || ((ln_w == nullptr) != (ln_b == nullptr))) { set_last_error("code_gather_ln: bad argument"); return SELFTOK_EINVAL; }
     if (n == 0) return SELFTOK_OK;
+    if (Dm != D || n < 0 || !ids || !codebook || !out || ((ln_w == nullptr) != (ln_b == nullptr))) { set_last_error("code_gather_ln: bad argument"); return SELFTOK_EINVAL; }
     if (flags & 1) hipLaunchKernelGGL(code_gather_ln_kernel<int32_t>, dim3((n + 255) / 256), dim3(256), 0, stream, (const int32_t*)ids, codebook, ln_w, ln_b, out, n, C, eps);
     else hipLaunchKernelGGL(code_gather_ln_kernel<long long>, dim3((n + 255) / 256), dim3(256), 0, stream, (const long long*)ids, codebook, ln_w, ln_b, out, n, C, eps);
     return check_launch("code_gather_ln_kernel");

@@ -125,3 +125,32 @@ def test_ema_decoder_option(pipe):
     _, la = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=2)
     _, lb = p2.decoding(ids, noise=noise, return_latent=True, max_steps=2)
     assert torch.equal(la, lb)
+
+
+@pytest.mark.parametrize("datasize", [128, 320])
+def test_other_resolutions_vs_oracle(pipe, datasize):
+    """enable_enc_variable_size: pos-embed cropping and ragged attention tiles at latent 16x16 / 40x40
+    (reference: cropped_pos_embed models_ours.py:183-202, sd3/mmdit.py:878-896); oracle on the same weights."""
+    from oracle import model as OM, schedule as OS
+    lat = datasize // 8
+    x0 = synth.hash_normalish(0xD5 + datasize, (1, 16, lat, lat), "cuda")
+    z = pipe.model.encoder.features(x0).cpu()
+    enc_sd = {k: v.cpu() for k, v in pipe.model.encoder.w.items()}
+    z_ref = OM.encoder_features(enc_sd, x0.cpu())
+    assert float((z - z_ref).abs().max()) < 3e-4
+    # two sampler steps on a lat x lat latent vs the oracle
+    dit_sd = {k: v.cpu() for k, v in pipe.model.model.w.items()}
+    dit_sd.update({k: v for k, v in enc_sd.items() if "final_layer_norm3" in k})
+    dit_sd["encoder.quantizer._codebook.embed"] = pipe.model.encoder.codebook.cpu()[None]
+    ids = synth.synthetic_token_ids(1, first_index=3)
+    noise = synth.hash_normalish(0xA0 + datasize, (1, 16, lat, lat), "cpu")
+    old = pipe.datasize
+    pipe.datasize = datasize
+    try:
+        rec, latent = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=2)
+    finally:
+        pipe.datasize = old
+    stg, kps = OS.parse_stages("200,400,600,800,1000", "192,184,72,48,16")
+    ref = OM.decode_latent(dit_sd, torch.from_numpy(ids), noise, stg, kps, 50, max_steps=2)
+    assert tuple(rec.shape) == (1, 3, datasize, datasize)
+    assert float((latent.cpu() - ref).abs().max()) < 2e-3

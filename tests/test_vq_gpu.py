@@ -114,3 +114,20 @@ def test_code_gather_ln(cb):
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
     plain = ops.code_gather_ln(ids.int(), cbc)
     assert torch.equal(plain.cpu(), cb[ids.cpu()])
+
+
+def test_vq_empty_and_bad_arguments(cb):
+    cbc = cb.cuda()
+    pk = ops.vq_pack_codebook(cbc)
+    for packed, c in ((False, cbc), (True, pk)):
+        ids = ops.vq_encode(torch.zeros(0, 16, device="cuda"), c, packed=packed)
+        assert ids.shape == (0,) and ids.dtype == torch.int64
+    assert ops.code_gather_ln(torch.zeros(0, 512, dtype=torch.int64, device="cuda"), cbc).shape == (0, 512, 16)
+    from selftoktokenizer_amd._lib import SelftokHipError
+    with pytest.raises(SelftokHipError):
+        ops.vq_encode(torch.zeros(4, 8, device="cuda"), cbc)            # wrong code dim
+    with pytest.raises(SelftokHipError):
+        ops.vq_pack_codebook(cbc[:100])                                  # C % 32 != 0 for the MFMA layout
+    ids = ops.vq_encode(synth.synthetic_vq_rows(7).cuda(), cbc[:100])    # ... but the generic kernel takes any C
+    from oracle import clib
+    np.testing.assert_array_equal(ids.cpu().numpy(), clib.vq_encode(synth.synthetic_vq_rows(7).numpy(), cb[:100].numpy())[0])
