@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libselftok_hip.so")
+LIB_PATH = os.environ.get("SELFTOK_HIP_LIB") or os.path.join(_HERE, "libselftok_hip.so")   # override: ablation builds (tools/)
 
 _vp, _i, _f, _sz, _l = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
 

@@ -237,8 +237,14 @@ __global__ __launch_bounds__(256) void vq_valu_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// packed layout: tile t (32 codes) = 512 floats; lane l = (h = l>>5, i = l&31) owns 8 consecutive
-// floats e[t*32+i][2m+h], m = 0..7  -- exactly the A fragments of the 8 chained 32x32x2 MFMAs.
+// packed layout: tile t (32 codes) = 512 floats = [part 0..1][lane 0..63][4 floats]; lane l = (h = l>>5, i = l&31)
+// owns e[t*32+i][2m+h] for m = 4*part + j -- exactly the A fragments of the 8 chained 32x32x2 MFMAs, stored so that
+// one wave reads (or DMAs into LDS) a whole 1 KiB (tile, part) piece with 16 B per lane, conflict-free.
+__device__ __forceinline__ int packed_offset(int i /*code in tile*/, int k /*element*/)
+{
+    const int m = k >> 1, lane = (k & 1) * 32 + i;
+    return (m >> 2) * 256 + lane * 4 + (m & 3);
+}
 // The word after the last tile (packed[C*16], zeroed by the caller) becomes non-zero if any code element could make a
 // score non-finite; the MFMA kernel then runs its exact NaN-aware scan instead of the fast one.
 __global__ void vq_pack_kernel(const float* __restrict__ cb, float* __restrict__ packed, int C)
@@ -246,9 +252,9 @@ __global__ void vq_pack_kernel(const float* __restrict__ cb, float* __restrict__
     int g = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (code, k)
     if (g >= C * D) return;
     int c = g >> 4, k = g & 15;
-    int t = c >> 5, i = c & 31, h = k & 1, m = k >> 1;
+    int t = c >> 5, i = c & 31;
     const float v = cb[g];
-    packed[(size_t)t * 512 + (h * 32 + i) * 8 + m] = v;
+    packed[(size_t)t * 512 + packed_offset(i, k)] = v;
     if (suspicious(v)) atomicOr(reinterpret_cast<unsigned int*>(packed) + (size_t)C * D, 1u);
 }
 
@@ -267,6 +273,11 @@ struct BestT {
 // recovered later by vq_finalize_packed_kernel, which recomputes the 16 candidate scores of that (tile, half).
 __device__ __forceinline__ void scanmax(BestT& b, const f32x16& acc, int tile)
 {
+#ifdef SELFTOK_VQ_ABLATE_SCAN      // tools/ ablation builds only: keep the accumulators live, skip the scan
+    asm volatile("" ::"v"(acc));
+    b.tile = tile;
+    return;
+#endif
     float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
     float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
     float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]);
@@ -306,11 +317,18 @@ __device__ __forceinline__ void scan16(BestT& b, const f32x16& acc, int tile)
     b.slot = slot;
 }
 
+constexpr int M_CH = 8;                 // code tiles per LDS chunk: 8 x 2 KiB = 16 KiB, double buffered
+
 template <int RT>
 __global__ __launch_bounds__(256) void vq_mfma_kernel(const float* __restrict__ z, const float* __restrict__ packed,
                                                       unsigned long long* __restrict__ partial, int N, int C,
                                                       int tiles_per_split, int normalize)
 {
+    // code tiles are staged HBM/L2 -> LDS once per workgroup by direct LDS-DMA (global_load_lds, 16 B per lane, no VGPR
+    // round trip) and shared by the 4 waves: without this every wave streams the whole code range through L1/L2
+    // (measured: ~20 TB/s of L2 traffic, the kernel's real bound at 77 % MFMA utilisation).
+    __shared__ __attribute__((aligned(16))) float s_frag[2][M_CH * 512];
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
     const int row0 = (blockIdx.x * 4 + wave) * 32 * RT;
@@ -318,6 +336,7 @@ __global__ __launch_bounds__(256) void vq_mfma_kernel(const float* __restrict__ 
     // B operands: B[k][j] = x[row j][k]; lane (half, col) holds k = 2m + half of row col
     float b[RT][8];
     bool xbad = false;
+    const uint32_t hmask = half ? 0xFFFFFFFFu : 0u;
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
         float zz[D], xx[D];
@@ -332,7 +351,8 @@ __global__ __launch_bounds__(256) void vq_mfma_kernel(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < D; ++k) xbad |= suspicious(xx[k]);
 #pragma unroll
-        for (int m = 0; m < 8; ++m) b[t][m] = half ? xx[2 * m + 1] : xx[2 * m];
+        for (int m = 0; m < 8; ++m)   // bit-select (not an indexed load: that would push xx[] into scratch/LDS)
+            b[t][m] = __uint_as_float((__float_as_uint(xx[2 * m + 1]) & hmask) | (__float_as_uint(xx[2 * m]) & ~hmask));
     }
     // exact (NaN-aware) scan only if this wave holds a non-finite row or the pack step flagged the codebook
     const bool slow = __any(xbad) || (reinterpret_cast<const uint32_t*>(packed)[(size_t)C * D] != 0u);
@@ -341,12 +361,11 @@ __global__ __launch_bounds__(256) void vq_mfma_kernel(const float* __restrict__ 
     const int tile_first = blockIdx.y * tiles_per_split;
     int tile_last = tile_first + tiles_per_split;
     if (tile_last > ntiles_total) tile_last = ntiles_total;
+    const int nt = tile_last - tile_first;
 
     BestT best[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) { best[t].v = -__builtin_inff(); best[t].tile = tile_first; best[t].slot = 0; best[t].nan = false; }
-
-    const float4* ap = reinterpret_cast<const float4*>(packed) + (size_t)tile_first * 128 + lane * 2;
 
     auto mfma_tile = [&](const float4& lo, const float4& hi, f32x16 (&acc)[RT]) {
         const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -358,50 +377,57 @@ __global__ __launch_bounds__(256) void vq_mfma_kernel(const float* __restrict__ 
             for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[t][m], acc[t], 0, 0, 0);
     };
 
-    if (tile_first < tile_last) {
-        if (!slow) {
-            // software pipeline: tile i+1's MFMAs are issued before tile i's accumulators are scanned, so a wave never
-            // waits on the latency of its last MFMA before it has more matrix work queued.
-            // (two accumulator sets and two fragment sets ping-pong: no register copies, loads run 2 tiles ahead)
+    // this wave's share of a chunk: pieces wave, wave+4, ... of the 2*M_CH (tile, part) pieces, 1 KiB each
+    auto stage = [&](int chunk, int buf) {
+#pragma unroll
+        for (int pi = wave; pi < 2 * M_CH; pi += 4) {
+            int tl = chunk * M_CH + (pi >> 1);
+            tl = tl < nt ? tl : nt - 1;                                   // ragged last chunk: re-read the last tile
+            const float* src = packed + (size_t)(tile_first + tl) * 512 + (pi & 1) * 256 + lane * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(&s_frag[buf][pi * 256]), 16, 0, 0);
+        }
+    };
+    auto frag_lo = [&](int buf, int j) { return *reinterpret_cast<const float4*>(&s_frag[buf][j * 512 + lane * 4]); };
+    auto frag_hi = [&](int buf, int j) { return *reinterpret_cast<const float4*>(&s_frag[buf][j * 512 + 256 + lane * 4]); };
+
+    if (nt > 0) {
+        const int nchunks = (nt + M_CH - 1) / M_CH;
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunks) stage(c + 1, buf ^ 1);                   // DMA the next chunk behind this chunk's MFMAs
+            const int base = c * M_CH;                                    // first tile of the chunk (relative)
+            const bool full = base + M_CH <= nt;
             f32x16 accA[RT], accB[RT];
-            const int nt = tile_last - tile_first;
-            // fragment of tile (tile_first + i); past the end the last tile is re-read (unconditional loads: a
-            // load-or-zero select makes hipcc branch around every dword) and those MFMA results are never scanned
-            auto frag = [&](int i, int part) -> float4 { return ap[(size_t)(i < nt ? i : nt - 1) * 128 + part]; };
-            float4 f0lo = frag(0, 0), f0hi = frag(0, 1);                 // even tiles
-            float4 f1lo = frag(1, 0), f1hi = frag(1, 1);                 // odd tiles
-            mfma_tile(f0lo, f0hi, accA);                                 // tile 0 -> accA
-            f0lo = frag(2, 0); f0hi = frag(2, 1);
-            int i = 0;                                                   // accA holds tile i (even), f1 = tile i+1, f0 = tile i+2
-            for (; i + 2 < nt; i += 2) {
-                mfma_tile(f1lo, f1hi, accB);                             // tile i+1
-                f1lo = frag(i + 3, 0); f1hi = frag(i + 3, 1);
+            if (!slow && full) {
+                // two accumulator sets ping-pong: the scan of tile j is issued after the MFMAs of tile j+1
+                mfma_tile(frag_lo(buf, 0), frag_hi(buf, 0), accA);
 #pragma unroll
-                for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile_first + i);
-                mfma_tile(f0lo, f0hi, accA);                             // tile i+2
-                f0lo = frag(i + 4, 0); f0hi = frag(i + 4, 1);
+                for (int j = 0; j < M_CH; j += 2) {
+                    mfma_tile(frag_lo(buf, j + 1), frag_hi(buf, j + 1), accB);
 #pragma unroll
-                for (int t = 0; t < RT; ++t) scanmax(best[t], accB[t], tile_first + i + 1);
-            }
-            // tail: accA holds tile i; tile i+1 may exist (fragments in f1)
-            if (i + 1 < nt) {
-                mfma_tile(f1lo, f1hi, accB);
+                    for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile_first + base + j);
+                    if (j + 2 < M_CH) mfma_tile(frag_lo(buf, j + 2), frag_hi(buf, j + 2), accA);
 #pragma unroll
-                for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile_first + i);
-#pragma unroll
-                for (int t = 0; t < RT; ++t) scanmax(best[t], accB[t], tile_first + i + 1);
+                    for (int t = 0; t < RT; ++t) scanmax(best[t], accB[t], tile_first + base + j + 1);
+                }
             } else {
+                for (int j = 0; j < M_CH && base + j < nt; ++j) {
+                    mfma_tile(frag_lo(buf, j), frag_hi(buf, j), accA);
+                    if (slow) {
 #pragma unroll
-                for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile_first + i);
-            }
-        } else {
-            for (int tile = tile_first; tile < tile_last; ++tile) {
-                f32x16 acc[RT];
-                mfma_tile(ap[0], ap[1], acc);
-                ap += 128;
+                        for (int t = 0; t < RT; ++t) scan16<true>(best[t], accA[t], tile_first + base + j);
+                    } else {
 #pragma unroll
-                for (int t = 0; t < RT; ++t) scan16<true>(best[t], acc[t], tile);
+                        for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile_first + base + j);
+                    }
+                }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // my DMAs of chunk c+1 have landed
+            __syncthreads();                                              // everyone's have, and chunk c's buffer is free
         }
     }
 
@@ -472,7 +498,7 @@ __global__ __launch_bounds__(256) void vq_finalize_packed_kernel(const unsigned 
                 const int i = (slot & 3) + 8 * (slot >> 2) + 4 * half;      // code inside the tile
                 float sc = 0.f;
 #pragma unroll
-                for (int k = 0; k < D; ++k) sc = __builtin_fmaf(x[k], pt[((k & 1) * 32 + i) * 8 + (k >> 1)], sc);
+                for (int k = 0; k < D; ++k) sc = __builtin_fmaf(x[k], pt[packed_offset(i, k)], sc);
                 unsigned long long beq = __ballot(sc == vmax);
                 uint32_t meq = (uint32_t)((beq >> ((threadIdx.x & 63) & ~15)) & 0xFFFFu);
                 const int win = meq ? (__ffs(meq) - 1) : 0;               // first slot equal to the maximum

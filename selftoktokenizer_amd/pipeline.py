@@ -150,6 +150,7 @@ class SelftokPipeline():
         self.k_table = self.diti.to_indices(self.flow.t_long)                # k for each of the 50 steps
         self.cond_vary = True
         self.saved_images = 8
+        self._graphs = {}        # (B, latent, steps, scale) -> (hipGraph, static noise, static ehs, static output)
 
     def _say(self, msg):
         if self.verbose:          # the reference prints these progress lines unconditionally (:192,212,223,230,292,299,320)
@@ -183,8 +184,36 @@ class SelftokPipeline():
         return norm_ip(recons, -1, 1)
 
     @torch.no_grad()
+    def _sample(self, xt, ehs, max_steps, uncond_scale, use_graph):
+        """the 50-step loop, optionally replayed from a hipGraph captured once per (batch, latent size) -- the loop is
+        ~21k kernel launches; at small batch the host cannot issue them as fast as the GPU retires them."""
+        if not use_graph:
+            return self.flow.p_sample_loop(self.model.model, xt, ehs, self.k_table, context_see_xt=True,
+                                           uncond_scale=uncond_scale, max_steps=max_steps)
+        key = (tuple(xt.shape), tuple(ehs.shape), max_steps, float(uncond_scale))
+        if key not in self._graphs:
+            s_noise = torch.empty(xt.shape, dtype=torch.float32, device=self.device)
+            s_ehs = torch.empty_like(ehs)
+            s_noise.copy_(xt); s_ehs.copy_(ehs)
+            run = lambda: self.flow.p_sample_loop(self.model.model, s_noise, s_ehs, self.k_table, context_see_xt=True,
+                                                  uncond_scale=uncond_scale, max_steps=max_steps)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):       # warm-up outside capture (hipBLASLt / allocator warm)
+                run()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                s_out = run()
+            self._graphs[key] = (g, s_noise, s_ehs, s_out)
+        g, s_noise, s_ehs, s_out = self._graphs[key]
+        s_noise.copy_(xt.to(self.device)); s_ehs.copy_(ehs)
+        g.replay()
+        return s_out.clone()
+
+    @torch.no_grad()
     def decoding(self, idx, device=None, noise: Optional[torch.Tensor] = None, return_latent: bool = False,
-                 max_steps: Optional[int] = None, uncond_scale: float = 1.0):
+                 max_steps: Optional[int] = None, uncond_scale: float = 1.0, use_graph: bool = False):
         """idx: np.ndarray int64 [B,K] -> bf16 [B,3,H,W] in [0,1] (reference :227-294).  `noise` (extension) replaces the
         `torch.randn` draw from the global CPU generator (:264); `uncond_scale` exposes the dormant CFG branch."""
         self._say("Begin decoding.")
@@ -195,8 +224,7 @@ class SelftokPipeline():
         ehs = outs_q if k0 >= self.K - 1 else outs_q * (torch.arange(self.K, device=self.device) <= k0)[None, :, None]
         latent_dim = self.datasize // 8
         xt = noise if noise is not None else torch.randn(B, 16, latent_dim, latent_dim)
-        pred_x0 = self.flow.p_sample_loop(self.model.model, xt, ehs, self.k_table, context_see_xt=True,
-                                          uncond_scale=uncond_scale, max_steps=max_steps)
+        pred_x0 = self._sample(xt, ehs, max_steps, uncond_scale, use_graph)
         recons = self._to_pixels(pred_x0)
         self._say('End decoding.')
         return (recons, pred_x0) if return_latent else recons

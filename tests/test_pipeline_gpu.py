@@ -154,3 +154,15 @@ def test_other_resolutions_vs_oracle(pipe, datasize):
     ref = OM.decode_latent(dit_sd, torch.from_numpy(ids), noise, stg, kps, 50, max_steps=2)
     assert tuple(rec.shape) == (1, 3, datasize, datasize)
     assert float((latent.cpu() - ref).abs().max()) < 2e-3
+
+
+def test_hipgraph_replay_equals_eager(pipe):
+    """the sampler loop captured into a hipGraph (use_graph=True) replays bit-identically, also on new inputs"""
+    ids, noise = synth.synthetic_token_ids(2), synth.synthetic_noise(2)
+    _, eager = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=3)
+    _, g1 = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=3, use_graph=True)     # capture + replay
+    assert torch.equal(eager, g1)
+    ids2, noise2 = synth.synthetic_token_ids(2, first_index=5), synth.synthetic_noise(2, first_index=5)
+    _, eager2 = pipe.decoding(ids2, noise=noise2, return_latent=True, max_steps=3)
+    _, g2 = pipe.decoding(ids2, noise=noise2, return_latent=True, max_steps=3, use_graph=True)   # replay only
+    assert torch.equal(eager2, g2)
