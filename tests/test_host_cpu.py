@@ -170,3 +170,20 @@ def test_checkpoint_loaders(tmp_path):
     torch.save(ldm, str(tmp_path / "sd3_medium.pt"))
     got = W.load_vae_checkpoint(str(tmp_path / "sd3_medium.pt"))
     assert set(got) == {k_lin, "encoder.conv_in.bias"} and got[k_lin].shape == (512, 512)
+
+
+def test_preprocess_matches_reference_transform_chain(tmp_path):
+    """Resize(256) -> CenterCrop(256) -> NormalizeToTensor on a 1200x630-like image (reference test.py:27-31)"""
+    from PIL import Image
+    from selftoktokenizer_amd import preprocess
+    rng = np.random.RandomState(0)
+    arr = rng.randint(0, 256, size=(63, 120, 3)).astype(np.uint8)
+    p = str(tmp_path / "im.png")
+    Image.fromarray(arr).save(p)
+    t = preprocess.load_image(p, 32)
+    assert t.shape == (3, 32, 32) and float(t.min()) >= -1 and float(t.max()) <= 1
+    r = preprocess.resize_shorter_side(Image.fromarray(arr), 32)
+    assert r.size == (60, 32)                                   # int(32*120/63) = 60: torchvision's truncation
+    preprocess.save_image((t + 1) / 2, str(tmp_path / "o.png"))
+    back = np.array(Image.open(str(tmp_path / "o.png")))
+    assert back.shape == (32, 32, 3)
