@@ -121,15 +121,13 @@ class QformerEncoderGPU:
                           ENC_QHEADS, Q // ENC_QHEADS)
             # latent stream: x += proj(attn); x += mlp(LN(x))
             x, xn2 = ops.residual_ln_mod(x, y=self.lin(p + ".attn.proj", xa))
-            h = torch.matmul(xn2, self.w[p + ".mlp.fc1.weight"].t())
-            ops.bias_gelu_(h, self.w[p + ".mlp.fc1.bias"])
+            h = ops.linear_gelu(xn2, self.w[p + ".mlp.fc1.weight"], self.w[p + ".mlp.fc1.bias"])
             last = i == ENC_DEPTH - 1
             x, xn = ops.residual_ln_mod(x, y=self.lin(p + ".mlp.fc2", h), want_n=not last)
             # query stream: q += g1*proj(attn); q += g2*mlp(mod(LN(q)))
             q, qn2 = ops.residual_ln_mod(q, y=self.lin(p + ".attn.query_proj", qa), gate=t[:, 2 * Q:3 * Q],
                                          shift=t[:, 3 * Q:4 * Q], scale=t[:, 4 * Q:5 * Q])
-            h = torch.matmul(qn2, self.w[p + ".q_mlp.fc1.weight"].t())
-            ops.bias_gelu_(h, self.w[p + ".q_mlp.fc1.bias"])
+            h = ops.linear_gelu(qn2, self.w[p + ".q_mlp.fc1.weight"], self.w[p + ".q_mlp.fc1.bias"])
             m = self.lin(p + ".q_mlp.fc2", h)
             if last:
                 q, _ = ops.residual_ln_mod(q, y=m, gate=t[:, 5 * Q:6 * Q], want_n=False)

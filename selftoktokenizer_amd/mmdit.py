@@ -116,8 +116,7 @@ class MMDiTGPU:
                 t = tab[i]
                 ctx, cn2 = ops.residual_ln_mod(ctx, y=self.lin(pc + ".attn.proj", oc), gate=t[:, 2 * H:3 * H],
                                                shift=t[:, 3 * H:4 * H], scale=t[:, 4 * H:5 * H])
-                h = torch.matmul(cn2, self.w[pc + ".mlp.fc1.weight"].t())
-                ops.bias_gelu_(h, self.w[pc + ".mlp.fc1.bias"])
+                h = ops.linear_gelu(cn2, self.w[pc + ".mlp.fc1.weight"], self.w[pc + ".mlp.fc1.bias"])
                 m = self.lin(pc + ".mlp.fc2", h)
                 if i + 1 < DIT_DEPTH - 1:
                     tn = tab[i + 1]
@@ -129,8 +128,7 @@ class MMDiTGPU:
             mx = mods_x[i]
             x, xn2 = ops.residual_ln_mod(x, y=self.lin(px + ".attn.proj", ox), gate=mx[:, 2 * H:3 * H],
                                          shift=mx[:, 3 * H:4 * H], scale=mx[:, 4 * H:5 * H], per_sample=True)
-            h = torch.matmul(xn2, self.w[px + ".mlp.fc1.weight"].t())
-            ops.bias_gelu_(h, self.w[px + ".mlp.fc1.bias"])
+            h = ops.linear_gelu(xn2, self.w[px + ".mlp.fc1.weight"], self.w[px + ".mlp.fc1.bias"])
             m = self.lin(px + ".mlp.fc2", h)
             if not last:
                 mn = mods_x[i + 1]

@@ -112,6 +112,16 @@ def bias_gelu_(h, bias=None):
     return h
 
 
+def linear_gelu(x, weight, bias):
+    """gelu_tanh(x @ weight.T + bias) -- Mlp.fc1 + act (sd3/other_impls.py:86-88; timm Mlp modules.py:109,293).
+    The bias add and the tanh-GELU ride in hipBLASLt's GEMM epilogue (one pass less over the [rows, 4H] hidden tensor:
+    -8 % per MLP GEMM, measured equal to GEMM + selftok_bias_gelu_f32 to 5e-7); `bias_gelu_` remains the stand-alone kernel."""
+    _need_cuda(x, weight)
+    shp = x.shape
+    out = torch._addmm_activation(bias, x.reshape(-1, shp[-1]), weight.t(), use_gelu=True)
+    return out.reshape(*shp[:-1], weight.shape[0])
+
+
 def silu(x):
     _need_cuda(x)
     x = x.contiguous()
