@@ -115,7 +115,11 @@ def main():
     from selftoktokenizer_amd.config import default_config
     from selftoktokenizer_amd.pipeline import SelftokPipeline
 
-    rank, world, local = D.init_from_env("nccl")
+    # SELFTOK_DIST_BACKEND=gloo + SELFTOK_ONE_GPU=1: dry run of the N>1 flow with every rank on GPU 0 (single-GPU boxes)
+    one_gpu = os.environ.get("SELFTOK_ONE_GPU") == "1"
+    if one_gpu:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = D.init_from_env(os.environ.get("SELFTOK_DIST_BACKEND", "nccl"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -124,8 +128,7 @@ def main():
     cfg = default_config(K, renderer=renderer)
     sd = W.synthetic_state_dict(W.expected_shapes(K, renderer=renderer), device=dev)
     vsd = W.synthetic_vae_state_dict(device=dev)
-    pipe = SelftokPipeline(cfg, None, None, device=dev, state_dict=sd, vae_state_dict=vsd)
-    pipe.verbose = False
+    pipe = SelftokPipeline(cfg, None, None, device=dev, state_dict=sd, vae_state_dict=vsd, verbose=False)
 
     images = synth.synthetic_images(B, device=dev, first_index=rank * B)          # resident in HBM
     noise = synth.synthetic_noise(B, device=dev, first_index=rank * B)

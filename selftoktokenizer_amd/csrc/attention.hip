@@ -163,12 +163,15 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
             for (int r = 0; r < 16; ++r)
                 if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= nkeys) sc[r] = -__builtin_inff();
         }
-        float mx = sc[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+        float mx;
+        {   // 16 -> 1 with v_max3_f32 (7 ops instead of 15)
+            float m0 = fmaxf(fmaxf(sc[0], sc[1]), sc[2]), m1 = fmaxf(fmaxf(sc[3], sc[4]), sc[5]);
+            float m2 = fmaxf(fmaxf(sc[6], sc[7]), sc[8]), m3 = fmaxf(fmaxf(sc[9], sc[10]), sc[11]);
+            float m4 = fmaxf(fmaxf(sc[12], sc[13]), sc[14]);
+            mx = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), sc[15]));
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
         const float m_new = fmaxf(m_run, mx * c);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -176,10 +179,16 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
             sc[r] = p;
             psum += p;
         }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+        // the running maximum of a row stops moving after the first few tiles: when it did not move for ANY row of this
+        // wave the rescale factor is exactly 1 and the 32 accumulator multiplies are skipped (exact, not a threshold)
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            m_run = m_new;
+        }
+        l_run += psum;
 
         // ---- O^T[d][q] += sum_key V[key][d] P[q][key];  MFMA m carries keys (m&3)+8*(m>>2) (+4 for half 1) ----
 #pragma unroll

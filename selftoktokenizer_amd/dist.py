@@ -45,6 +45,9 @@ def all_gather_ids(ids_local: torch.Tensor) -> torch.Tensor:
         return ids_local
     world = dist.get_world_size()
     K = ids_local.shape[1]
+    out_device = ids_local.device
+    if dist.get_backend() == "gloo" and ids_local.is_cuda:      # CPU collective (tests / single-GPU dry runs of the N>1 flow)
+        ids_local = ids_local.cpu()
     n_local = torch.tensor([ids_local.shape[0]], dtype=torch.int64, device=ids_local.device)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local)
@@ -54,7 +57,7 @@ def all_gather_ids(ids_local: torch.Tensor) -> torch.Tensor:
     send[: ids_local.shape[0]] = ids_local.to(torch.int32)
     bufs = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(bufs, send)                       # ncclAllGather over xGMI on the GPU box
-    return torch.cat([bufs[r][: counts[r]] for r in range(world)]).to(ids_local.dtype)
+    return torch.cat([bufs[r][: counts[r]] for r in range(world)]).to(ids_local.dtype).to(out_device)
 
 
 def barrier():
@@ -68,6 +71,6 @@ def barrier():
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

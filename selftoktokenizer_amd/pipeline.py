@@ -105,7 +105,7 @@ class _Flow(FlowSchedule):
 class SelftokPipeline():
     def __init__(self, cfg, ckpt_path, sd3_path, datasize=256, start=1.0, cfg_scale=1, model_type='sd3',
                  dtype=torch.bfloat16, ema_decoder=False, device=None, state_dict: Optional[Dict[str, torch.Tensor]] = None,
-                 vae_state_dict: Optional[Dict[str, torch.Tensor]] = None):
+                 vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, verbose: bool = True):
         """cfg: parse_args_from_yaml(...) ; ckpt_path: tokenizer .pth ; sd3_path: diffusers SD3 folder (…/vae/…).
         `state_dict` / `vae_state_dict` (extensions) bypass the files, e.g. with weights.synthetic_state_dict()."""
         _lib.load()                                                           # fail loudly if the HIP library is missing
@@ -129,7 +129,7 @@ class SelftokPipeline():
         vsd = vae_state_dict if vae_state_dict is not None else W.load_vae_checkpoint(sd3_path)
         self.vae = AutoencoderKLGPU(vsd, self.device, dtype)
 
-        self.verbose = True
+        self.verbose = verbose
         self._say("Loading all...")
         sd = state_dict if state_dict is not None else W.load_tokenizer_checkpoint(ckpt_path)
         self.ema_decoder = ema_decoder
