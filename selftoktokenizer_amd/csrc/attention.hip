@@ -54,8 +54,9 @@ constexpr int QROWS = 128;       // query rows per workgroup
 
 __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
 {
-    __shared__ __attribute__((aligned(16))) float s_k[KT * KSTR];
-    __shared__ __attribute__((aligned(16))) float s_v[KT * 64];
+    // K and V tiles, double buffered: tile t+1 is written while tile t is being consumed -> one barrier per tile
+    __shared__ __attribute__((aligned(16))) float s_kb[2][KT * KSTR];
+    __shared__ __attribute__((aligned(16))) float s_vb[2][KT * 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
@@ -129,20 +130,24 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
     const int ntiles = nt0 + nt1;
     if (ntiles == 0) return;
     issue_loads(nt0 > 0 ? 0 : 1, 0, nt0 > 0 ? n0 : n1);
+    auto write_tile = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int key = st_key + 16 * u;
+            *reinterpret_cast<float4*>(&s_kb[buf][key * KSTR + st_part * 4]) = rk[u];
+            *reinterpret_cast<float4*>(&s_vb[buf][key * 64 + st_part * 4]) = rv[u];
+        }
+    };
+    write_tile(0);
+    __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         const int seg = t < nt0 ? 0 : 1;
         const int key0 = (seg == 0 ? t : t - nt0) * KT;
         const int nkeys = seg == 0 ? n0 : n1;
-        __syncthreads();                                     // everyone is done reading the previous tile
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            int key = st_key + 16 * u;
-            *reinterpret_cast<float4*>(&s_k[key * KSTR + st_part * 4]) = rk[u];
-            *reinterpret_cast<float4*>(&s_v[key * 64 + st_part * 4]) = rv[u];
-        }
-        __syncthreads();
-        if (t + 1 < ntiles) {                                // prefetch the next tile behind this tile's MFMAs
+        const float* s_k = s_kb[t & 1];
+        const float* s_v = s_vb[t & 1];
+        if (t + 1 < ntiles) {                                // global loads of the next tile fly behind this tile's MFMAs
             const int seg_n = (t + 1) < nt0 ? 0 : 1;
             issue_loads(seg_n, (seg_n == 0 ? t + 1 : t + 1 - nt0) * KT, seg_n == 0 ? n0 : n1);
         }
@@ -199,6 +204,8 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sc[m], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sc[m], o1, 0, 0, 0);
         }
+        if (t + 1 < ntiles) write_tile((t + 1) & 1);        // that buffer was last read in iteration t-1 (barrier below)
+        __syncthreads();
     }
 
     // ---- epilogue: O[q][d] = O^T / l ----
