@@ -16,6 +16,7 @@ from __future__ import annotations
 import math
 from typing import Dict
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -59,7 +60,7 @@ class QformerEncoderGPU:
         self.pe_w = self.w["encoder.x_embedder.proj.weight"].reshape(ENC_HIDDEN, -1).t().contiguous()
         self._pos_cache = {}
         # input-independent adaLN tables: Linear(SiLU(t_embedder(1000+8k)))  [K, 6*512] per block
-        pos_emb = sinusoid_host(torch.from_numpy(DiTiCont.get_position(__import__("numpy").arange(K))).to(torch.int64)).to(device)
+        pos_emb = sinusoid_host(torch.from_numpy(DiTiCont.get_position(np.arange(K))).to(torch.int64)).to(device)
         self.tables = []
         for i in range(ENC_DEPTH):
             p = f"encoder.blocks.{i}"

@@ -3,7 +3,6 @@ Resize(size) [shorter side, bilinear + antialias on PIL images] -> CenterCrop(si
 `save_image` for the [0,1] outputs of `decoding`."""
 from __future__ import annotations
 
-import numpy as np
 import torch
 from PIL import Image
 

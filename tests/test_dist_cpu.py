@@ -1,7 +1,6 @@
 """not gpu: the N>1 path (batch sharding + id all-gather) with world_size 2 over gloo on CPU."""
 import os
 
-import numpy as np
 import torch
 import torch.multiprocessing as mp
 

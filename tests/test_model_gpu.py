@@ -13,7 +13,6 @@ import pytest
 import torch
 
 from selftoktokenizer_amd import ops, synth, weights as W
-from selftoktokenizer_amd.config import default_config
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")

@@ -2,7 +2,7 @@
 import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from selftoktokenizer_amd import ops, synth, weights as W
+from selftoktokenizer_amd import synth, weights as W
 from selftoktokenizer_amd.vae import AutoencoderKLGPU
 
 def timeit(fn, n=3, warm=1):
