@@ -78,8 +78,17 @@ class MMDiTGPU:
 
     # ---- the 24 joint blocks + final layer ---------------------------------------------------------
     @torch.no_grad()
+    def block0_context_qkv(self, ctx0: torch.Tensor) -> torch.Tensor:
+        """QKV of the context stream in block 0: LN(ctx0)*(1+scale)+shift -> Linear.  Depends on the tokens only (not on
+        x_t or t), so the sampler computes it once per decode instead of once per step (the reference recomputes it)."""
+        H = DIT_HIDDEN
+        t0 = self.ctx_tables[0][: ctx0.shape[1]]
+        _, cn = ops.residual_ln_mod(ctx0, shift=t0[:, 0:H], scale=t0[:, H:2 * H])
+        return self.lin("model.joint_blocks.0.context_block.attn.qkv", cn)
+
+    @torch.no_grad()
     def core(self, xe: torch.Tensor, c: torch.Tensor, ctx: Optional[torch.Tensor], seg0_sees_seg1: bool = True,
-             kvis: Optional[torch.Tensor] = None) -> torch.Tensor:
+             kvis: Optional[torch.Tensor] = None, cqkv0: Optional[torch.Tensor] = None) -> torch.Tensor:
         """xe [B,n_x,H] embedded image tokens, c [B,H], ctx [B,n_ctx,H] live context tokens (or None / n_ctx = 0)
         -> FinalLayer output [B,n_x,64] (before unpatchify)."""
         H, NH = DIT_HIDDEN, DIT_HEADS
@@ -93,7 +102,7 @@ class MMDiTGPU:
         tab = [t[:n] for t in self.ctx_tables]
         x = xe
         _, xn = ops.residual_ln_mod(x, shift=mods_x[0][:, 0:H], scale=mods_x[0][:, H:2 * H], per_sample=True)
-        if has_ctx:
+        if has_ctx and cqkv0 is None:
             _, cn = ops.residual_ln_mod(ctx, shift=tab[0][:, 0:H], scale=tab[0][:, H:2 * H])
         for i in range(DIT_DEPTH):
             pc, px = f"model.joint_blocks.{i}.context_block", f"model.joint_blocks.{i}.x_block"
@@ -102,7 +111,8 @@ class MMDiTGPU:
             ox = torch.empty(B, nx, H, device=x.device)
             seg1 = (xqkv[..., :H], xqkv[..., H:2 * H], xqkv[..., 2 * H:], ox)
             if has_ctx:
-                cqkv = self.lin(pc + ".attn.qkv", cn)                              # [B,n,3H]
+                # [B,n,3H]; block 0's is step-invariant and may come precomputed (a strided [:, :n] view is fine)
+                cqkv = cqkv0[:, :n] if (i == 0 and cqkv0 is not None) else self.lin(pc + ".attn.qkv", cn)
                 if last:   # pre_only context block: keys/values only, its attention output is discarded (sd3/mmdit.py:544-547)
                     seg0 = (None, cqkv[..., H:2 * H], cqkv[..., 2 * H:], None)
                 else:
@@ -146,11 +156,11 @@ class MMDiTGPU:
         return ops.add_rows_(xe, self._pos_bias(Hh // 2, Ww // 2))
 
     @torch.no_grad()
-    def velocity_tokens(self, x, t_freq, ctx0, n_live: int, context_see_xt: bool = True):
+    def velocity_tokens(self, x, t_freq, ctx0, n_live: int, context_see_xt: bool = True, cqkv0=None):
         """one model evaluation inside the sampler: returns the FinalLayer tokens [B,256,64]"""
         c = self.time_embed(t_freq)
         ctx = ctx0[:, :n_live].contiguous() if n_live < ctx0.shape[1] else ctx0
-        return self.core(self.embed_image(x), c, ctx if n_live > 0 else None, context_see_xt)
+        return self.core(self.embed_image(x), c, ctx if n_live > 0 else None, context_see_xt, cqkv0=cqkv0 if n_live > 0 else None)
 
     @torch.no_grad()
     def __call__(self, x=None, t=None, y=None, encoder_hidden_states=None, **kwargs):

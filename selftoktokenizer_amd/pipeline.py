@@ -83,17 +83,18 @@ class _Flow(FlowSchedule):
         x = noise.to(self.device).float().contiguous()
         hp, wp = x.shape[-2] // 2, x.shape[-1] // 2
         ctx0 = dit.embed_context(ehs)                                         # step independent
+        cqkv0 = dit.block0_context_qkv(ctx0)                                  # so is block 0's context QKV
         steps = self.num_timesteps if max_steps is None else min(max_steps, self.num_timesteps)
         for i in range(steps):
             n_live = int(k_table[i]) + 1                                      # mask = arange(K) <= k  (models_ours.py:353)
             tf = self.t_freq[i:i + 1].expand(B, -1).contiguous()
             if uncond_scale == 1.0:
-                y = dit.velocity_tokens(x, tf, ctx0, n_live, context_see_xt)
+                y = dit.velocity_tokens(x, tf, ctx0, n_live, context_see_xt, cqkv0)
                 yu = None
             else:
                 # CFG branch (rectified_flow.py:280-289): the conditional call omits context_see_xt (-> False) and
                 # the unconditional one sees no context token at all
-                y = dit.velocity_tokens(x, tf, ctx0, n_live, False)
+                y = dit.velocity_tokens(x, tf, ctx0, n_live, False, cqkv0)
                 tfu = self.t_freq_uncond[i:i + 1].expand(B, -1).contiguous()
                 yu = dit.velocity_tokens(x, tfu, ctx0, 0, False)
             x, _ = ops.unpatchify_cfg_euler(y, x, float(self.dt[i]), y_uncond=yu, cfg_scale=uncond_scale, C=x.shape[1], hp=hp, wp=wp)
