@@ -25,9 +25,14 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            kw["device_id"] = torch.device("cuda", local)     # bind the communicator to this rank's GPU up front
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        except TypeError:                                      # older torch without device_id
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 

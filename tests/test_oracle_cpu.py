@@ -107,12 +107,19 @@ def test_vae_oracle_close_to_mirror():
     assert img.tolist() == [0.0, 0.0, 0.5, 0.75, 1.0]
 
 
-@pytest.mark.slow
-def test_dit_oracle_matches_reference():
-    """2.09 B synthetic parameters on CPU (~1-2 min): MMDiT.forward of the reference for three (t, k) pairs"""
-    g = gold("dit_forward_b1.npz")
+@pytest.fixture(scope="module")
+def dit_sd():
+    """2.09 B synthetic MMDiT parameters on CPU (~40 s), shared by the two slow tests"""
     shapes = W.expected_shapes(512)
-    sd = W.synthetic_state_dict({k: v for k, v in shapes.items() if k.startswith("model.") or "final_layer_norm3" in k or "_codebook.embed" == k[-15:]})
+    return W.synthetic_state_dict({k: v for k, v in shapes.items()
+                                   if k.startswith("model.") or "final_layer_norm3" in k or k.endswith("_codebook.embed")})
+
+
+@pytest.mark.slow
+def test_dit_oracle_matches_reference(dit_sd):
+    """MMDiT.forward of the reference for three (t, k) pairs"""
+    g = gold("dit_forward_b1.npz")
+    sd = dit_sd
     ids = torch.from_numpy(synth.synthetic_token_ids(1))
     ehs = OM.codes_from_ids(sd, ids)
     torch.testing.assert_close(ehs, torch.from_numpy(g["ehs"]), rtol=0, atol=1e-6)
@@ -123,6 +130,21 @@ def test_dit_oracle_matches_reference():
         mask = torch.arange(512)[None] <= int(g[f"k_{case}"])
         v = OM.dit_forward(sd, x, t, ehs, mask, True, tables)
         assert float((v - torch.from_numpy(g[f"v_{case}"])).abs().max()) <= 1e-5
+
+
+@pytest.mark.slow
+def test_sampler_oracle_matches_reference_pipeline_latents(dit_sd):
+    """the reference's own SelftokPipeline.decoding run (50-step flow, hash noise): DiT inputs captured at steps 1 and 2
+    = latents after 1 and 2 Euler steps; the oracle's decode_latent must reproduce them (same CPU arithmetic)"""
+    g = gold("pipeline_b1.npz")
+    sd = dit_sd
+    stg, kps = OS.parse_stages("200,400,600,800,1000", "192,184,72,48,16")
+    trace = []
+    OM.decode_latent(sd, torch.from_numpy(g["tokens"]), synth.synthetic_noise(1), stg, kps, 50, trace=trace, max_steps=2)
+    steps = list(g["lat_steps"])
+    for n_steps in (1, 2):
+        ref = torch.from_numpy(g["lats"][steps.index(n_steps)])
+        assert float((trace[n_steps - 1] - ref).abs().max()) <= 1e-5
 
 
 def test_pinning_report_is_committed():
