@@ -110,26 +110,39 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
     const int st_key = tid >> 4, st_part = tid & 15;   // + 16 keys for the second float4
     float4 rk[2], rv[2];
 
-    auto issue_loads = [&](int seg, int key0, int nkeys) {
+    // running per-thread source pointers (advanced by one tile per iteration; recomputed only at the segment switch):
+    // keeps the 64-bit address arithmetic out of the loop -- every VALU op next to fp32 MFMAs costs matrix-pipe time
+    const float* kp = nullptr;
+    const float* vp = nullptr;
+    long k_step = 0, v_step = 0, k_half = 0, v_half = 0;
+    auto set_segment = [&](int seg) {
         const AttnSeg& ks = P.seg[seg];
+        kp = ks.k + (size_t)b * ks.k_bs + (size_t)st_key * ks.k_rs + h * 64 + st_part * 4;
+        vp = ks.v + (size_t)b * ks.v_bs + (size_t)st_key * ks.v_rs + h * 64 + st_part * 4;
+        k_step = (long)KT * ks.k_rs; v_step = (long)KT * ks.v_rs;
+        k_half = 16 * ks.k_rs; v_half = 16 * ks.v_rs;
+    };
+    auto issue_loads = [&](int key0, int nkeys) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             int key = key0 + st_key + 16 * u;
             if (key < nkeys) {
-                rk[u] = *reinterpret_cast<const float4*>(ks.k + (size_t)b * ks.k_bs + (size_t)key * ks.k_rs + h * 64 + st_part * 4);
-                rv[u] = *reinterpret_cast<const float4*>(ks.v + (size_t)b * ks.v_bs + (size_t)key * ks.v_rs + h * 64 + st_part * 4);
+                rk[u] = *reinterpret_cast<const float4*>(kp + u * k_half);
+                rv[u] = *reinterpret_cast<const float4*>(vp + u * v_half);
             } else {
                 rk[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 rv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+        kp += k_step; vp += v_step;
     };
 
     // flattened tile list: segment 0 keys [0,n0) then segment 1 keys [0,n1)
     const int nt0 = (n0 + KT - 1) / KT, nt1 = (n1 + KT - 1) / KT;
     const int ntiles = nt0 + nt1;
     if (ntiles == 0) return;
-    issue_loads(nt0 > 0 ? 0 : 1, 0, nt0 > 0 ? n0 : n1);
+    set_segment(nt0 > 0 ? 0 : 1);
+    issue_loads(0, nt0 > 0 ? n0 : n1);
     auto write_tile = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -149,7 +162,8 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
         const float* s_v = s_vb[t & 1];
         if (t + 1 < ntiles) {                                // global loads of the next tile fly behind this tile's MFMAs
             const int seg_n = (t + 1) < nt0 ? 0 : 1;
-            issue_loads(seg_n, (seg_n == 0 ? t + 1 : t + 1 - nt0) * KT, seg_n == 0 ? n0 : n1);
+            if (t + 1 == nt0) set_segment(1);                // first tile of segment 1
+            issue_loads((seg_n == 0 ? t + 1 : t + 1 - nt0) * KT, seg_n == 0 ? n0 : n1);
         }
 
         // ---- S^T[key][q] = sum_dd K[key][dd] Q[q][dd] ----
