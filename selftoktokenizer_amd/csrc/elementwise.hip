@@ -9,6 +9,7 @@
 //   per-sample table [B, 6H]  (image stream 't_emb'):                        stride_b = 6H, stride_t = 0
 // so the reference's [B,T,H] broadcasts (modules.py:29-37, sd3/mmdit.py:78-83) are never materialised.
 #include "common.h"
+#include "selftok_hip.h"   // the C ABI declared there must match the definitions below
 
 namespace selftok {
 

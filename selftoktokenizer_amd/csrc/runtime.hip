@@ -1,5 +1,6 @@
 // Error plumbing + version for libselftok_hip.so (C ABI, no exceptions cross the boundary).
 #include "common.h"
+#include "selftok_hip.h"   // the C ABI declared there must match the definitions below
 #include <stdio.h>
 #include <string.h>
 

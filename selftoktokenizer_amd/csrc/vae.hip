@@ -5,6 +5,7 @@
 // bf16 (sd3_impls.py:215-254 GroupNorm -> SiLU; SelftokPipeline.py:135-137,216-218,285-290 for the
 // latent-format and norm_ip element-wise chains), so the fused kernels below round at the same points.
 #include "common.h"
+#include "selftok_hip.h"   // the C ABI declared there must match the definitions below
 #include <hip/hip_bf16.h>
 
 namespace selftok {

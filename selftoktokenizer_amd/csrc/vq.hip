@@ -27,6 +27,7 @@
 //
 // This file is compiled with -ffp-contract=off: every FMA below is explicit.
 #include "common.h"
+#include "selftok_hip.h"   // the C ABI declared there must match the definitions below
 #include <stdlib.h>
 
 namespace selftok {
