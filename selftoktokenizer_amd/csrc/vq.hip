@@ -279,6 +279,24 @@ __device__ __forceinline__ void scanmax(BestT& b, const f32x16& acc, int tile)
     b.tile = tile;
     return;
 #endif
+    // v_max3_f32 spelled out: `fmaxf` on MFMA results makes hipcc emit a canonicalising `v_max_f32 x,x` per chain
+    // (3 of 13 scan ops).  Inputs here are finite by the fast-path precondition.  The asm reads an accumulator set whose
+    // MFMAs were issued a full tile (>= 16 MFMAs) earlier -- the caller pins that order with sched_barrier -- so the
+    // MFMA-write -> VALU-read wait states hipcc cannot see inside asm are satisfied by construction.
+    auto max3 = [](float a, float bb, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(bb), "v"(c)); return r; };
+    const float m0 = max3(acc[0], acc[1], acc[2]), m1 = max3(acc[3], acc[4], acc[5]), m2 = max3(acc[6], acc[7], acc[8]);
+    const float m3 = max3(acc[9], acc[10], acc[11]), m4 = max3(acc[12], acc[13], acc[14]);
+    const float m5 = max3(m0, m1, m2), m6 = max3(m3, m4, acc[15]);
+    const float m = max3(m5, m6, b.v);   // includes the running best: g below is "strictly improved"
+    const bool g = m > b.v;              // strict: the earliest tile holding the maximum wins
+    b.v = m;
+    b.tile = g ? tile : b.tile;
+}
+
+// same scan with compiler-visible `fmaxf` (hipcc inserts the MFMA->VALU wait states itself): used where the scan directly
+// follows the MFMAs of the SAME accumulators (ragged last chunk), where the asm version above would be unsafe.
+__device__ __forceinline__ void scanmax_safe(BestT& b, const f32x16& acc, int tile)
+{
     float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
     float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
     float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]);
@@ -287,7 +305,7 @@ __device__ __forceinline__ void scanmax(BestT& b, const f32x16& acc, int tile)
     float m5 = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2);
     float m6 = __builtin_fmaxf(__builtin_fmaxf(m3, m4), acc[15]);
     const float m = __builtin_fmaxf(m5, m6);
-    const bool g = m > b.v;              // strict: the earliest tile holding the maximum wins
+    const bool g = m > b.v;
     b.v = g ? m : b.v;
     b.tile = g ? tile : b.tile;
 }
@@ -409,11 +427,15 @@ __global__ __launch_bounds__(256) void vq_mfma_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < M_CH; j += 2) {
                     mfma_tile(frag_lo(buf, j + 1), frag_hi(buf, j + 1), accB);
+                    __builtin_amdgcn_sched_barrier(0);        // the scan (inline asm) must stay behind accB's MFMAs
 #pragma unroll
                     for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile_first + base + j);
+                    __builtin_amdgcn_sched_barrier(0);
                     if (j + 2 < M_CH) mfma_tile(frag_lo(buf, j + 2), frag_hi(buf, j + 2), accA);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = 0; t < RT; ++t) scanmax(best[t], accB[t], tile_first + base + j + 1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
                 for (int j = 0; j < M_CH && base + j < nt; ++j) {
@@ -423,7 +445,7 @@ __global__ __launch_bounds__(256) void vq_mfma_kernel(const float* __restrict__ 
                         for (int t = 0; t < RT; ++t) scan16<true>(best[t], accA[t], tile_first + base + j);
                     } else {
 #pragma unroll
-                        for (int t = 0; t < RT; ++t) scanmax(best[t], accA[t], tile_first + base + j);
+                        for (int t = 0; t < RT; ++t) scanmax_safe(best[t], accA[t], tile_first + base + j);
                     }
                 }
             }
@@ -657,7 +679,7 @@ int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, vo
     unsigned long long* partial = (unsigned long long*)workspace;
     const int ntiles = C >> 5;
     const int norm = (flags & 2) ? 0 : 1;
-    int rt = N >= 8192 ? 2 : 1;
+    int rt = N >= 32768 ? 4 : (N >= 8192 ? 2 : 1);     // measured: 130 / 126 / 118 TF at N=32768 for RT = 4 / 2 / 1
     {   // tuning override (bench/debug): SELFTOK_VQ_RT=1|2|4
         static int env_rt = -1;
         if (env_rt < 0) { const char* e = getenv("SELFTOK_VQ_RT"); env_rt = e ? atoi(e) : 0; }
