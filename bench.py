@@ -171,6 +171,7 @@ def main():
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
 
     if rank != 0:
+        D.shutdown()
         return
     n_vq = B * K
     vq_ms = float(np.mean([a.elapsed_time(b) for a, b in vq_events])) if vq_events else float("nan")
@@ -213,6 +214,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, K)
     print(json.dumps(line), flush=True)
+    D.shutdown()
 
 
 if __name__ == "__main__":

@@ -79,3 +79,8 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
