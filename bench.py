@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--decoder", default="diffusion", choices=["diffusion", "renderer"])
     ap.add_argument("--decode-steps", type=int, default=None, help="debug only: truncate the 50-step loop (marks the line invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm", default=None, choices=["fp32", "f16x2"], help="arithmetic of the MMDiT block Linears")
     return ap.parse_args()
 
 
@@ -128,7 +129,7 @@ def main():
     cfg = default_config(K, renderer=renderer)
     sd = W.synthetic_state_dict(W.expected_shapes(K, renderer=renderer), device=dev)
     vsd = W.synthetic_vae_state_dict(device=dev)
-    pipe = SelftokPipeline(cfg, None, None, device=dev, state_dict=sd, vae_state_dict=vsd, verbose=False)
+    pipe = SelftokPipeline(cfg, None, None, device=dev, state_dict=sd, vae_state_dict=vsd, verbose=False, gemm=args.gemm)
 
     images = synth.synthetic_images(B, device=dev, first_index=rank * B)          # resident in HBM
     noise = synth.synthetic_noise(B, device=dev, first_index=rank * B)

@@ -110,6 +110,21 @@ int selftok_rmsnorm_f32(const float* x, const float* w, float* out, long rows, i
 /* rotary embedding (mimogpt/utils/rotary_embedding_torch.py:37-53; no call site in the reference). */
 int selftok_rotary_f32(const float* t, const float* freqs, float* out, long rows, int seq, int dim, hipStream_t stream);
 
+/* ---- fp32-equivalent Linear on the f16 matrix cores ("f16x2 split") ---------------------------------
+ * out[M,N] = act(A[M,K] W[N,K]^T + bias[N]),  fp32 in / fp32 out; replaces the fp32 nn.Linear GEMMs of the MMDiT
+ * blocks (qkv / proj / fc1 / fc2: sd3/mmdit.py:291-297, 485-496; sd3/other_impls.py:65-90; F.linear in the reference).
+ * Every operand is split x = x0 + x1 2^-11 into two fp16 values and a.w ~= a0 w0 + 2^-11 (a0 w1 + a1 w0) runs on
+ * v_mfma_f32_32x32x16_f16 with separate fp32 accumulators for the high and the low terms: error against an fp64
+ * product is below that of an fp32 GEMM (tests/test_gemm_gpu.py).  The weight is split once into the kernel's tile
+ * order (N % 128 == 0, K % 32 == 0; selftok_linear_f16x2_packed_bytes = 4 N K).  `overflow` (device int, may be NULL)
+ * gets bit 0 OR-ed when an activation, bit 1 when a weight, is not below 65504 in magnitude (fp16 range): the result
+ * is then invalid and the caller must use its fp32 GEMM.  A row stride lda (floats, multiple of 4), out row stride ldo. */
+#define SELFTOK_LINEAR_GELU 1   /* act = GELU(tanh), the Mlp activation (sd3/other_impls.py:82-90) */
+size_t selftok_linear_f16x2_packed_bytes(int N, int K);
+int selftok_linear_f16x2_pack_weight(const float* W, void* packed, int N, int K, int* overflow, hipStream_t stream);
+int selftok_linear_f16x2_f32(const float* A, long lda, const void* packed, const float* bias, float* out, long ldo,
+                             int M, int N, int K, int flags, int* overflow, hipStream_t stream);
+
 /* ---- two-segment attention with implicit prefix-visibility mask ------------------------------
  * Replaces attention(q,k,v,heads,mask)=SDPA with a materialised bool mask (sd3/other_impls.py:37-45,
  * called from block_mixing sd3/mmdit.py:529-530; mask built at sd3/mmdit.py:1041-1094) and the SDPA calls of

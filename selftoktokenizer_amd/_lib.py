@@ -35,6 +35,9 @@ SIGNATURES = {
     "selftok_rmsnorm_f32": (_i, [_vp, _vp, _vp, _l, _i, _f, _vp]),
     "selftok_rotary_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "selftok_attn_f32": (_i, [_vp, _vp]),
+    "selftok_linear_f16x2_packed_bytes": (_sz, [_i, _i]),
+    "selftok_linear_f16x2_pack_weight": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "selftok_linear_f16x2_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp, _vp]),
     "selftok_groupnorm_silu_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "selftok_latent_process_in": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     "selftok_latent_process_out": (_i, [_vp, _vp, _l, _f, _f, _vp]),

@@ -32,8 +32,13 @@ from .weights import DIT_DEPTH, DIT_HEADS, DIT_HIDDEN, POS_MAX_DIT
 
 
 class MMDiTGPU:
-    def __init__(self, sd: Dict[str, torch.Tensor], device, K: int, renderer: bool = False):
+    GEMM_MODES = ("fp32", "f16x2")
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device, K: int, renderer: bool = False, gemm: str = "fp32"):
         self.device, self.K, self.renderer = device, K, renderer
+        self.gemm = "fp32"
+        self._packed = {}                                                   # linear name -> f16x2-split weight image
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)    # sticky fp16-range flag of the split GEMMs
         self.w = {k: v.to(device=device, dtype=torch.float32).contiguous() for k, v in sd.items() if k.startswith("model.")}
         H = DIT_HIDDEN
         if not renderer:
@@ -50,9 +55,40 @@ class MMDiTGPU:
             h = self.lin(p + ".t_embedder.mlp.2", ops.silu(h))
             self.ctx_tables.append(self.lin(p + ".adaLN_modulation.1", ops.silu(h)).contiguous())
         self.context_pos_embed = self.w["model.context_pos_embed"][0].contiguous()                    # [K,H]
+        if gemm != "fp32":
+            self.set_gemm(gemm)
 
-    def lin(self, name, x):
-        return F.linear(x, self.w[name + ".weight"], self.w[name + ".bias"])
+    # ---- GEMM arithmetic of the block Linears ---------------------------------------------------
+    def set_gemm(self, mode: str) -> str:
+        """'fp32': hipBLASLt fp32 GEMMs (PyTorch-ROCm).  'f16x2': the qkv / proj / fc1 / fc2 Linears of the 24 joint blocks
+        (99.6 % of the decode FLOPs) run on ops.linear_f16x2 -- fp32-equivalent split arithmetic on the f16 matrix cores,
+        more accurate than the fp32 library GEMM (tests/test_gemm_gpu.py).  Weights are split once, here.  If a weight is
+        outside the fp16 range the mode stays 'fp32'.  Returns the mode in force."""
+        if mode not in self.GEMM_MODES:
+            raise ValueError(f"gemm mode {mode!r}: expected one of {self.GEMM_MODES}")
+        if mode == "f16x2" and not self._packed:
+            flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+            packed = {}
+            for name, w in self.w.items():
+                if (name.endswith(".weight") and ".joint_blocks." in name and w.dim() == 2
+                        and any(t in name for t in (".attn.qkv.", ".attn.proj.", ".mlp.fc1.", ".mlp.fc2."))
+                        and ops.linear_f16x2_supported(w.shape[0], w.shape[1])):
+                    packed[name[:-len(".weight")]] = ops.linear_f16x2_pack(w, flag)
+            if int(flag.item()) != 0:
+                print("[selftok] f16x2 GEMM mode refused: a weight is outside the fp16 range; staying on fp32 GEMMs")
+                mode = "fp32"
+            else:
+                self._packed = packed
+        self.gemm = mode
+        return mode
+
+    def lin(self, name, x, gelu: bool = False):
+        w, b = self.w[name + ".weight"], self.w[name + ".bias"]
+        if self.gemm == "f16x2" and name in self._packed:
+            return ops.linear_f16x2(x, self._packed[name], b, w.shape[0], gelu=gelu, overflow=self.overflow)
+        if gelu:
+            return ops.linear_gelu(x, w, b)
+        return F.linear(x, w, b)
 
     def _pos_bias(self, h: int, w: int) -> torch.Tensor:
         key = (h, w)
@@ -126,7 +162,7 @@ class MMDiTGPU:
                 t = tab[i]
                 ctx, cn2 = ops.residual_ln_mod(ctx, y=self.lin(pc + ".attn.proj", oc), gate=t[:, 2 * H:3 * H],
                                                shift=t[:, 3 * H:4 * H], scale=t[:, 4 * H:5 * H])
-                h = ops.linear_gelu(cn2, self.w[pc + ".mlp.fc1.weight"], self.w[pc + ".mlp.fc1.bias"])
+                h = self.lin(pc + ".mlp.fc1", cn2, gelu=True)
                 m = self.lin(pc + ".mlp.fc2", h)
                 if i + 1 < DIT_DEPTH - 1:
                     tn = tab[i + 1]
@@ -138,7 +174,7 @@ class MMDiTGPU:
             mx = mods_x[i]
             x, xn2 = ops.residual_ln_mod(x, y=self.lin(px + ".attn.proj", ox), gate=mx[:, 2 * H:3 * H],
                                          shift=mx[:, 3 * H:4 * H], scale=mx[:, 4 * H:5 * H], per_sample=True)
-            h = ops.linear_gelu(xn2, self.w[px + ".mlp.fc1.weight"], self.w[px + ".mlp.fc1.bias"])
+            h = self.lin(px + ".mlp.fc1", xn2, gelu=True)
             m = self.lin(px + ".mlp.fc2", h)
             if not last:
                 mn = mods_x[i + 1]

@@ -122,6 +122,47 @@ def linear_gelu(x, weight, bias):
     return out.reshape(*shp[:-1], weight.shape[0])
 
 
+# ----------------------------------------------------------------------------------------------
+# fp32-equivalent Linear on the f16 matrix cores (csrc/gemm_split.hip)
+# ----------------------------------------------------------------------------------------------
+LINEAR_GELU = 1
+
+
+def linear_f16x2_supported(N: int, K: int) -> bool:
+    return N % 128 == 0 and K % 32 == 0
+
+
+def linear_f16x2_pack(weight: torch.Tensor, overflow: torch.Tensor = None) -> torch.Tensor:
+    """nn.Linear weight [N,K] fp32 -> the kernel's split/tiled fp16 image (4*N*K bytes).  One-time, at load.
+    `overflow` (int32 [1], device): bit 1 is set if a weight is outside the fp16 range."""
+    _need_cuda(weight)
+    w = weight.contiguous().float()
+    N, K = w.shape
+    lib = _lib.load()
+    nbytes = lib.selftok_linear_f16x2_packed_bytes(N, K)
+    if nbytes == 0:
+        raise _lib.SelftokHipError(f"linear_f16x2: weight {N}x{K} needs N % 128 == 0 and K % 32 == 0")
+    packed = torch.empty(nbytes // 2, dtype=torch.float16, device=w.device)
+    _lib.check(lib.selftok_linear_f16x2_pack_weight(_p(w), _p(packed), N, K, _p(overflow), _stream()), "selftok_linear_f16x2_pack_weight")
+    return packed
+
+
+def linear_f16x2(x: torch.Tensor, packed: torch.Tensor, bias, N: int, gelu: bool = False, overflow: torch.Tensor = None) -> torch.Tensor:
+    """act(x @ W.T + bias) with W given as linear_f16x2_pack(W).  x [..., K] fp32 (rows may be strided), out [..., N] fp32."""
+    _need_cuda(x, packed)
+    K = x.shape[-1]
+    assert x.dtype == torch.float32 and packed.numel() * 2 == 4 * N * K, "packed weight does not match (N, K)"
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1 or (x2.shape[0] > 1 and (x2.stride(0) % 4 or x2.stride(0) < K)):
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    lda = x2.stride(0) if M > 1 else K
+    _lib.check(_lib.load().selftok_linear_f16x2_f32(_p(x2), lda, _p(packed), _p(bias), _p(out), N, M, N, K,
+                                                    LINEAR_GELU if gelu else 0, _p(overflow), _stream()), "selftok_linear_f16x2_f32")
+    return out.reshape(*x.shape[:-1], N)
+
+
 def silu(x):
     _need_cuda(x)
     x = x.contiguous()

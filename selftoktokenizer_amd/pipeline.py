@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -22,6 +24,7 @@ from .schedule import DiTiCont, FlowSchedule
 from .vae import AutoencoderKLGPU
 
 SD3_SCALE, SD3_SHIFT = 1.5305, 0.0609     # SD3LatentFormat (sd3/sd3_impls.py:136-138)
+DEFAULT_GEMM = "fp32"                     # see MMDiTGPU.set_gemm
 
 
 class NormalizeToTensor(object):
@@ -106,9 +109,11 @@ class _Flow(FlowSchedule):
 class SelftokPipeline():
     def __init__(self, cfg, ckpt_path, sd3_path, datasize=256, start=1.0, cfg_scale=1, model_type='sd3',
                  dtype=torch.bfloat16, ema_decoder=False, device=None, state_dict: Optional[Dict[str, torch.Tensor]] = None,
-                 vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, verbose: bool = True):
+                 vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, verbose: bool = True, gemm: Optional[str] = None):
         """cfg: parse_args_from_yaml(...) ; ckpt_path: tokenizer .pth ; sd3_path: diffusers SD3 folder (…/vae/…).
-        `state_dict` / `vae_state_dict` (extensions) bypass the files, e.g. with weights.synthetic_state_dict()."""
+        `state_dict` / `vae_state_dict` (extensions) bypass the files, e.g. with weights.synthetic_state_dict().
+        `gemm` (extension): arithmetic of the MMDiT block Linears, 'fp32' (hipBLASLt fp32) or 'f16x2' (fp32-equivalent
+        split GEMM on the f16 matrix cores, csrc/gemm_split.hip); default from $SELFTOK_GEMM, else DEFAULT_GEMM."""
         _lib.load()                                                           # fail loudly if the HIP library is missing
         if device is None:
             device = "cuda"
@@ -139,6 +144,7 @@ class SelftokPipeline():
             dit_sd = {("model." + k if not k.startswith("model.") else k): v for k, v in sd["ema_state_dict"].items()}
         encoder = QformerEncoderGPU(sd, self.device, K)
         dit = MMDiTGPU(dit_sd, self.device, K, renderer=renderer)
+        dit.set_gemm(gemm or os.environ.get("SELFTOK_GEMM") or DEFAULT_GEMM)
         self.model = _Tokenizer(encoder, dit, self.diti)
 
         self.count = 0
@@ -184,6 +190,26 @@ class SelftokPipeline():
         recons = self.vae.decode(z)[0].contiguous()
         return norm_ip(recons, -1, 1)
 
+    def set_gemm(self, mode: str) -> str:
+        """switch the MMDiT block Linears between 'fp32' and 'f16x2' (see MMDiTGPU.set_gemm); returns the mode in force"""
+        return self.model.model.set_gemm(mode)
+
+    @torch.no_grad()
+    def _checked(self, run):
+        """run() -> latent.  In 'f16x2' GEMM mode an activation outside the fp16 range (|a| >= 65504) invalidates the
+        result (sticky device flag, one host read per call): redo the call on the fp32 library GEMMs."""
+        dit = self.model.model
+        out = run()
+        if dit.gemm == "f16x2" and int(dit.overflow.item()) != 0:
+            print("[selftok] f16x2 GEMM: activation outside the fp16 range -> recomputing this call with fp32 GEMMs")
+            dit.overflow.zero_()
+            dit.gemm = "fp32"
+            try:
+                out = run()
+            finally:
+                dit.gemm = "f16x2"
+        return out
+
     @torch.no_grad()
     def _sample(self, xt, ehs, max_steps, uncond_scale, use_graph):
         """the 50-step loop, optionally replayed from a hipGraph captured once per (batch, latent size) -- the loop is
@@ -191,7 +217,7 @@ class SelftokPipeline():
         if not use_graph:
             return self.flow.p_sample_loop(self.model.model, xt, ehs, self.k_table, context_see_xt=True,
                                            uncond_scale=uncond_scale, max_steps=max_steps)
-        key = (tuple(xt.shape), tuple(ehs.shape), max_steps, float(uncond_scale))
+        key = (tuple(xt.shape), tuple(ehs.shape), max_steps, float(uncond_scale), self.model.model.gemm)
         if key not in self._graphs:
             s_noise = torch.empty(xt.shape, dtype=torch.float32, device=self.device)
             s_ehs = torch.empty_like(ehs)
@@ -225,7 +251,7 @@ class SelftokPipeline():
         ehs = outs_q if k0 >= self.K - 1 else outs_q * (torch.arange(self.K, device=self.device) <= k0)[None, :, None]
         latent_dim = self.datasize // 8
         xt = noise if noise is not None else torch.randn(B, 16, latent_dim, latent_dim)
-        pred_x0 = self._sample(xt, ehs, max_steps, uncond_scale, use_graph)
+        pred_x0 = self._checked(lambda: self._sample(xt, ehs, max_steps, uncond_scale, use_graph))
         recons = self._to_pixels(pred_x0)
         self._say('End decoding.')
         return (recons, pred_x0) if return_latent else recons
@@ -235,7 +261,7 @@ class SelftokPipeline():
         """one MMDiT_Renderer pass instead of the 50-step loop (reference :296-322)"""
         self._say("Begin decoding with Renderer.")
         outs_q = self._codes(idx)
-        pred_x0, _ = self.model.model(y=None, encoder_hidden_states=outs_q)
+        pred_x0 = self._checked(lambda: self.model.model(y=None, encoder_hidden_states=outs_q)[0])
         recons = self._to_pixels(pred_x0)
         self._say('End decoding with Renderer.')
         return (recons, pred_x0) if return_latent else recons

@@ -1,0 +1,92 @@
+"""-m gpu: the f16x2-split Linear kernel (csrc/gemm_split.hip, through the C ABI) against an fp64 product.
+
+Gate: the split GEMM may replace the fp32 library GEMM on the parity path only if it is at least
+as accurate -- its error against the exact (fp64) product must not exceed the fp32 GEMM's own error on the same data.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from selftoktokenizer_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(M, N, K, seed, act_scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    a = torch.randn(M, K, device="cuda", generator=g) * (1.0 + 3.0 * torch.rand(1, K, device="cuda", generator=g)) * act_scale
+    w = (torch.rand(N, K, device="cuda", generator=g) * 2 - 1) * (3.0 / K) ** 0.5
+    b = torch.randn(N, device="cuda", generator=g) * 0.1
+    return a, w, b
+
+
+def _errs(out, ref):
+    e = out.double() - ref
+    return float(e.abs().max()), float(e.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 32), (1000, 1536, 1536), (2048 + 37, 4608, 1536), (777, 1536, 6144), (3, 256, 64)])
+def test_split_linear_not_worse_than_fp32_gemm(M, N, K):
+    a, w, b = _data(M, N, K, seed=M + N + K)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    packed = ops.linear_f16x2_pack(w, flag)
+    out = ops.linear_f16x2(a, packed, b, N, overflow=flag)
+    ref = a.double() @ w.double().t() + b.double()
+    lib = F.linear(a, w, b)
+    mx_s, rms_s = _errs(out, ref)
+    mx_l, rms_l = _errs(lib, ref)
+    print(f"M={M} N={N} K={K}: split max {mx_s:.3e} rms {rms_s:.3e} | fp32 library max {mx_l:.3e} rms {rms_l:.3e}")
+    assert int(flag.item()) == 0
+    assert rms_s <= rms_l * 1.05 + 1e-9 and mx_s <= mx_l * 2.0 + 1e-7
+    # transpose-detecting: asymmetric data, exact row/col placement
+    assert torch.allclose(out, lib, rtol=0, atol=8 * mx_l + 1e-6)
+
+
+def test_split_linear_gelu_strided_rows_no_bias():
+    M, N, K = 600, 6144, 1536
+    a, w, b = _data(M, N, K, seed=5)
+    big = torch.zeros(M, 3 * K, device="cuda")
+    big[:, K:2 * K] = a
+    view = big[:, K:2 * K]                                 # row stride 3K: a slice of a fused buffer
+    packed = ops.linear_f16x2_pack(w)
+    out = ops.linear_f16x2(view, packed, b, N, gelu=True)
+    ref = F.gelu((a.double() @ w.double().t() + b.double()), approximate="tanh")
+    lib = F.gelu(F.linear(a, w, b), approximate="tanh")
+    assert _errs(out, ref)[1] <= _errs(lib, ref)[1] * 1.05
+    out_nb = ops.linear_f16x2(a.reshape(2, 300, K), packed, None, N)
+    assert out_nb.shape == (2, 300, N)
+    assert _errs(out_nb.reshape(M, N), a.double() @ w.double().t())[1] <= _errs(F.linear(a, w), a.double() @ w.double().t())[1] * 1.05
+
+
+def test_split_linear_tiny_and_large_magnitudes():
+    """values far below the fp16 normal range ride in the scaled low part; values beyond 65504 raise the flag"""
+    M, N, K = 512, 256, 1536
+    for scale in (1e-3, 1e-6, 1e2):
+        a, w, b = _data(M, N, K, seed=9, act_scale=scale)
+        packed = ops.linear_f16x2_pack(w)
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        out = ops.linear_f16x2(a, packed, None, N, overflow=flag)
+        ref = a.double() @ w.double().t()
+        lib = F.linear(a, w)
+        rs, rl = _errs(out, ref)[1], _errs(lib, ref)[1]
+        print(f"scale {scale:g}: split rms {rs:.3e} fp32 library rms {rl:.3e}")
+        assert int(flag.item()) == 0 and rs <= rl * 1.05 + 1e-12 * scale
+    a, w, b = _data(M, N, K, seed=9)
+    a[17, 300] = 7.0e4
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.linear_f16x2(a, ops.linear_f16x2_pack(w), None, N, overflow=flag)
+    assert int(flag.item()) & 1
+    w[3, 3] = 1.0e5
+    flag.zero_()
+    ops.linear_f16x2_pack(w, flag)
+    assert int(flag.item()) & 2
+
+
+def test_split_linear_bad_arguments():
+    from selftoktokenizer_amd._lib import SelftokHipError
+    with pytest.raises(SelftokHipError):
+        ops.linear_f16x2_pack(torch.zeros(100, 64, device="cuda"))          # N % 128
+    with pytest.raises(SelftokHipError):
+        ops.linear_f16x2_pack(torch.zeros(128, 48, device="cuda"))          # K % 32
+    packed = ops.linear_f16x2_pack(torch.zeros(128, 64, device="cuda"))
+    assert ops.linear_f16x2(torch.zeros(0, 64, device="cuda"), packed, None, 128).shape == (0, 128)

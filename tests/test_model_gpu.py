@@ -34,10 +34,14 @@ def encoder(sd):
     return QformerEncoderGPU(sd, torch.device("cuda"), 512)
 
 
-@pytest.fixture(scope="module")
-def dit(sd):
+@pytest.fixture(scope="module", params=["fp32", "f16x2"])
+def dit(sd, request):
+    """both GEMM arithmetics of the block Linears: hipBLASLt fp32 and the f16x2 split kernel (csrc/gemm_split.hip)"""
     from selftoktokenizer_amd.mmdit import MMDiTGPU
-    return MMDiTGPU(sd, torch.device("cuda"), 512)
+    d = MMDiTGPU(sd, torch.device("cuda"), 512, gemm=request.param)
+    assert d.gemm == request.param
+    yield d
+    assert int(d.overflow.item()) == 0
 
 
 def test_encoder_features_and_ids(encoder):

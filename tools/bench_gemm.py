@@ -1,17 +1,44 @@
-"""hipBLASLt fp32 GEMM rates for the MMDiT shapes: F.linear (weight [N,K]) vs mm with a pre-transposed [K,N] weight."""
-import sys, os, json
+"""GPU micro-benchmark: f16x2-split Linear (csrc/gemm_split.hip) vs the fp32 library GEMM at the MMDiT shapes
+(B = 64: context rows 64 x 358 (mean live tokens), image rows 64 x 256)."""
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch, torch.nn.functional as F
-def t(f, n=8):
-    for _ in range(3): f()
-    torch.cuda.synchronize(); s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(n): f()
-    e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / n
-for M in (64 * 256, 64 * 358, 64 * 512, 768):
-    for name, N, K in (("qkv", 4608, 1536), ("proj", 1536, 1536), ("fc1", 6144, 1536), ("fc2", 1536, 6144)):
-        x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.02; b = torch.randn(N, device="cuda")
-        wt = w.t().contiguous()
-        fl = 2.0 * M * N * K
-        a = t(lambda: F.linear(x, w, b)); c = t(lambda: torch.addmm(b, x, wt))
-        print(json.dumps({"M": M, "op": name, "N": N, "K": K, "linear_TF": round(fl / a / 1e9, 1), "mm_pretransposed_TF": round(fl / c / 1e9, 1)}), flush=True)
+from selftoktokenizer_amd import ops  # noqa: E402
+
+
+def bench(fn, n=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n
+
+
+def main():
+    torch.manual_seed(0)
+    shapes = [(64 * 358, 4608, 1536), (64 * 358, 1536, 1536), (64 * 358, 6144, 1536), (64 * 358, 1536, 6144),
+              (64 * 256, 4608, 1536), (64 * 256, 6144, 1536), (64 * 256, 1536, 6144), (64 * 512, 4608, 1536)]
+    if len(sys.argv) > 1:
+        shapes = shapes[: int(sys.argv[1])]
+    for M, N, K in shapes:
+        a = torch.randn(M, K, device="cuda")
+        w = torch.randn(N, K, device="cuda") * 0.02
+        b = torch.randn(N, device="cuda")
+        packed = ops.linear_f16x2_pack(w)
+        flop = 2.0 * M * N * K
+        t_lib = bench(lambda: F.linear(a, w, b))
+        t_s = bench(lambda: ops.linear_f16x2(a, packed, b, N))
+        print(f"M={M} N={N} K={K}: fp32 library {t_lib * 1e3:.3f} ms ({flop / t_lib / 1e12:.0f} TF) | f16x2 split {t_s * 1e3:.3f} ms "
+              f"({flop / t_s / 1e12:.0f} TF-equiv, {3 * flop / t_s / 1e12:.0f} TF f16 MFMA = {3 * flop / t_s / 2.5e15:.2f} of peak) | x{t_lib / t_s:.2f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
