@@ -5,38 +5,46 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of synthetic input per GPU: `encoding` (SD3-VAE encode ->
-Q-Former encoder -> VQ nearest-code) then `decoding` (50-step rectified-flow MMDiT loop -> SD3-VAE decode) of
-B = 64 images of 256x256 with the 512-token tokenizer (BASELINE.json configs[1]).  Inputs (images, decode noise,
-weights) are resident in HBM before the timed region.  Weights are hash-generated (no checkpoints offline) with
-the architecture of the published 512-token model; arithmetic is the parity path: fp32 tokenizer/DiT, bf16 VAE.
+One "step" = one pass of the hot path over one batch of synthetic input per GPU through the PUBLIC drop-in API:
+`tokens = pipe.encoding(images)` (SD3-VAE encode -> Q-Former encoder -> VQ nearest-code), the id all-gather, then
+`pipe.decoding(tokens.cpu().numpy())` (50-step rectified-flow MMDiT loop -> SD3-VAE decode) of B = 64 images of
+256x256 with the 512-token tokenizer (BASELINE.json configs[1]).  Images are resident in HBM before the timed
+region; the decode noise is drawn inside `decoding` from the global CPU generator exactly as the reference does
+(SelftokPipeline.py:264).  Weights are hash-generated (no checkpoints offline) with the architecture of the
+published 512-token model; arithmetic is the parity path: fp32 tokenizer/DiT, bf16 VAE.
 
-N > 1: batch sharding (weak scaling, 64 images per GPU), one RCCL all-gather of the token ids per step.
+N > 1: `python bench.py --gpus N` re-executes itself under torch.distributed.run (one rank per GPU); the driver's
+own torchrun launch is used as is.  Batch sharding (weak scaling, 64 images per GPU), one RCCL all-gather of the
+token ids per step (event-timed, reported), every rank decodes its slice of the GATHERED id matrix.
 
 Extra objects on the JSON line:
-  roofline     : the VQ nearest-code kernel (vq_mfma_kernel), timed live with HIP events on its launch stream.
-  cpu_baseline : oracle/ (our CPU restatement, verified equal to the reference) on this box's host cores, rank 0,
-                 N=1 only, on a bounded sample (see "sample").
+  roofline          : the VQ nearest-code kernel (vq_mfma_kernel), timed live with HIP events on its launch stream.
+  roofline_kernels  : the other kernels a step is made of (attention, LN+modulate, fp32 GEMM, f16x2-split GEMM), event-timed
+                      stand-alone at the shapes of the timed step.
+  token_match       : token-id exact match of the timed batch against the CPU oracle (kernel boundary + end to end).
+  gemm_modes        : the same step with the MMDiT Linears on the other GEMM arithmetic (fp32 library <-> f16x2 split).
+  cpu_baseline      : oracle/ (our CPU restatement, verified equal to the reference) on this box's host cores, rank 0,
+                      N=1 only, on a bounded sample (see "sample").
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: bf16/f16 MFMA, dense
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec peak
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -45,9 +53,37 @@ def parse():
     ap.add_argument("--tokens", type=int, default=512, choices=[512, 1024])
     ap.add_argument("--decoder", default="diffusion", choices=["diffusion", "renderer"])
     ap.add_argument("--decode-steps", type=int, default=None, help="debug only: truncate the 50-step loop (marks the line invalid)")
+    ap.add_argument("--gemm", default=None, choices=["fp32", "f16x2"], help="arithmetic of the MMDiT block Linears of the headline number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm", default=None, choices=["fp32", "f16x2"], help="arithmetic of the MMDiT block Linears")
-    return ap.parse_args()
+    ap.add_argument("--no-token-check", action="store_true")
+    ap.add_argument("--no-kernel-roofs", action="store_true")
+    ap.add_argument("--no-other-gemm", action="store_true", help="skip the second measurement on the other GEMM arithmetic")
+    ap.add_argument("--selftest-dist", action="store_true",
+                    help="no GPU work: initialise the ranks, all-gather synthetic ids, print the JSON skeleton (CPU test of the N>1 entry)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N > 1 entry: `python bench.py --gpus N` spawns N ranks itself
+# ---------------------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(n: int, argv, port: int):
+    """the torchrun command line `python bench.py --gpus n ...` re-executes itself under (one process per GPU)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_respawn(args, argv) -> None:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this host driver
+        rc = subprocess.call(launch_command(args.gpus, argv, free_port()), env=env)
+        sys.exit(rc)
 
 
 def host_cores() -> int:
@@ -64,10 +100,12 @@ def host_cores() -> int:
 
 
 def cpu_baseline(sd_gpu, vsd_gpu, cfg, K):
-    """oracle/ on the host cores: B=1, full encode (VAE-enc + Q-Former + VQ), 2 of the 50 decode steps (every step has
-    identical FLOPs up to the shrinking context, extrapolated x25), full VAE decode."""
-    from oracle import model as OM, schedule as OS
-    from selftoktokenizer_amd import synth, weights as W
+    """oracle/ on the host cores.  Headline: B=1, full encode (VAE-enc + Q-Former + VQ), 2 of the 50 decode steps (every
+    step has identical FLOPs up to the shrinking context, extrapolated x25), full VAE decode.  Breadth:
+    encode at B=8, the VQ nearest-code lookup alone at N = 512 and 32768 rows."""
+    import torch
+    from oracle import clib, model as OM, schedule as OS
+    from selftoktokenizer_amd import synth
     torch.set_num_threads(host_cores())
     sd = {k: v.detach().cpu() for k, v in sd_gpu.items()}
     vsd = {k: v.detach().cpu() for k, v in vsd_gpu.items()}
@@ -86,11 +124,30 @@ def cpu_baseline(sd_gpu, vsd_gpu, cfg, K):
         t0 = time.perf_counter()
         OM.norm_ip(OM.vae_decode(vsd, OM.process_out(lat).to(torch.bfloat16)))
         t_vd = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        OM.pipeline_encode(sd, vsd, synth.synthetic_images(8), enc_tables)
+        t_enc8 = time.perf_counter() - t0
+        cb = sd["encoder.quantizer._codebook.embed"][0].numpy()
+        vq = {}
+        for n in (512, 32768):
+            z = synth.synthetic_vq_rows(n, seed=0xBE0C).numpy()
+            t0 = time.perf_counter()
+            clib.vq_encode(z, cb)
+            vq[f"N{n}_rows_per_s"] = round(n / (time.perf_counter() - t0), 1)
     total = t_enc + 25.0 * t_2 + t_vd
     return {"value": round(1.0 / total, 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"B=1 256x256 K={K}: full encode {t_enc:.2f}s + 2 of 50 decode steps {t_2:.2f}s (x25 extrapolated) "
                       f"+ VAE decode {t_vd:.2f}s on {torch.get_num_threads()} host threads; oracle/ = lean restatement "
-                      "(no redundant encoder passes / table recomputes of the reference)"}
+                      "(no redundant encoder passes / table recomputes of the reference)",
+            "encode_images_per_s": {"B1": round(1.0 / t_enc, 3), "B8": round(8.0 / t_enc8, 3)},
+            "vq_lookup_scalar_C_1_thread": vq}
+
+
+REFERENCE_SURVEY_BASELINE = {
+    "value": round(1.0 / 166.5, 5), "unit": "images/s", "cores": 8, "kind": "reference",
+    "sample": "the reference itself (mimogpt.infer.SelftokPipeline, fp32 DiT/bf16 VAE, incl. its 50 redundant encoder passes and per-call "
+              "table recomputes) timed ONCE in the build container (8 vCPU) for SURVEY.md section 6 / BASELINE.md: encoding B=1 0.47 s, "
+              "one MMDiT.forward 2.82 s, VAE decode 0.35 s -> 166.5 s per image.  It cannot travel to the GPU box; not re-measured here."}
 
 
 def fp32_flops_per_image(K: int, k_table, renderer: bool) -> float:
@@ -110,18 +167,142 @@ def fp32_flops_per_image(K: int, k_table, renderer: bool) -> float:
     return float(enc + dec)
 
 
-def main():
-    args = parse()
-    from selftoktokenizer_amd import dist as D, ops, synth, weights as W
-    from selftoktokenizer_amd.config import default_config
-    from selftoktokenizer_amd.pipeline import SelftokPipeline
+def event_time_ms(fn, n=10, warm=2):
+    import torch
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def kernel_roofs(pipe, B, K, k_table):
+    """stand-alone, event-timed launches of the kernels a decode step is made of, at the shapes of the timed step
+    (context rows = the mean live length over the 50 steps)."""
+    import torch
+    import torch.nn.functional as F
+    from selftoktokenizer_amd import ops
+    dev = pipe.device
+    H, NH = 1536, 24
+    n = int(round(float(sum(int(k) + 1 for k in k_table)) / len(k_table)))
+    out = []
+    # attention: 23 of 24 blocks have both streams as queries
+    cq = torch.randn(B, n, 3 * H, device=dev)
+    xq = torch.randn(B, 256, 3 * H, device=dev)
+    oc, ox = torch.empty(B, n, H, device=dev), torch.empty(B, 256, H, device=dev)
+    seg0 = (cq[..., :H], cq[..., H:2 * H], cq[..., 2 * H:], oc)
+    seg1 = (xq[..., :H], xq[..., H:2 * H], xq[..., 2 * H:], ox)
+    ms = event_time_ms(lambda: ops.attention(seg0, seg1, NH, 64))
+    fl = 4.0 * B * NH * 64 * (n + 256) * (n + 256)
+    out.append({"kernel": "attn64_kernel", "bound": "mfma(fp32)", "shape": f"B={B} heads=24 S={n}+256", "avg_launch_ms": round(ms, 4),
+                "achieved": round(fl / ms / 1e9, 1), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "launches_per_step": 24 * 50})
+    # fused residual + LayerNorm + modulate on the context stream
+    x, y = torch.randn(B, n, H, device=dev), torch.randn(B, n, H, device=dev)
+    tab = torch.randn(n, 6 * H, device=dev)
+    ms = event_time_ms(lambda: ops.residual_ln_mod(x, y=y, gate=tab[:, 2 * H:3 * H], shift=tab[:, 3 * H:4 * H], scale=tab[:, 4 * H:5 * H]))
+    by = 4.0 * B * n * H * 4 + 3.0 * n * H * 4
+    out.append({"kernel": "residual_ln_mod_kernel", "bound": "hbm", "shape": f"[{B},{n},{H}] ctx stream", "avg_launch_ms": round(ms, 4),
+                "achieved": round(by / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
+                "launches_per_step": 4 * 24 * 50})
+    # the block Linears: qkv of the context stream as the representative shape
+    a = torch.randn(B * n, H, device=dev)
+    w = torch.randn(3 * H, H, device=dev) * 0.02
+    b = torch.randn(3 * H, device=dev)
+    fl = 2.0 * B * n * 3 * H * H
+    ms = event_time_ms(lambda: F.linear(a, w, b))
+    out.append({"kernel": "hipBLASLt fp32 GEMM (PyTorch-ROCm)", "bound": "mfma(fp32)", "shape": f"[{B * n},{H}]x[{H},{3 * H}]", "avg_launch_ms": round(ms, 4),
+                "achieved": round(fl / ms / 1e9, 1), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)})
+    packed = ops.linear_f16x2_pack(w)
+    ms = event_time_ms(lambda: ops.linear_f16x2(a, packed, b, 3 * H))
+    out.append({"kernel": "linear_f16x2_kernel", "bound": "mfma(f16)", "shape": f"[{B * n},{H}]x[{H},{3 * H}]", "avg_launch_ms": round(ms, 4),
+                "achieved": round(3 * fl / ms / 1e9, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (f16 MFMA: 3 per fp32 product)",
+                "frac": round(3 * fl / ms / 1e9 / F16_MFMA_PEAK_TFLOPS, 4), "fp32_equivalent_TFLOPs": round(fl / ms / 1e9, 1)})
+    return out
+
+
+def token_match(pipe, images, tokens_gpu, sd_gpu, vsd_gpu, K, n_check=4):
+    """token-id exact match of the timed batch (rank 0's shard) against the CPU oracle:
+       kernel_boundary : the HIP VQ kernel vs the C oracle on the SAME features, every row of the batch (must be 1.0);
+       e2e_same_latents: GPU encoder+VQ vs oracle encoder+VQ from the same fp32 latents (fp32 GEMM library differences only);
+       e2e_vs_oracle   : from pixels, i.e. incl. the bf16 VAE (MIOpen vs CPU convolutions), first n_check images."""
+    import numpy as np
+    import torch
+    from oracle import clib, model as OM
+    torch.set_num_threads(host_cores())
+    enc = pipe.model.encoder
+    with torch.no_grad():
+        x0 = pipe.encode_latents(images)
+        z = enc.features(x0)
+        ids_gpu = tokens_gpu.cpu().numpy()
+        cb = enc.codebook.cpu().numpy()
+        ids_c, _ = clib.vq_encode(z.reshape(-1, 16).cpu().numpy(), cb)
+        kb = float((ids_c.reshape(ids_gpu.shape) == ids_gpu).mean())
+        sd = {k: v.detach().cpu() for k, v in sd_gpu.items() if k.startswith("encoder.")}
+        vsd = {k: v.detach().cpu() for k, v in vsd_gpu.items() if k.startswith("encoder.") or k.startswith("quant_conv")}
+        tables = OM.encoder_tables(sd, K)
+        z_o = OM.encoder_features(sd, x0[:n_check].cpu(), tables)
+        ids_same = OM.vq_ids(sd, z_o).numpy()
+        ids_e2e = OM.pipeline_encode(sd, vsd, images[:n_check].cpu(), tables).numpy()
+
+        def gaps(ids_o, z_feat):
+            mism = ids_o != ids_gpu[:n_check]
+            if not mism.any():
+                return []
+            xn = torch.nn.functional.normalize(z_feat.reshape(-1, 16), dim=-1)[torch.from_numpy(mism.reshape(-1))]
+            top2 = (xn @ torch.from_numpy(cb).T).topk(2, dim=-1).values
+            return [round(float(g), 8) for g in (top2[:, 0] - top2[:, 1])]
+    return {"kernel_boundary": kb, "kernel_boundary_rows": int(ids_gpu.size),
+            "e2e_same_latents": round(float((ids_same == ids_gpu[:n_check]).mean()), 6), "mismatch_gaps_same_latents": gaps(ids_same, z_o),
+            "e2e_vs_oracle": round(float((ids_e2e == ids_gpu[:n_check]).mean()), 6), "images_checked": n_check,
+            "note": "gap = oracle top-1 minus top-2 cosine score of each mismatching token (a flip needs an upstream difference larger than the gap); "
+                    "e2e_vs_oracle additionally carries the bf16 VAE encoder (MIOpen vs CPU convolutions; the oracle itself matches the reference 99.8 % there)"}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    maybe_respawn(args, argv)
+
+    import numpy as np
+    import torch
+    from selftoktokenizer_amd import dist as D, synth
 
     # SELFTOK_DIST_BACKEND=gloo + SELFTOK_ONE_GPU=1: dry run of the N>1 flow with every rank on GPU 0 (single-GPU boxes)
     one_gpu = os.environ.get("SELFTOK_ONE_GPU") == "1"
+    backend_req = os.environ.get("SELFTOK_DIST_BACKEND", "gloo" if args.selftest_dist else "nccl")
     if one_gpu:
         os.environ["LOCAL_RANK"] = "0"
-    rank, world, local = D.init_from_env(os.environ.get("SELFTOK_DIST_BACKEND", "nccl"))
+    rank, world, local = D.init_from_env(backend_req)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)"
+    backend = D.backend_name()
+    if world > 1 and not args.selftest_dist and os.environ.get("SELFTOK_DIST_BACKEND") is None:
+        assert backend == "nccl", f"N>1 must run over RCCL (torch.distributed backend 'nccl'), got {backend}"
+
+    if args.selftest_dist:
+        B, K = args.batch, args.tokens
+        ids = torch.from_numpy(synth.synthetic_token_ids(B, K, first_index=rank * B))
+        gathered, ag_ms = D.all_gather_ids_timed(ids)
+        ok = bool(torch.equal(gathered, torch.from_numpy(synth.synthetic_token_ids(world * B, K))))
+        ok_all = D.max_over_ranks(0.0 if ok else 1.0, "cpu") == 0.0
+        D.barrier()
+        if rank == 0:
+            print(json.dumps({"selftest": "dist", "n_gpus": world, "ranks": world, "backend": backend, "allgather_ok": ok_all,
+                              "allgather_bytes": int(world * B * K * 4), "allgather_ms": round(ag_ms, 4)}), flush=True)
+        D.shutdown()
+        return
+
+    from selftoktokenizer_amd import ops, weights as W
+    from selftoktokenizer_amd.config import default_config
+    from selftoktokenizer_amd.pipeline import SelftokPipeline
+
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if not one_gpu:
+        assert torch.cuda.device_count() > local, f"rank {rank}: local rank {local} but only {torch.cuda.device_count()} visible GPUs"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     K, B = args.tokens, args.batch
@@ -130,46 +311,54 @@ def main():
     sd = W.synthetic_state_dict(W.expected_shapes(K, renderer=renderer), device=dev)
     vsd = W.synthetic_vae_state_dict(device=dev)
     pipe = SelftokPipeline(cfg, None, None, device=dev, state_dict=sd, vae_state_dict=vsd, verbose=False, gemm=args.gemm)
+    gemm_main = pipe.model.model.gemm
 
     images = synth.synthetic_images(B, device=dev, first_index=rank * B)          # resident in HBM
-    noise = synth.synthetic_noise(B, device=dev, first_index=rank * B)
     torch.cuda.synchronize()
 
-    # ---- live timing of the dominant hand-written kernel of the north star (VQ argmax) ----
-    vq_events = []
-
-    def encode_tokens(x0):
-        z = pipe.model.encoder.features(x0)
-        ids, launch_main, launch_fin = ops.vq_encode_split_launch(z, pipe.model.encoder.codebook_packed)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()                      # torch's current stream == the stream the kernel is launched on
-        launch_main()
-        e1.record()
-        launch_fin()
-        vq_events.append((e0, e1))
-        return ids
+    ag = {"ms": [], "bytes": 0}
+    last = {}
 
     def step():
-        x0 = pipe.encode_latents(images)
-        ids = encode_tokens(x0)                                  # [B,K] int64 on device
-        ids_all = D.all_gather_ids(ids)                          # RCCL all-gather (no-op at N=1)
-        lo = rank * B
-        mine = ids_all[lo:lo + B]
+        tokens = pipe.encoding(images)                            # [B,K] int64 on device (public API)
+        ids_all, ms = D.all_gather_ids_timed(tokens)             # RCCL all-gather of the ids (no-op at N=1)
+        ag["ms"].append(ms)
+        ag["bytes"] = int(ids_all.shape[0] * ids_all.shape[1] * 4) if world > 1 else 0
+        mine = ids_all[rank * B:(rank + 1) * B].cpu().numpy()     # my slice of the GATHERED matrix, as the host array the API takes
+        last["tokens"] = tokens
         if renderer:
             return pipe.decoding_with_renderer(mine)
-        return pipe.decoding(mine, noise=noise, max_steps=args.decode_steps)
+        return pipe.decoding(mine, max_steps=args.decode_steps)   # noise: torch.randn on the CPU generator, as the reference
 
-    for _ in range(args.warmup):
-        step()
-    vq_events.clear()
-    torch.cuda.synchronize()
-    D.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    D.barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    def timed(nsteps, nwarm):
+        torch.manual_seed(1234 + rank)
+        for _ in range(nwarm):
+            step()
+        ops.VQ_EVENTS = []
+        ag["ms"].clear()
+        torch.cuda.synchronize()
+        D.barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize()
+        D.barrier()
+        el = D.max_over_ranks(time.perf_counter() - t0, dev)
+        ev, ops.VQ_EVENTS = ops.VQ_EVENTS, None
+        return el, ev
+
+    elapsed, vq_events = timed(args.steps, args.warmup)
+
+    # ---- the same step on the other GEMM arithmetic (all ranks take part: barriers inside) ----
+    other = None
+    if not args.no_other_gemm:
+        alt = "f16x2" if gemm_main == "fp32" else "fp32"
+        if pipe.set_gemm(alt) == alt:
+            n_alt = min(args.steps, 2)
+            el_alt, _ = timed(n_alt, 1)
+            other = {"gemm": alt, "value": round(world * B * n_alt / el_alt, 4), "unit": "images/s", "steps": n_alt, "warmup": 1,
+                     "ms_per_step": round(1000.0 * el_alt / n_alt, 2)}
+        pipe.set_gemm(gemm_main)
 
     if rank != 0:
         D.shutdown()
@@ -191,6 +380,9 @@ def main():
             "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
             "hbm_achieved_GBs": round(alg_bytes / (vq_ms * 1e-3) / 1e9, 2), "hbm_frac": round(alg_bytes / (vq_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
             "note": "N*C*D = %d x 32768 x 16 fp32 FMA chain is ~7.9 kFLOP/B: matrix-core bound, not HBM bound (SURVEY.md 8d)" % n_vq}
+    arith = {"fp32": "fp32 Q-Former/VQ/MMDiT (hipBLASLt fp32 GEMMs), bf16 SD3-VAE (reference dtypes)",
+             "f16x2": "fp32 Q-Former/VQ/MMDiT with the MMDiT block Linears on the f16x2-split kernel (fp32-equivalent: error vs fp64 below the "
+                      "fp32 library GEMM's, tests/test_gemm_gpu.py), bf16 SD3-VAE"}
     line = {
         "metric": "images/sec encode+decode, 256x256 %d-token" % K, "value": round(world * B * args.steps / elapsed, 4),
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,8 +391,11 @@ def main():
         "config": {"workload": "BASELINE configs[%d]: batch %d x 256x256 per GPU, %d-token encode + %s decode"
                                % (3 if renderer else (2 if K == 1024 else 1), B, K, "one-step renderer" if renderer else "50-step diffusion"),
                    "global_batch": world * B, "tokens": K, "decode_steps": 1 if renderer else (args.decode_steps or 50),
-                   "arithmetic": "fp32 Q-Former/VQ/MMDiT, bf16 SD3-VAE (reference dtypes)", "parallelism": "batch-shard x%d" % world,
+                   "gemm": gemm_main, "arithmetic": arith[gemm_main], "parallelism": "batch-shard x%d" % world,
+                   "api": "pipe.encoding(images) -> id all-gather -> pipe.decoding(ids.cpu().numpy()) (noise from the CPU generator, as the reference)",
                    "weights": "hash-generated, architecture of tokenizer_512_ckpt"},
+        "ranks": world, "backend": backend if world > 1 else None,
+        "allgather_bytes": ag["bytes"], "allgather_ms": round(float(np.mean(ag["ms"])), 4) if world > 1 and ag["ms"] else None,
         "roofline": roof,
     }
     fl_img = fp32_flops_per_image(K, pipe.k_table[: (args.decode_steps or 50)], renderer)
@@ -208,12 +403,21 @@ def main():
     line["job_roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "fp32_tflop_per_image": round(fl_img / 1e12, 2),
                             "achieved": round(job_tf, 1), "peak": FP32_MFMA_PEAK_TFLOPS * world,
                             "frac": round(job_tf / (FP32_MFMA_PEAK_TFLOPS * world), 4),
-                            "note": "fp32 matrix FLOPs actually executed (encoder + MMDiT, context truncated to live tokens) / wall time; "
-                                    "bf16 VAE work (0.89 TFLOP/img) excluded"}
+                            "note": "fp32-equivalent matrix FLOPs actually executed (encoder + MMDiT, context truncated to live tokens) / wall time, "
+                                    "against the fp32 matrix peak; bf16 VAE work (0.89 TFLOP/img) excluded.  In f16x2 GEMM mode the Linears run on the "
+                                    "16x faster f16 matrix cores (3 MFMAs per fp32 product), so this fraction may exceed 1"}
+    if other is not None:
+        line["gemm_modes"] = {gemm_main: {"value": line["value"], "ms_per_step": line["ms_per_step"]}, other["gemm"]: other,
+                              "note": "same step, MMDiT block Linears on the other arithmetic; 'value' of this line is the '%s' run" % gemm_main}
     if args.decode_steps is not None and not renderer:
         line["config"]["INVALID"] = "decode loop truncated with --decode-steps (debug run)"
+    if not args.no_kernel_roofs and not renderer:
+        line["roofline_kernels"] = kernel_roofs(pipe, B, K, pipe.k_table)
+    if not args.no_token_check:
+        line["token_match"] = token_match(pipe, images, last["tokens"], sd, vsd, K)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, K)
+        line["cpu_baseline_reference_survey"] = REFERENCE_SURVEY_BASELINE
     print(json.dumps(line), flush=True)
     D.shutdown()
 

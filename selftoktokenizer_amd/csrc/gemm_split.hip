@@ -50,6 +50,7 @@ constexpr int W_P = 4 * W_G;
 constexpr int W_BYTES = 2 * W_P;           // 16384
 constexpr int STAGE = A_BYTES + W_BYTES;   // 49408
 constexpr int GROUP_M = 8;
+constexpr int NSTAGE = 3;                   // 3 x 48.25 KiB = 144.75 KiB of the CU's 160 KiB
 
 __device__ __forceinline__ float gelu_tanh_f(float x)   // same formula as selftok_bias_gelu_f32 (elementwise.hip)
 {
@@ -98,7 +99,9 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_kernel(const float* __res
                                                               const float* __restrict__ bias, float* __restrict__ out, long ldo,
                                                               int M, int N, int K, int* __restrict__ overflow, int mblocks, int nblocks)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    // three-stage LDS ring: while tile t is multiplied, tile t+1 is complete (its first fragments are pre-read before
+    // the barrier, so the matrix pipe restarts immediately after it) and tile t+2 is being filled.
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -150,10 +153,10 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_kernel(const float* __res
         unsigned char* base = smem + stage * STAGE + a_dst;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f16x4 hi, lo;
-            split4(pre[i], hi, lo, mx);
-            *reinterpret_cast<f16x4*>(base + i * 64 * 16) = hi;
-            *reinterpret_cast<f16x4*>(base + i * 64 * 16 + A_P) = lo;
+            f16x4 h, l;
+            split4(pre[i], h, l, mx);
+            *reinterpret_cast<f16x4*>(base + i * 64 * 16) = h;
+            *reinterpret_cast<f16x4*>(base + i * 64 * 16 + A_P) = l;
         }
     };
 
@@ -168,44 +171,68 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_kernel(const float* __res
 
     const int a_frag = lh * A_G + (wm * 64 + l31) * 16;            // + rb*32*16 + s*2*A_G (+ A_P)
     const int w_frag = A_BYTES + lh * W_G + (wn * 64 + l31) * 16;  // + cb*32*16 + s*2*W_G (+ W_P)
+    f16x8 a0[2][2], w0[2][2], a1[2][2], w1[2][2];                  // fragment sets of the two 16-deep k-steps of a tile
+    auto read_frags = [&](int stage, int s, f16x8 (&af)[2][2], f16x8 (&wf)[2][2]) {
+        const unsigned char* st = smem + stage * STAGE;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                af[b][p] = *reinterpret_cast<const f16x8*>(st + a_frag + b * 32 * 16 + s * 2 * A_G + p * A_P);
+                wf[b][p] = *reinterpret_cast<const f16x8*>(st + w_frag + b * 32 * 16 + s * 2 * W_G + p * W_P);
+            }
+    };
+    auto mfma_row = [&](int i, f16x8 (&af)[2][2], f16x8 (&wf)[2][2]) {      // 6 MFMAs: row block i x both column blocks
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wf[j][0], hi[i][j], 0, 0, 0);
+            lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wf[j][1], lo[i][j], 0, 0, 0);
+            lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], wf[j][0], lo[i][j], 0, 0, 0);
+        }
+    };
 
+    // ---- prologue: tiles 0 and 1 staged, tile 2's rows in flight.  Tile indices past the end are clamped to the last
+    // tile everywhere: the tail iterations then stage data nobody reads, and the loop body has no conditional code
+    // (a conditional prefetch makes hipcc wait for the loads at once to merge registers at the join) ----
+    const int KL = KT - 1;
     load_a(0);
     dma_w(0, 0);
     write_a(0);
+    load_a(1 < KL ? 1 : KL);
+    dma_w(1 < KL ? 1 : KL, 1);
+    write_a(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    load_a(2 < KL ? 2 : KL);
+    read_frags(0, 0, a0, w0);
 
+    int cs = 0, ns = 1, ws = 2;                                     // ring positions of tiles kt, kt+1, kt+2
     for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < KT;
-        if (more) {                                                 // next tile: fp32 rows -> registers, weights -> LDS by DMA
-            load_a(kt + 1);
-            dma_w(kt + 1, cur ^ 1);
-        }
-        const unsigned char* st = smem + cur * STAGE;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f16x8 af[2][2], wf[2][2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    af[b][p] = *reinterpret_cast<const f16x8*>(st + a_frag + b * 32 * 16 + s * 2 * A_G + p * A_P);
-                    wf[b][p] = *reinterpret_cast<const f16x8*>(st + w_frag + b * 32 * 16 + s * 2 * W_G + p * W_P);
-                }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wf[j][0], hi[i][j], 0, 0, 0);
-                    lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wf[j][1], lo[i][j], 0, 0, 0);
-                    lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], wf[j][0], lo[i][j], 0, 0, 0);
-                }
-        }
-        if (more) write_a(cur ^ 1);                                 // split the prefetched rows into the other stage
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // my weight DMAs of tile kt+1 have landed
-        __syncthreads();                                            // everyone's have; stage `cur` is free again
+        const int t2 = kt + 2 < KL ? kt + 2 : KL, t3 = kt + 3 < KL ? kt + 3 : KL;
+        read_frags(cs, 1, a1, w1);
+        mfma_row(0, a0, w0);
+        __builtin_amdgcn_sched_barrier(0);
+        write_a(ws);                                                // rows of tile kt+2 (loaded an iteration ago): split -> LDS
+        dma_w(t2, ws);                                              // weights of tile kt+2 by LDS-DMA
+        __builtin_amdgcn_sched_barrier(0);                          // vmcnt counts in issue order: the DMAs must stay OLDER than the loads
+        load_a(t3);                                                 // rows of tile kt+3: a full iteration to arrive
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(1, a0, w0);
+        mfma_row(0, a1, w1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(ns, 0, a0, w0);                                  // tile kt+1 has been complete since the last barrier
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(1, a1, w1);
+        __builtin_amdgcn_sched_barrier(0);
+        // tile kt+2 must be in LDS (my DMAs landed, my ds_writes done) before anyone reads it after the NEXT barrier; the
+        // four row loads of tile kt+3 (younger than the DMAs) stay in flight across the barrier
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int t = cs; cs = ns; ns = ws; ws = t;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (overflow && !(mx < F16_MAX)) atomicOr(overflow, 1);
 

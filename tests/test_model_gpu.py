@@ -81,6 +81,30 @@ def test_dit_forward_vs_reference(dit, encoder, case):
     assert err < 2e-3
 
 
+def test_f16x2_gemm_gate_vs_reference(sd, encoder):
+    """VERDICT r1 item 6 gate: with the block Linears on the f16x2 split kernel the velocity error against the REFERENCE
+    (CPU, MKL fp32) must not exceed the error of the hipBLASLt fp32 path by more than fp32 noise."""
+    from selftoktokenizer_amd.mmdit import MMDiTGPU
+    g = gold("dit_forward_b1.npz")
+    d = MMDiTGPU(sd, torch.device("cuda"), 512)
+    ids = torch.from_numpy(synth.synthetic_token_ids(1)).cuda()
+    ehs = encoder.codes_ln(ids)
+    x = synth.synthetic_noise(1, device="cuda")
+    errs = {}
+    for mode in ("fp32", "f16x2"):
+        assert d.set_gemm(mode) == mode
+        for case in "abc":
+            t = torch.full((1,), float(g[f"t_{case}"]), device="cuda")
+            mask = (torch.arange(512, device="cuda")[None] <= int(g[f"k_{case}"]))
+            v, _ = d(x, t, encoder_hidden_states=ehs, mask=mask, context_see_xt=True)
+            errs[mode, case] = float((v.cpu() - torch.from_numpy(g[f"v_{case}"])).abs().max())
+    print("velocity max abs err vs reference:", errs)
+    assert int(d.overflow.item()) == 0
+    for case in "abc":
+        assert errs["f16x2", case] <= 1.25 * errs["fp32", case] + 2e-6
+        assert errs["f16x2", case] < 5e-5
+
+
 def test_dit_truncated_context_equals_masked(dit, encoder):
     """sampler fast path (context truncated to k+1 tokens, no mask) == per-sample kvis path"""
     ids = torch.from_numpy(synth.synthetic_token_ids(2)).cuda()

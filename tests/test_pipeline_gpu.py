@@ -41,7 +41,18 @@ def test_encoding_vs_reference(pipe):
     assert match >= 0.98
 
 
-def test_decoding_vs_reference(pipe):
+@pytest.mark.parametrize("gemm", ["fp32", "f16x2"])
+def test_decoding_vs_reference(pipe, gemm):
+    """50-step decode against the reference pipeline's own run, with the MMDiT Linears on hipBLASLt fp32 and on the f16x2
+    split kernel: the same gates hold for both (the split arithmetic is the more accurate of the two)."""
+    assert pipe.set_gemm(gemm) == gemm
+    try:
+        _decoding_vs_reference(pipe)
+    finally:
+        pipe.set_gemm("fp32")
+
+
+def _decoding_vs_reference(pipe):
     g = np.load(os.path.join(GOLD, "pipeline_b1.npz"))
     noise = synth.synthetic_noise(1)
     trace = []
