@@ -31,12 +31,14 @@
 // work-groups in one L2.
 #include "common.h"
 #include "selftok_hip.h"
+#include <stdlib.h>
 
 namespace selftok {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16v __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 256, BN = 128, BK = 32;
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
@@ -48,9 +50,12 @@ constexpr int A_BYTES = 2 * A_P;           // 33024
 constexpr int W_G = BN * 16;               // weight image: linear (filled by LDS-DMA)
 constexpr int W_P = 4 * W_G;
 constexpr int W_BYTES = 2 * W_P;           // 16384
-constexpr int STAGE = A_BYTES + W_BYTES;   // 49408
-constexpr int GROUP_M = 8;
-constexpr int NSTAGE = 3;                   // 3 x 48.25 KiB = 144.75 KiB of the CU's 160 KiB
+constexpr int A_STAGES = 2;                // activation images: tile kt (being multiplied) and tile kt+1 (being written)
+constexpr int W_STAGES = 5;                // weight images: tile kt .. kt+3 (three DMAs in flight) + the one freed last
+constexpr int W_AHEAD = 3;                 // the weight DMA of tile kt+3 is issued in iteration kt
+constexpr int W_BASE = A_STAGES * A_BYTES; // 66048
+constexpr int LDS_BYTES = W_BASE + W_STAGES * W_BYTES;   // 147968 of the CU's 163840
+constexpr int GROUP_M = 4;                 // 32 consecutive tiles (one XCD's resident set) = 4 row blocks x 8 column blocks
 
 __device__ __forceinline__ float gelu_tanh_f(float x)   // same formula as selftok_bias_gelu_f32 (elementwise.hip)
 {
@@ -59,7 +64,8 @@ __device__ __forceinline__ float gelu_tanh_f(float x)   // same formula as selft
     return 0.5f * x * (1.0f + tanhf(inner));
 }
 
-__device__ __forceinline__ void split4(const float4& v, f16x4& hi, f16x4& lo, float& mx)
+template <typename V4>
+__device__ __forceinline__ void split4(const V4& v, f16x4& hi, f16x4& lo, float& mx)
 {
     const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -94,14 +100,22 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     if (!(mx < F16_MAX) && overflow) atomicOr(overflow, 2);
 }
 
-template <int ACT>
+// ABL: ablation mask for tools/microbench (timing only, results wrong): 1 no split/ds_write, 2 no row loads, 4 no weight DMA,
+// 8 no MFMA, 16 no fragment reads.  The product library instantiates ABL = 0 only.
+//
+// Pipeline (one barrier per 32-deep k-tile).  PMC showed the first version bound by memory latency, not by instructions:
+// 30 % of the L2 requests miss (every A row panel is re-fetched from the Infinity Cache once per 32-tile round) and a miss
+// costs more than one k-iteration, so everything is fetched several iterations ahead:
+//   * activation rows (fp32) travel in registers, two sets: the set split+written in iteration kt (tile kt+1) was loaded in
+//     iteration kt-2 and is re-issued at once for tile kt+3;
+//   * weight tiles travel by LDS-DMA into a 5-deep ring, issued 3 iterations ahead; `s_waitcnt vmcnt(N)` is counted so that
+//     only the DMA of tile kt+1 has to have landed at the barrier ending iteration kt (vmcnt retires in issue order).
+template <int ACT, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void linear_f16x2_kernel(const float* __restrict__ A, long lda, const _Float16* __restrict__ Wp,
                                                               const float* __restrict__ bias, float* __restrict__ out, long ldo,
                                                               int M, int N, int K, int* __restrict__ overflow, int mblocks, int nblocks)
 {
-    // three-stage LDS ring: while tile t is multiplied, tile t+1 is complete (its first fragments are pre-read before
-    // the barrier, so the matrix pipe restarts immediately after it) and tile t+2 is being filled.
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_kernel(const float* __res
         nb = in / gsz;
     }
     const int m0 = mb * BM, n0 = nb * BN;
-    const int KT = K / BK;
+    const int KT = K / BK, KL = KT - 1;
 
     // ---- staging maps ----
     const int a_q = tid & 7, a_r = tid >> 3;                       // float4 column (k = 4q) and row (+64 i)
@@ -135,22 +149,38 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_kernel(const float* __res
     const int a_dst = (a_q >> 1) * A_G + a_r * 16 + (a_q & 1) * 8; // + i*64*16 (+ A_P for the lo plane)
     const _Float16* w_src = Wp + (size_t)nb * KT * (W_BYTES / 2) + (size_t)wave * 512 + lane * 8;   // chunk `wave`; +8 chunks for the second
 
-    float4 pre[4];
+    f32x4v preA[4], preB[4];                                       // the two register sets of activation rows in flight
     float mx = 0.f;
-    auto load_a = [&](int kt) {
+    // The row loads are inline asm: hipcc waits vmcnt(0) at the first use of an ordinary load while LDS-DMAs are in flight
+    // (it would drain the whole prefetch pipeline every iteration); hidden from it, they are waited for by the counted
+    // `wait_rows` below, which names the registers so that no use can be scheduled above it.
+    // Tile indices past the end are clamped to the last tile: the tail iterations then stage data nobody reads and the loop
+    // body has no conditional code.
+    auto load_a = [&](f32x4v (&pre)[4], int kt) {
+        kt = kt < KL ? kt : KL;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pre[i] = *reinterpret_cast<const float4*>(a_src[i] + (size_t)kt * BK);
+        for (int i = 0; i < 4; ++i) {
+            const float* p = a_src[i] + (size_t)kt * BK;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre[i]) : "v"(p) : "memory");
+        }
+    };
+    // VM ops retire in issue order.  Per iteration (phase B): 2 weight DMAs, then 4 row loads.  The set consumed in phase A of
+    // iteration kt was issued in iteration kt-2, so the 2 + 4 younger ops of iteration kt-1 may stay in flight.
+    auto wait_rows = [&](f32x4v (&pre)[4]) {
+        if (ABL & 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3])::"memory");
+        else asm volatile("s_waitcnt vmcnt(6)" : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3])::"memory");
     };
     auto dma_w = [&](int kt, int stage) {
+        kt = kt < KL ? kt : KL;
         const _Float16* src = w_src + (size_t)kt * (W_BYTES / 2);
-        unsigned char* dst = smem + stage * STAGE + A_BYTES + wave * 1024;
+        unsigned char* dst = smem + W_BASE + stage * W_BYTES + wave * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 8 * 512),
                                          (__attribute__((address_space(3))) void*)(dst + 8 * 1024), 16, 0, 0);
     };
-    auto write_a = [&](int stage) {
-        unsigned char* base = smem + stage * STAGE + a_dst;
+    auto write_a = [&](f32x4v (&pre)[4], int stage) {
+        unsigned char* base = smem + stage * A_BYTES + a_dst;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f16x4 h, l;
@@ -170,69 +200,88 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_kernel(const float* __res
         }
 
     const int a_frag = lh * A_G + (wm * 64 + l31) * 16;            // + rb*32*16 + s*2*A_G (+ A_P)
-    const int w_frag = A_BYTES + lh * W_G + (wn * 64 + l31) * 16;  // + cb*32*16 + s*2*W_G (+ W_P)
-    f16x8 a0[2][2], w0[2][2], a1[2][2], w1[2][2];                  // fragment sets of the two 16-deep k-steps of a tile
-    auto read_frags = [&](int stage, int s, f16x8 (&af)[2][2], f16x8 (&wf)[2][2]) {
-        const unsigned char* st = smem + stage * STAGE;
+    const int w_frag = W_BASE + lh * W_G + (wn * 64 + l31) * 16;   // + cb*32*16 + s*2*W_G (+ W_P)
+    f16x8 af0[2][2], wf0[2][2], af1[2][2], wf1[2][2];              // fragments of the two 16-deep k-steps of a tile
+    auto read_frags = [&](f16x8 (&af)[2][2], f16x8 (&wf)[2][2], int a_stage, int w_stage, int s) {
+        const unsigned char* sa = smem + a_stage * A_BYTES + a_frag + s * 2 * A_G;
+        const unsigned char* sw = smem + w_stage * W_BYTES + w_frag + s * 2 * W_G;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                af[b][p] = *reinterpret_cast<const f16x8*>(st + a_frag + b * 32 * 16 + s * 2 * A_G + p * A_P);
-                wf[b][p] = *reinterpret_cast<const f16x8*>(st + w_frag + b * 32 * 16 + s * 2 * W_G + p * W_P);
+                af[b][p] = *reinterpret_cast<const f16x8*>(sa + b * 32 * 16 + p * A_P);
+                wf[b][p] = *reinterpret_cast<const f16x8*>(sw + b * 32 * 16 + p * W_P);
             }
     };
-    auto mfma_row = [&](int i, f16x8 (&af)[2][2], f16x8 (&wf)[2][2]) {      // 6 MFMAs: row block i x both column blocks
+    // 6 MFMAs: row block i of one 16-deep k-step of the wave's 64 x 64 tile
+    auto mfma_row = [&](int i, f16x8 (&af)[2][2], f16x8 (&wf)[2][2]) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wf[j][0], hi[i][j], 0, 0, 0);
-            lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wf[j][1], lo[i][j], 0, 0, 0);
-            lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], wf[j][0], lo[i][j], 0, 0, 0);
-        }
+            for (int j = 0; j < 2; ++j) {
+                hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wf[j][0], hi[i][j], 0, 0, 0);
+                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wf[j][1], lo[i][j], 0, 0, 0);
+                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], wf[j][0], lo[i][j], 0, 0, 0);
+            }
     };
 
-    // ---- prologue: tiles 0 and 1 staged, tile 2's rows in flight.  Tile indices past the end are clamped to the last
-    // tile everywhere: the tail iterations then stage data nobody reads, and the loop body has no conditional code
-    // (a conditional prefetch makes hipcc wait for the loads at once to merge registers at the join) ----
-    const int KL = KT - 1;
-    load_a(0);
-    dma_w(0, 0);
-    write_a(0);
-    load_a(1 < KL ? 1 : KL);
-    dma_w(1 < KL ? 1 : KL, 1);
-    write_a(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    load_a(2 < KL ? 2 : KL);
-    read_frags(0, 0, a0, w0);
-
-    int cs = 0, ns = 1, ws = 2;                                     // ring positions of tiles kt, kt+1, kt+2
-    for (int kt = 0; kt < KT; ++kt) {
-        const int t2 = kt + 2 < KL ? kt + 2 : KL, t3 = kt + 3 < KL ? kt + 3 : KL;
-        read_frags(cs, 1, a1, w1);
-        mfma_row(0, a0, w0);
+    // one k-iteration = two phases, each 12 MFMAs with the staging work of the OTHER phase's data interleaved by the
+    // compiler (no fences inside a phase: an in-order wave can only hide VALU / LDS / VMEM issue in the 32-cycle shadow of
+    // its own MFMAs, and the two waves of a SIMD run in lockstep on the one barrier per iteration):
+    //   phase A: MFMA(tile kt, k-step 0)  ||  fragments of k-step 1 -> regs; rows of tile kt+1: wait, split, ds_write
+    //   barrier (tile kt+1 complete in LDS; every wave is done reading the stage tile kt+2 will overwrite)
+    //   phase B: MFMA(tile kt, k-step 1)  ||  weight DMA + row loads of tile kt+3; fragments of tile kt+1, k-step 0 -> regs
+    auto iteration = [&](int kt, f32x4v (&pre)[4], int ws_cur, int ws_next, int ws_new) {
+        const int as = kt & 1;
+        if (!(ABL & 16)) read_frags(af1, wf1, as, ws_cur, 1);
+        if (!(ABL & 8)) mfma_row(0, af0, wf0);                      // six MFMAs queued before the wave may block on its rows
         __builtin_amdgcn_sched_barrier(0);
-        write_a(ws);                                                // rows of tile kt+2 (loaded an iteration ago): split -> LDS
-        dma_w(t2, ws);                                              // weights of tile kt+2 by LDS-DMA
-        __builtin_amdgcn_sched_barrier(0);                          // vmcnt counts in issue order: the DMAs must stay OLDER than the loads
-        load_a(t3);                                                 // rows of tile kt+3: a full iteration to arrive
+        wait_rows(pre);                                             // also guarantees my (older) weight DMA of tile kt+1
+        if (!(ABL & 1)) write_a(pre, as ^ 1);
+        if (!(ABL & 8)) mfma_row(1, af0, wf0);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_row(1, a0, w0);
-        mfma_row(0, a1, w1);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(ns, 0, a0, w0);                                  // tile kt+1 has been complete since the last barrier
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(1, a1, w1);
-        __builtin_amdgcn_sched_barrier(0);
-        // tile kt+2 must be in LDS (my DMAs landed, my ds_writes done) before anyone reads it after the NEXT barrier; the
-        // four row loads of tile kt+3 (younger than the DMAs) stay in flight across the barrier
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const int t = cs; cs = ns; ns = ws; ws = t;
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 8)) mfma_row(0, af1, wf1);                      // queue matrix work first: hipcc waits lgkmcnt(0) before the
+        __builtin_amdgcn_sched_barrier(0);                          // first MFMA after a ds_read, whatever that read feeds
+        if (!(ABL & 16)) read_frags(af0, wf0, as ^ 1, ws_next, 0);
+        if (!(ABL & 4)) dma_w(kt + W_AHEAD, ws_new);                // VM issue order per iteration: 2 DMAs, then 4 row loads
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 2)) load_a(pre, kt + 3);
+        if (!(ABL & 8)) mfma_row(1, af1, wf1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: tile 0 staged, weight tiles 1 and 2 and the rows of tiles 1 (preB) and 2 (preA) in flight ----
+    dma_w(0, 0);
+    load_a(preA, 0);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(preA[0]), "+v"(preA[1]), "+v"(preA[2]), "+v"(preA[3])::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    write_a(preA, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    dma_w(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(preB, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    dma_w(2, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(preA, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(af0, wf0, 0, 0, 0);
+
+    // weight ring position of tile kt is kt % 5; the loop is unrolled by two so that the register sets have static names
+    auto ring = [](int x) { return x >= W_STAGES ? x - W_STAGES : x; };
+    int wc = 0;                                                     // kt % W_STAGES
+    int kt = 0;
+    for (; kt + 1 < KT; kt += 2) {
+        iteration(kt, preB, wc, ring(wc + 1), ring(wc + W_AHEAD));
+        wc = ring(wc + 1);
+        iteration(kt + 1, preA, wc, ring(wc + 1), ring(wc + W_AHEAD));
+        wc = ring(wc + 1);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (kt < KT) iteration(kt, preB, wc, ring(wc + 1), ring(wc + W_AHEAD));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(preA[0]), "+v"(preA[1]), "+v"(preA[2]), "+v"(preA[3]), "+v"(preB[0]), "+v"(preB[1]), "+v"(preB[2]), "+v"(preB[3])::"memory");
 
     if (overflow && !(mx < F16_MAX)) atomicOr(overflow, 1);
 
@@ -283,6 +332,15 @@ int selftok_linear_f16x2_f32(const float* A, long lda, const void* packed, const
     if (!A || !packed || !out || lda < K || ldo < N || (lda & 3)) { set_last_error("linear_f16x2: bad pointers/strides (lda % 4 == 0, lda >= K, ldo >= N)"); return SELFTOK_EINVAL; }
     const int mblocks = (M + BM - 1) / BM, nblocks = N / BN;
     const dim3 grid((unsigned)(mblocks * nblocks));
+#ifdef SELFTOK_GEMM_ABLATE
+    {
+        const char* e = getenv("SELFTOK_GEMM_ABL");
+        const int abl = e ? atoi(e) : 0;
+#define ABL_CASE(v) if (abl == v) { hipLaunchKernelGGL((linear_f16x2_kernel<0, v>), grid, dim3(512), 0, stream, A, lda, (const _Float16*)packed, bias, out, ldo, M, N, K, overflow, mblocks, nblocks); return check_launch("linear_f16x2_kernel(ablated)"); }
+        ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(7) ABL_CASE(8) ABL_CASE(16) ABL_CASE(24) ABL_CASE(23) ABL_CASE(31)
+#undef ABL_CASE
+    }
+#endif
     if (flags & SELFTOK_LINEAR_GELU)
         hipLaunchKernelGGL(linear_f16x2_kernel<1>, grid, dim3(512), 0, stream, A, lda, (const _Float16*)packed, bias, out, ldo, M, N, K, overflow, mblocks, nblocks);
     else

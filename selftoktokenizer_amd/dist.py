@@ -65,6 +65,29 @@ def all_gather_ids(ids_local: torch.Tensor) -> torch.Tensor:
     return torch.cat([bufs[r][: counts[r]] for r in range(world)]).to(ids_local.dtype).to(out_device)
 
 
+def backend_name():
+    """'nccl' (= RCCL on ROCm) / 'gloo' / None when there is a single rank"""
+    return dist.get_backend() if dist.is_initialized() and dist.get_world_size() > 1 else None
+
+
+def all_gather_ids_timed(ids_local: torch.Tensor):
+    """all_gather_ids + its duration in ms: HIP events on the current stream for RCCL (the collective is enqueued on the
+    stream, the host does not wait), host clock for gloo.  (ids_all, 0.0) with a single rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return ids_local, 0.0
+    if dist.get_backend() == "nccl" and ids_local.is_cuda:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = all_gather_ids(ids_local)
+        e1.record()
+        e1.synchronize()
+        return out, float(e0.elapsed_time(e1))
+    import time
+    t0 = time.perf_counter()
+    out = all_gather_ids(ids_local)
+    return out, 1000.0 * (time.perf_counter() - t0)
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         if dist.get_backend() == "nccl":

@@ -11,6 +11,7 @@ from . import _lib
 
 IDS_I32 = 1
 PRENORMED = 2
+VQ_EVENTS = None     # bench.py sets this to a list: vq_encode(packed=True) then appends (start, end) HIP events around the argmax kernel
 
 
 def _stream():
@@ -43,6 +44,16 @@ def vq_encode(z: torch.Tensor, codebook: torch.Tensor, *, packed: bool = False, 
     """z [...,16] fp32 (pre-norm) , codebook [C,16] (raw, or packed if packed=True) -> ids [...]"""
     _need_cuda(z, codebook)
     lib = _lib.load()
+    if packed and VQ_EVENTS is not None and not return_best and not prenormed and z.numel() > 0:
+        # same two launches as selftok_vq_encode_packed_f32, with HIP events around the argmax kernel on its launch stream
+        ids, launch_main, launch_fin = vq_encode_split_launch(z, codebook, ids_dtype)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch_main()
+        e1.record()
+        launch_fin()
+        VQ_EVENTS.append((e0, e1))
+        return ids
     zz = z.contiguous().float().reshape(-1, z.shape[-1])
     N, D = zz.shape
     C = (codebook.numel() - 64) // D if packed else codebook.shape[0]

@@ -47,3 +47,45 @@ def test_all_gather_ids_world2_gloo_even_and_uneven():
     for total in (4, 5):
         for rank, same, is64, tmax in _run(total):
             assert same and is64 and tmax == 2.0
+
+
+def _bench(*argv, env=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_gpus_n_spawns_n_ranks_itself():
+    """`python bench.py --gpus 2` (no torchrun around it, the form VERDICT r1 found broken) must start 2 ranks, gather ids
+    over the process group and say so in its JSON; `--selftest-dist` stops before any GPU work."""
+    rc, line, err = _bench("--gpus", "2", "--selftest-dist", "--batch", "3", env={"SELFTOK_DIST_BACKEND": "gloo"})
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] == "gloo" and line["allgather_ok"] is True
+    assert line["allgather_bytes"] == 2 * 3 * 512 * 4 and line["allgather_ms"] > 0
+    rc, line, _ = _bench("--gpus", "1", "--selftest-dist", "--batch", "2")
+    assert rc == 0 and line["n_gpus"] == 1 and line["backend"] is None
+
+
+def test_bench_refuses_world_size_mismatch():
+    """a launcher that starts fewer ranks than --gpus says must fail loudly, not print n_gpus: 1"""
+    rc, line, err = _bench("--gpus", "2", "--selftest-dist", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and line is None and "WORLD_SIZE=1" in err
+
+
+def test_bench_launch_command_is_one_rank_per_gpu():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    cmd = m.launch_command(8, ["--gpus", "8", "--steps", "3"], 29999)
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "3"] and cmd[-5].endswith("bench.py")
