@@ -11,7 +11,8 @@
  * data_ptr()), explicit sizes, a hipStream_t to launch on.  Every function returns 0 on success,
  * SELFTOK_EINVAL (-1) for a bad argument, SELFTOK_EHIP (-2) for a HIP launch error;
  * selftok_last_error() returns a thread-local message.  Nothing allocates, nothing synchronises,
- * nothing keeps state between calls: all entry points are re-entrant and graph-capturable.
+ * nothing keeps state between calls (no environment variables are read; the only memo is the per-device
+ * occupancy of a kernel, a constant): all entry points are re-entrant and graph-capturable.
  */
 #ifndef SELFTOK_HIP_H
 #define SELFTOK_HIP_H
@@ -34,6 +35,10 @@ typedef struct ihipStream_t* hipStream_t;
 /* flags shared by the VQ entry points */
 #define SELFTOK_IDS_I32 1     /* ids are int32 (default: int64, the reference's dtype) */
 #define SELFTOK_PRENORMED 2   /* z rows are already unit-norm: skip the fused l2norm */
+/* launch-shape overrides of the packed (MFMA) path, for tests and tuning only -- ids never depend on them:
+ * rows per wave tile (1, 2 or 4 x 32) and the number of code splits (1..64).  0 = choose from N and the device. */
+#define SELFTOK_VQ_RT(n) (((n) & 0xF) << 8)
+#define SELFTOK_VQ_SPLIT(n) (((n) & 0xFF) << 16)
 
 int selftok_version(void);
 const char* selftok_last_error(void);

@@ -47,6 +47,29 @@ def vq_encode(z: np.ndarray, codebook: np.ndarray, normalize: bool = True):
     return ids, best
 
 
+def vq_encode_mt(z: np.ndarray, codebook: np.ndarray, threads: int = 0, normalize: bool = True):
+    """vq_encode over row chunks on a thread pool (rows are independent; the C call releases the GIL): the same scalar
+    arithmetic, only wall time differs -- lets the full-size GPU parity tests compare every row in seconds."""
+    from concurrent.futures import ThreadPoolExecutor
+    z = np.ascontiguousarray(z, dtype=np.float32).reshape(-1, 16)
+    n = z.shape[0]
+    if threads <= 0:
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:
+            q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                threads = min(threads, max(1, int(int(q) / int(p))))
+        except Exception:
+            pass
+    threads = max(1, min(threads, 64, (n + 255) // 256))
+    if threads == 1:
+        return vq_encode(z, codebook, normalize)
+    bounds = np.linspace(0, n, threads + 1).astype(np.int64)
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda i: vq_encode(z[bounds[i]:bounds[i + 1]], codebook, normalize), range(threads)))
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+
 def vq_scores(x: np.ndarray, codebook: np.ndarray) -> np.ndarray:
     x, xp = _f32(x)
     cb, cbp = _f32(codebook)

@@ -253,6 +253,41 @@ def dit_forward(sd: SD, x: torch.Tensor, t: torch.Tensor, ehs: torch.Tensor, mas
     return unpatchify(final_layer(sd, xo, c), Hh // 2, Ww // 2)
 
 
+def cfg_uncond_forward(sd: SD, x: torch.Tensor, t: torch.Tensor, K: int, tables=None) -> torch.Tensor:
+    """MMDiT.cfg_inference(x, t, None, None, mask=zeros[B,K], shape=K) (sd3/mmdit.py:1117-1163), the unconditional branch of
+    classifier-free guidance: integer-floored timestep, all-zero context WITHOUT context_embedder / context_pos_embed,
+    sd3_cond_pooling is the string 'None' in the shipped configs (no pooled y), and ONE mask row for every query -- no
+    context key visible, every image key visible (context rows therefore see the image tokens here)."""
+    tables = tables or dit_ctx_tables(sd, K)
+    B, _, Hh, Ww = x.shape
+    t_int = torch.floor(t * 1000).int().clamp(0, 999)
+    xe = patch_embed(sd, "model.x_embedder", x) + crop_pos(sd["model.pos_embed"], 192, Hh // 2, Ww // 2)
+    c = t_embedder(sd, "model.t_embedder", t_int)
+    ctx = torch.zeros(B, K, xe.shape[-1], dtype=xe.dtype)
+    row = torch.cat([torch.zeros(B, K), torch.ones(B, xe.shape[1])], dim=1).bool()
+    amask = row[:, None, None, :].repeat(1, 1, K + xe.shape[1], 1)
+    xo = joint_blocks(sd, ctx, xe, c, amask, tables)
+    return unpatchify(final_layer(sd, xo, c), Hh // 2, Ww // 2)
+
+
+def sample_one_step(sd: SD, x: torch.Tensor, i: int, ehs: torch.Tensor, mask: torch.Tensor, sch, tables=None,
+                    cfg_scale: float = 1.0, context_see_xt: bool = True) -> torch.Tensor:
+    """RectifiedFlow.sample_one_step + euler_step 'velocity' (sd3/rectified_flow.py:258-304) for schedule entry i.
+    cfg_scale != 1: out = u + s (c - u) with u = cfg_inference(...) and c = model(x, t, None, context, mask=) -- that call does
+    not forward context_see_xt, which therefore falls back to False (sd3/mmdit.py:1012)."""
+    B = x.shape[0]
+    a_t = torch.tensor(sch["scheduled_t"][i])
+    a_prev = torch.tensor(sch["scheduled_t_prev"][i])
+    t = torch.full((B,), float(sch["scheduled_t"][i]), dtype=torch.float32)
+    if cfg_scale == 1.0:
+        v = dit_forward(sd, x, t, ehs, mask, context_see_xt, tables)
+    else:
+        u = cfg_uncond_forward(sd, x, t, ehs.shape[1], tables)
+        c = dit_forward(sd, x, t, ehs, mask, False, tables)
+        v = u + cfg_scale * (c - u)
+    return x - (a_t - a_prev) * v
+
+
 def renderer_forward(sd: SD, ehs: torch.Tensor, tables=None) -> torch.Tensor:
     """MMDiT_Renderer.forward(y=None, encoder_hidden_states=ehs) (sd3/mmdit.py:1511-1620)"""
     B, K, _ = ehs.shape
@@ -269,9 +304,12 @@ def renderer_forward(sd: SD, ehs: torch.Tensor, tables=None) -> torch.Tensor:
 
 
 def decode_latent(sd: SD, ids: torch.Tensor, noise: torch.Tensor, stages, k_per_stage, num_steps: int = 50,
-                  tables=None, trace: Optional[list] = None, max_steps: Optional[int] = None) -> torch.Tensor:
+                  tables=None, trace: Optional[list] = None, max_steps: Optional[int] = None, uncond_scale: float = 1.0,
+                  prefix_k: Optional[int] = None) -> torch.Tensor:
     """SelftokPipeline.decoding up to pred_x0 (SelftokPipeline.py:232-282) + p_sample_loop / euler_step
-    (sd3/rectified_flow.py:165-256, 258-309) with cfg_scale == 1 (the pipeline never forwards uncond_scale)."""
+    (sd3/rectified_flow.py:165-256, 258-309).  The pipeline never forwards uncond_scale (cfg_scale == 1); `uncond_scale` exposes
+    p_sample_loop's own argument.  `prefix_k`: p_sample_loop's `super_mask` = the first prefix_k tokens (mask * super_mask,
+    rectified_flow.py:226-227) -- decoding from a partial token prefix, README.md:241."""
     B, K = ids.shape
     ehs = codes_from_ids(sd, ids)                       # mask at timestep_map[0] (k=K-1) is all-true: ehs * 1
     sch = schedule.make_schedule(num_steps)
@@ -280,12 +318,10 @@ def decode_latent(sd: SD, ids: torch.Tensor, noise: torch.Tensor, stages, k_per_
     x = noise.float()
     steps = num_steps if max_steps is None else min(max_steps, num_steps)
     for i in range(steps):
-        a_t = torch.tensor(sch["scheduled_t"][i])
-        a_prev = torch.tensor(sch["scheduled_t_prev"][i])
-        t = torch.full((B,), float(sch["scheduled_t"][i]), dtype=torch.float32)
         mask = (torch.arange(K)[None, :] <= int(ks[i])).expand(B, K)
-        v = dit_forward(sd, x, t, ehs, mask, True, tables)
-        x = x - (a_t - a_prev) * v
+        if prefix_k is not None:
+            mask = mask & (torch.arange(K)[None, :] < int(prefix_k))
+        x = sample_one_step(sd, x, i, ehs, mask, sch, tables, cfg_scale=uncond_scale, context_see_xt=True)
         if trace is not None:
             trace.append(x.clone())
     return x

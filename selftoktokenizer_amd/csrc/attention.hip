@@ -312,7 +312,7 @@ int selftok_attn_f32(const selftok_attn_desc* d, hipStream_t stream)
         int t1 = P.seg[1].q ? (P.seg[1].len + QROWS - 1) / QROWS : 0;
         if (t0 + t1 == 0) return SELFTOK_OK;
         P.qtiles = t0 + t1;
-        { static int no = -1; if (no < 0) { const char* e = getenv("SELFTOK_ATTN_NOXCD"); no = e ? atoi(e) : 0; } P.xcd_remap = no ? 0 : 1; }
+        P.xcd_remap = 1;
         hipLaunchKernelGGL(attn64_kernel, dim3((t0 + t1) * d->H * d->B), dim3(256), 0, stream, P);
         return check_launch("attn64_kernel");
     }

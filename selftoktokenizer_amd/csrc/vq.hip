@@ -680,19 +680,23 @@ int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, vo
     const int ntiles = C >> 5;
     const int norm = (flags & 2) ? 0 : 1;
     int rt = N >= 32768 ? 4 : (N >= 8192 ? 2 : 1);     // measured: 130 / 126 / 118 TF at N=32768 for RT = 4 / 2 / 1
-    {   // tuning override (bench/debug): SELFTOK_VQ_RT=1|2|4
-        static int env_rt = -1;
-        if (env_rt < 0) { const char* e = getenv("SELFTOK_VQ_RT"); env_rt = e ? atoi(e) : 0; }
-        if (env_rt == 1 || env_rt == 2 || env_rt == 4) rt = env_rt;
+    {   // explicit tuning override in `flags` (tests sweep it; results never depend on it): SELFTOK_VQ_RT(1|2|4)
+        const int f_rt = (flags >> 8) & 0xF;
+        if (f_rt == 1 || f_rt == 2 || f_rt == 4) rt = f_rt;
     }
     int row_blocks = (N + 128 * rt - 1) / (128 * rt);
-    static int slots4 = -1, slots2 = -1, slots1 = -1;      // resident workgroups on this device, queried once
-    if (slots4 < 0) { slots4 = resident_slots(vq_mfma_kernel<4>); slots2 = resident_slots(vq_mfma_kernel<2>); slots1 = resident_slots(vq_mfma_kernel<1>); }
-    int split = pick_split_balanced(row_blocks, ntiles, 64, rt == 4 ? slots4 : (rt == 2 ? slots2 : slots1));
-    {   // tuning override (bench/debug): SELFTOK_VQ_SPLIT=n
-        static int env_split = -1;
-        if (env_split < 0) { const char* e = getenv("SELFTOK_VQ_SPLIT"); env_split = e ? atoi(e) : 0; }
-        if (env_split > 0 && env_split <= 64) split = env_split;
+    // resident workgroups per kernel variant: a pure function of (device, kernel), memoised per device -- no call-to-call state
+    static int slots[16][3] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (slots[dev][0] == 0) {
+        slots[dev][2] = resident_slots(vq_mfma_kernel<4>); slots[dev][1] = resident_slots(vq_mfma_kernel<2>);
+        slots[dev][0] = resident_slots(vq_mfma_kernel<1>);
+    }
+    int split = pick_split_balanced(row_blocks, ntiles, 64, rt == 4 ? slots[dev][2] : (rt == 2 ? slots[dev][1] : slots[dev][0]));
+    {   // SELFTOK_VQ_SPLIT(n), 1 <= n <= 64
+        const int f_split = (flags >> 16) & 0xFF;
+        if (f_split > 0 && f_split <= 64) split = f_split;
     }
     int tps = (ntiles + split - 1) / split;
     split = (ntiles + tps - 1) / tps;

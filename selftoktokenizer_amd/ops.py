@@ -19,9 +19,14 @@ def _stream():
 
 
 def _need_cuda(*ts):
+    """every op launches on the CURRENT device's current stream: tensors on another GPU are refused (a kernel launched on
+    GPU 0's stream against GPU 1 pointers would fault or race) -- select the device first (SelftokPipeline does)."""
     for t in ts:
         if t is not None and not t.is_cuda:
             raise _lib.SelftokHipError("selftok HIP ops need device tensors (there is no CPU fallback)")
+        if t is not None and t.device.index != torch.cuda.current_device():
+            raise _lib.SelftokHipError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                                       "call torch.cuda.set_device / use `with torch.cuda.device(...)` first")
 
 
 def _p(t):
@@ -40,8 +45,9 @@ def vq_pack_codebook(codebook: torch.Tensor) -> torch.Tensor:
 
 
 def vq_encode(z: torch.Tensor, codebook: torch.Tensor, *, packed: bool = False, return_best: bool = False,
-              ids_dtype=torch.int64, prenormed: bool = False):
-    """z [...,16] fp32 (pre-norm) , codebook [C,16] (raw, or packed if packed=True) -> ids [...]"""
+              ids_dtype=torch.int64, prenormed: bool = False, rt: int = 0, split: int = 0):
+    """z [...,16] fp32 (pre-norm) , codebook [C,16] (raw, or packed if packed=True) -> ids [...].
+    rt / split: launch-shape overrides of the packed path (SELFTOK_VQ_RT / SELFTOK_VQ_SPLIT; 0 = automatic)."""
     _need_cuda(z, codebook)
     lib = _lib.load()
     if packed and VQ_EVENTS is not None and not return_best and not prenormed and z.numel() > 0:
@@ -60,7 +66,7 @@ def vq_encode(z: torch.Tensor, codebook: torch.Tensor, *, packed: bool = False, 
     ids = torch.empty(N, dtype=ids_dtype, device=z.device)
     best = torch.empty(N, dtype=torch.float32, device=z.device) if return_best else None
     ws = torch.empty(lib.selftok_vq_workspace_bytes(N, C), dtype=torch.uint8, device=z.device)
-    flags = (IDS_I32 if ids_dtype == torch.int32 else 0) | (PRENORMED if prenormed else 0)
+    flags = (IDS_I32 if ids_dtype == torch.int32 else 0) | (PRENORMED if prenormed else 0) | ((rt & 0xF) << 8) | ((split & 0xFF) << 16)
     fn = lib.selftok_vq_encode_packed_f32 if packed else lib.selftok_vq_encode_f32
     _lib.check(fn(_p(zz), _p(codebook), _p(ids), _p(best), _p(ws), N, C, D, flags, _stream()),
                "selftok_vq_encode_packed_f32" if packed else "selftok_vq_encode_f32")
@@ -73,6 +79,10 @@ def vq_encode(z: torch.Tensor, codebook: torch.Tensor, *, packed: bool = False, 
 def code_gather_ln(ids: torch.Tensor, codebook: torch.Tensor, ln_w=None, ln_b=None, eps: float = 1e-6) -> torch.Tensor:
     """ids [...] (int64/int32) -> LayerNorm16(codebook[ids]) [...,16]"""
     _need_cuda(ids, codebook)
+    if ids.is_floating_point() or ids.is_complex() or ids.dtype == torch.bool:
+        raise TypeError(f"code_gather_ln: ids must be an integer tensor, got {ids.dtype}")
+    if ids.dtype not in (torch.int32, torch.int64):
+        ids = ids.to(torch.int64)                      # uint16 / int16 / uint8 wire formats: the kernel reads 4- or 8-byte ids only
     flat = ids.contiguous().reshape(-1)
     n = flat.numel()
     C, D = codebook.shape

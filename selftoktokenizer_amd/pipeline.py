@@ -81,7 +81,9 @@ class _Flow(FlowSchedule):
     @torch.no_grad()
     def p_sample_loop(self, dit: MMDiTGPU, noise: torch.Tensor, ehs: torch.Tensor, k_table: np.ndarray,
                       context_see_xt: bool = True, uncond_scale: float = 1.0, max_steps: Optional[int] = None,
-                      trace: Optional[list] = None) -> torch.Tensor:
+                      trace: Optional[list] = None, prefix_k: Optional[int] = None) -> torch.Tensor:
+        """`prefix_k`: the reference loop's `super_mask` (rectified_flow.py:226-227, mask = mask * super_mask) for the prefix mask
+        arange(K) < prefix_k -- only the first prefix_k tokens are ever visible (decode from a partial token sequence)."""
         B = noise.shape[0]
         x = noise.to(self.device).float().contiguous()
         hp, wp = x.shape[-2] // 2, x.shape[-1] // 2
@@ -90,6 +92,8 @@ class _Flow(FlowSchedule):
         steps = self.num_timesteps if max_steps is None else min(max_steps, self.num_timesteps)
         for i in range(steps):
             n_live = int(k_table[i]) + 1                                      # mask = arange(K) <= k  (models_ours.py:353)
+            if prefix_k is not None:
+                n_live = min(n_live, int(prefix_k))
             tf = self.t_freq[i:i + 1].expand(B, -1).contiguous()
             if uncond_scale == 1.0:
                 y = dit.velocity_tokens(x, tf, ctx0, n_live, context_see_xt, cqkv0)
@@ -99,7 +103,7 @@ class _Flow(FlowSchedule):
                 # the unconditional one sees no context token at all
                 y = dit.velocity_tokens(x, tf, ctx0, n_live, False, cqkv0)
                 tfu = self.t_freq_uncond[i:i + 1].expand(B, -1).contiguous()
-                yu = dit.velocity_tokens(x, tfu, ctx0, 0, False)
+                yu = dit.velocity_tokens(x, tfu, ctx0, 0, False)              # cfg_inference: no context key visible at all
             x, _ = ops.unpatchify_cfg_euler(y, x, float(self.dt[i]), y_uncond=yu, cfg_scale=uncond_scale, C=x.shape[1], hp=hp, wp=wp)
             if trace is not None:
                 trace.append(x.clone())
@@ -123,9 +127,20 @@ class SelftokPipeline():
             raise ValueError(f"Unsupported MODEL_TYPE: {model_type}. Expected 'sd3'")
         self.cfg, self.datasize, self.model_type, self.dtype = cfg, datasize, model_type, dtype
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is not None:
+            torch.cuda.set_device(self.device)                                # our launches use the current device's stream
         p = cfg.tokenizer.params
         p.noise_schedule_config.is_eval = cfg.common.is_eval
-        assert p.get("diffusion_type", "flow") == "flow"
+        # configuration knobs the reference honours but this hot path does not implement: refuse, never ignore silently
+        if p.get("diffusion_type", "flow") != "flow":
+            raise NotImplementedError("diffusion_type != 'flow' (the Gaussian-diffusion sampler is outside the hot path)")
+        nsc = p.noise_schedule_config
+        if nsc.get("parameterization", "velocity") != "velocity":
+            raise NotImplementedError("noise_schedule_config.parameterization == 'x0' (rectified_flow.py:305-307) is not implemented; "
+                                      "the shipped configs use 'velocity'")
+        cut = p.get("cut_of_k", None)
+        if cut and float(cut) < 1:
+            raise NotImplementedError("cut_of_k < 1 (context padding, rectified_flow.py:216-224) is not implemented; the shipped configs do not set it")
         K = int(p.k)
         renderer = "Renderer" in str(p.model)
         self.diti = DiTiCont(1000, K, p.stages, p.k_per_stage)
@@ -133,11 +148,13 @@ class SelftokPipeline():
         self.context_see_xt = bool(p.get("context_see_xt", False))
 
         vsd = vae_state_dict if vae_state_dict is not None else W.load_vae_checkpoint(sd3_path)
+        W.check_vae_state_dict(vsd)
         self.vae = AutoencoderKLGPU(vsd, self.device, dtype)
 
         self.verbose = verbose
         self._say("Loading all...")
         sd = state_dict if state_dict is not None else W.load_tokenizer_checkpoint(ckpt_path)
+        W.check_tokenizer_state_dict(sd, K, renderer=renderer, ema=bool(ema_decoder))   # load_state_dict(strict=False) / strict EMA load
         self.ema_decoder = ema_decoder
         dit_sd = sd
         if ema_decoder:   # reference :193-194: EMA copy of the DiT under 'ema_state_dict' (keys without the 'model.' prefix)
@@ -180,7 +197,15 @@ class SelftokPipeline():
 
     @torch.no_grad()
     def _codes(self, idx) -> torch.Tensor:
-        token_idx = torch.from_numpy(np.ascontiguousarray(idx)).to(self.device) if isinstance(idx, np.ndarray) else idx.to(self.device)
+        if isinstance(idx, np.ndarray):
+            if not np.issubdtype(idx.dtype, np.integer):
+                raise TypeError(f"token ids must be integers, got {idx.dtype} (the reference indexes the codebook with them)")
+            idx = np.ascontiguousarray(idx if idx.dtype in (np.int64, np.int32) else idx.astype(np.int64))   # uint16 / int16 / uint8 wire formats
+            token_idx = torch.from_numpy(idx).to(self.device)
+        else:
+            if idx.is_floating_point() or idx.dtype == torch.bool:
+                raise TypeError(f"token ids must be integers, got {idx.dtype}")
+            token_idx = idx.to(self.device)
         B = token_idx.shape[0]
         return self.model.encoder.codes_ln(token_idx.reshape(B, -1))          # get_output_from_indices + final_layer_norm3
 
@@ -211,19 +236,19 @@ class SelftokPipeline():
         return out
 
     @torch.no_grad()
-    def _sample(self, xt, ehs, max_steps, uncond_scale, use_graph):
+    def _sample(self, xt, ehs, max_steps, uncond_scale, use_graph, prefix_k=None):
         """the 50-step loop, optionally replayed from a hipGraph captured once per (batch, latent size) -- the loop is
         ~21k kernel launches; at small batch the host cannot issue them as fast as the GPU retires them."""
         if not use_graph:
             return self.flow.p_sample_loop(self.model.model, xt, ehs, self.k_table, context_see_xt=True,
-                                           uncond_scale=uncond_scale, max_steps=max_steps)
-        key = (tuple(xt.shape), tuple(ehs.shape), max_steps, float(uncond_scale), self.model.model.gemm)
+                                           uncond_scale=uncond_scale, max_steps=max_steps, prefix_k=prefix_k)
+        key = (tuple(xt.shape), tuple(ehs.shape), max_steps, float(uncond_scale), self.model.model.gemm, prefix_k)
         if key not in self._graphs:
             s_noise = torch.empty(xt.shape, dtype=torch.float32, device=self.device)
             s_ehs = torch.empty_like(ehs)
             s_noise.copy_(xt); s_ehs.copy_(ehs)
             run = lambda: self.flow.p_sample_loop(self.model.model, s_noise, s_ehs, self.k_table, context_see_xt=True,
-                                                  uncond_scale=uncond_scale, max_steps=max_steps)
+                                                  uncond_scale=uncond_scale, max_steps=max_steps, prefix_k=prefix_k)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):       # warm-up outside capture (hipBLASLt / allocator warm)
@@ -240,10 +265,16 @@ class SelftokPipeline():
 
     @torch.no_grad()
     def decoding(self, idx, device=None, noise: Optional[torch.Tensor] = None, return_latent: bool = False,
-                 max_steps: Optional[int] = None, uncond_scale: float = 1.0, use_graph: bool = False):
+                 max_steps: Optional[int] = None, uncond_scale: float = 1.0, use_graph: bool = False,
+                 prefix_k: Optional[int] = None):
         """idx: np.ndarray int64 [B,K] -> bf16 [B,3,H,W] in [0,1] (reference :227-294).  `noise` (extension) replaces the
-        `torch.randn` draw from the global CPU generator (:264); `uncond_scale` exposes the dormant CFG branch."""
+        `torch.randn` draw from the global CPU generator (:264); `uncond_scale` exposes the dormant CFG branch
+        (p_sample_loop's argument of that name).  `prefix_k` (extension): decode from the first prefix_k tokens only -- the
+        reference loop's `super_mask` hook with a prefix mask (rectified_flow.py:226-227; README.md:241: an AR model emits the
+        sequence in reverse order, `tokens.from_ar_order` restores it and `tokens.pad_prefix` pads a partial one to [B,K])."""
         self._say("Begin decoding.")
+        if prefix_k is not None and not (0 <= int(prefix_k) <= self.K):
+            raise ValueError(f"prefix_k must be in [0, {self.K}]")
         outs_q = self._codes(idx)
         B = outs_q.shape[0]
         # t_mapped = timestep_map[0] -> k = K-1 -> enc_mask all true -> encoder_hidden_states = outs_q (:243-252)
@@ -251,7 +282,7 @@ class SelftokPipeline():
         ehs = outs_q if k0 >= self.K - 1 else outs_q * (torch.arange(self.K, device=self.device) <= k0)[None, :, None]
         latent_dim = self.datasize // 8
         xt = noise if noise is not None else torch.randn(B, 16, latent_dim, latent_dim)
-        pred_x0 = self._checked(lambda: self._sample(xt, ehs, max_steps, uncond_scale, use_graph))
+        pred_x0 = self._checked(lambda: self._sample(xt, ehs, max_steps, uncond_scale, use_graph, prefix_k))
         recons = self._to_pixels(pred_x0)
         self._say('End decoding.')
         return (recons, pred_x0) if return_latent else recons

@@ -34,6 +34,8 @@ def load_image(path: str, size: int = 256) -> torch.Tensor:
 
 
 def save_image(img: torch.Tensor, path: str) -> None:
-    """[3,H,W] in [0,1] (any float dtype/device) -> 8-bit file, torchvision.utils.save_image rounding (x*255+0.5)."""
-    a = img.detach().float().cpu().clamp(0, 1).mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    """[3,H,W] in [0,1] (any float dtype/device) -> 8-bit file with torchvision.utils.save_image's arithmetic:
+    `mul(255).add_(0.5).clamp_(0, 255)` evaluated IN THE TENSOR'S OWN DTYPE (the reference passes the bf16 output of `decoding`
+    straight to torchvision, test.py:42-43, so the x*255+0.5 rounding happens in bf16), then truncation to uint8."""
+    a = img.detach().cpu().clone().mul_(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
     Image.fromarray(a).save(path)

@@ -53,6 +53,27 @@ def reverse_for_ar(tokens) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(tokens)[:, ::-1])
 
 
+def to_ar_order(tokens) -> np.ndarray:
+    """tokenizer order -> the order an AR model is trained on / emits (README.md:241: reversed)"""
+    return reverse_for_ar(tokens)
+
+
+def from_ar_order(tokens) -> np.ndarray:
+    """what an AR model emitted (coarse -> fine) -> tokenizer order, ready for `SelftokPipeline.decoding`"""
+    return reverse_for_ar(tokens)
+
+
+def pad_prefix(prefix, K: int, fill: int = 0):
+    """[B,k] tokenizer-order prefix (k <= K) -> (int64 [B,K] padded with `fill`, k): the arguments of
+    `SelftokPipeline.decoding(idx, prefix_k=k)`.  The padding ids are never visible (mask * super_mask)."""
+    t = np.asarray(prefix)
+    if t.ndim != 2 or t.shape[1] > K:
+        raise ValueError(f"prefix must be [B,k] with k <= {K}")
+    out = np.full((t.shape[0], K), fill, dtype=np.int64)
+    out[:, : t.shape[1]] = t
+    return out, int(t.shape[1])
+
+
 def prefix_mask(K: int, k) -> np.ndarray:
     """visibility mask of a partial decode that uses only tokens 0..k (reference get_encoder_mask, models_ours.py:345-353)"""
     k = np.asarray(k).reshape(-1, 1)

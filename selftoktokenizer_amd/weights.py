@@ -285,6 +285,61 @@ def diffusers_to_ldm_key(key: str) -> str:
 # real checkpoints
 # ----------------------------------------------------------------------------
 
+def load_state(model_shapes: Dict[str, Shape], state_dict: Dict[str, torch.Tensor], prefix: str = "", init_method=None):
+    """The reference's `load_state(model, state_dict, prefix, init_method)` filter (SelftokPipeline.py:46-83) over a shape table
+    instead of an nn.Module: strip `prefix`, keep only keys the model has, drop keys whose shape differs, and -- for the SD3
+    pretrain prefix 'model.diffusion_model.' -- the reference's exclusion lists (context_embedder, every context_block, and by
+    init_method the final layer / the x_block attention).  Returns (kept, missing, unexpected, shape_mismatched):
+    `missing` = model keys without a tensor, `unexpected` = always [] (foreign keys are filtered out before loading, as the
+    reference does), `shape_mismatched` = keys dropped for their shape."""
+    def strip(k):
+        return k.replace(prefix, "") if prefix else k
+    if prefix == "model.diffusion_model.":
+        excluded = ["context_embedder.bias", "context_embedder.weight"]
+        if init_method == 1:
+            excluded += ["final_layer.adaLN_modulation.1.bias", "final_layer.adaLN_modulation.1.weight",
+                         "final_layer.linear.bias", "final_layer.linear.weight"]
+        kept = {strip(k): v for k, v in state_dict.items()
+                if strip(k) in model_shapes and strip(k) not in excluded and "context_block" not in k
+                and not (init_method == 2 and "x_block.attn" in k)}
+    else:
+        kept = {strip(k): v for k, v in state_dict.items() if strip(k) in model_shapes}
+    bad = [k for k, v in kept.items() if tuple(v.shape) != tuple(model_shapes[k])]
+    for k in bad:
+        kept.pop(k)
+    missing = [k for k in model_shapes if k not in kept]
+    return kept, missing, [], bad
+
+
+def check_tokenizer_state_dict(sd: Dict[str, torch.Tensor], K: int, renderer: bool = False, ema: bool = False) -> None:
+    """What `ImageTokenizer.load_state_dict(state_dict, strict=False)` (SelftokPipeline.py:195) accepts, made explicit for the
+    keys the encode/decode path reads.  torch raises on a size mismatch even with strict=False -> RuntimeError here too.  A MISSING
+    key is silently tolerated by the reference, which then runs on randomly initialised parameters; this build refuses instead
+    (RuntimeError naming the keys).  Unexpected keys (optimizer state, diffusion.* buffers, ...) are ignored like the reference.
+    `ema`: also require the strict `ema.load_state_dict(state_dict['ema_state_dict'])` contract of :193-194 -- exactly the
+    MMDiT keys without the 'model.' prefix, missing or unexpected keys are errors."""
+    shapes = expected_shapes(K, renderer=renderer)
+    need = {k: v for k, v in shapes.items() if not k.startswith("encoder.quantizer.") or k.endswith("_codebook.embed")
+            or ".project_in." in k}
+    mism = [f"{k}: checkpoint {tuple(sd[k].shape)} vs model {tuple(v)}" for k, v in need.items() if k in sd and tuple(sd[k].shape) != tuple(v)]
+    if mism:
+        raise RuntimeError("size mismatch for " + "; ".join(mism[:8]) + (" ..." if len(mism) > 8 else ""))
+    missing = [k for k in need if k not in sd and not (ema and k.startswith("model."))]
+    if missing:
+        raise RuntimeError(f"{len(missing)} tokenizer parameters are missing from the checkpoint (the reference would silently keep random "
+                           f"initial values, strict=False): {missing[:6]}{' ...' if len(missing) > 6 else ''}")
+    if ema:
+        if "ema_state_dict" not in sd:
+            raise KeyError("ema_state_dict")                       # what state_dict['ema_state_dict'] raises in the reference
+        dit = {k[len("model."):]: v for k, v in shapes.items() if k.startswith("model.")}
+        e = sd["ema_state_dict"]
+        miss = [k for k in dit if k not in e]
+        unexp = [k for k in e if k not in dit]
+        bad = [k for k in dit if k in e and tuple(e[k].shape) != tuple(dit[k])]
+        if miss or unexp or bad:
+            raise RuntimeError(f"Error(s) in loading ema_state_dict (strict): missing {miss[:4]}, unexpected {unexp[:4]}, size mismatch {bad[:4]}")
+
+
 def load_tokenizer_checkpoint(path: str) -> Dict[str, torch.Tensor]:
     """`torch.load(ckpt, map_location='cpu')` flat state dict (reference SelftokPipeline.py:190)."""
     sd = torch.load(path, map_location="cpu")
@@ -293,20 +348,48 @@ def load_tokenizer_checkpoint(path: str) -> Dict[str, torch.Tensor]:
     return sd
 
 
+VAE_FILENAMES = ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.bin",
+                 "diffusion_pytorch_model.fp16.bin")
+
+
 def load_vae_checkpoint(sd3_path: str) -> Dict[str, torch.Tensor]:
-    """<sd3_path>/vae/diffusion_pytorch_model.safetensors in diffusers layout (reference SelftokPipeline.py:162),
-    or a single-file ldm checkpoint with `first_stage_model.` keys (reference set_sd3_vae, :115-121)."""
+    """<sd3_path>/vae/diffusion_pytorch_model.{safetensors,fp16.safetensors,bin} in diffusers layout (what
+    `AutoencoderKL.from_pretrained(sd3_path, subfolder="vae")` reads, reference SelftokPipeline.py:162), or a single-file ldm
+    checkpoint with `first_stage_model.` keys (reference set_sd3_vae + load_state, :46-83, :115-121).  The result is checked
+    against the 244-entry SD3-VAE table: anything missing or mis-shaped is reported here, not as a KeyError deep inside the VAE."""
     import os
-    cand = os.path.join(sd3_path, "vae", "diffusion_pytorch_model.safetensors")
-    if os.path.exists(cand):
-        from safetensors.torch import load_file
-        return load_file(cand)
-    raw = torch.load(sd3_path, map_location="cpu")
-    inv = {diffusers_to_ldm_key(k): k for k in vae_shapes()}
-    out = {}
-    for k, v in raw.items():
-        k2 = k.replace("first_stage_model.", "")
-        if k2 in inv:
-            tgt = inv[k2]
-            out[tgt] = v.reshape(vae_shapes()[tgt])
+    shapes = vae_shapes()
+    out = None
+    if os.path.isdir(sd3_path):
+        for name in VAE_FILENAMES:
+            cand = os.path.join(sd3_path, "vae", name)
+            if os.path.exists(cand):
+                if name.endswith(".safetensors"):
+                    from safetensors.torch import load_file
+                    raw = load_file(cand)
+                else:
+                    raw = torch.load(cand, map_location="cpu")
+                out = {k: v for k, v in raw.items() if k in shapes}
+                break
+        if out is None:
+            raise FileNotFoundError(f"no VAE weights under {os.path.join(sd3_path, 'vae')}: looked for {', '.join(VAE_FILENAMES)}")
+    else:
+        raw = torch.load(sd3_path, map_location="cpu")
+        ldm_shapes = {diffusers_to_ldm_key(k): k for k in shapes}
+        out = {}
+        for k, v in raw.items():
+            k2 = k.replace("first_stage_model.", "")
+            if k2 in ldm_shapes:
+                tgt = ldm_shapes[k2]
+                if v.numel() == int(torch.tensor(shapes[tgt]).prod()):          # attention q/k/v/out are 1x1 convs in the ldm layout
+                    out[tgt] = v.reshape(shapes[tgt])
     return out
+
+
+def check_vae_state_dict(vsd: Dict[str, torch.Tensor]) -> None:
+    shapes = vae_shapes()
+    missing = [k for k in shapes if k not in vsd]
+    bad = [f"{k}: {tuple(vsd[k].shape)} vs {tuple(shapes[k])}" for k in shapes if k in vsd and tuple(vsd[k].shape) != tuple(shapes[k])]
+    if missing or bad:
+        raise RuntimeError(f"SD3 VAE checkpoint does not match the 244-tensor stabilityai layout: {len(missing)} missing "
+                           f"{missing[:5]}{' ...' if len(missing) > 5 else ''}; size mismatch {bad[:5]}")

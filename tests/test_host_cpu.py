@@ -187,3 +187,104 @@ def test_preprocess_matches_reference_transform_chain(tmp_path):
     preprocess.save_image((t + 1) / 2, str(tmp_path / "o.png"))
     back = np.array(Image.open(str(tmp_path / "o.png")))
     assert back.shape == (32, 32, 3)
+
+
+def test_load_state_filter_semantics():
+    """the reference's load_state(model, state_dict, prefix, init_method) (SelftokPipeline.py:46-83): prefix stripping, foreign keys
+    dropped, shape mismatches dropped, and the SD3-pretrain exclusion lists"""
+    shapes = {"a.weight": (2, 3), "b.bias": (4,), "joint_blocks.0.context_block.attn.qkv.weight": (1,), "joint_blocks.0.x_block.attn.qkv.weight": (1,),
+              "final_layer.linear.weight": (2, 2), "context_embedder.bias": (3,)}
+    pre = "model.diffusion_model."
+    sd = {pre + "a.weight": torch.zeros(2, 3), pre + "b.bias": torch.zeros(5), pre + "joint_blocks.0.context_block.attn.qkv.weight": torch.zeros(1),
+          pre + "joint_blocks.0.x_block.attn.qkv.weight": torch.zeros(1), pre + "final_layer.linear.weight": torch.zeros(2, 2),
+          pre + "context_embedder.bias": torch.zeros(3), "first_stage_model.z": torch.zeros(1)}
+    kept, missing, unexpected, bad = W.load_state(shapes, sd, pre)
+    assert set(kept) == {"a.weight", "joint_blocks.0.x_block.attn.qkv.weight", "final_layer.linear.weight"}
+    assert bad == ["b.bias"] and unexpected == [] and "context_embedder.bias" in missing and "b.bias" in missing
+    assert set(W.load_state(shapes, sd, pre, init_method=1)[0]) == {"a.weight", "joint_blocks.0.x_block.attn.qkv.weight"}
+    assert set(W.load_state(shapes, sd, pre, init_method=2)[0]) == {"a.weight", "final_layer.linear.weight"}
+    plain = {"a.weight": torch.zeros(2, 3), "zzz": torch.zeros(1)}
+    kept, missing, _, _ = W.load_state(shapes, plain)
+    assert set(kept) == {"a.weight"} and len(missing) == 5
+
+
+def test_tokenizer_checkpoint_contract(tmp_path):
+    """ImageTokenizer.load_state_dict(strict=False) + strict EMA load (SelftokPipeline.py:193-198), on shape tables only"""
+    shapes = W.expected_shapes(512)
+    meta = {k: torch.empty(v, device="meta") for k, v in shapes.items()}
+    W.check_tokenizer_state_dict(meta, 512)                                        # complete: fine
+    W.check_tokenizer_state_dict(dict(meta, optimizer_state=torch.empty(1, device="meta")), 512)   # unexpected keys are ignored
+    bad = dict(meta)
+    bad["model.context_pos_embed"] = torch.empty(1, 1024, 1536, device="meta")
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        W.check_tokenizer_state_dict(bad, 512)
+    part = {k: v for k, v in meta.items() if k != "encoder.query_tokens"}
+    with pytest.raises(RuntimeError, match="missing"):
+        W.check_tokenizer_state_dict(part, 512)
+    # ema_decoder=True: the DiT comes from state_dict['ema_state_dict'] (keys without 'model.'), strict
+    enc_only = {k: v for k, v in meta.items() if not k.startswith("model.")}
+    with pytest.raises(KeyError):
+        W.check_tokenizer_state_dict(enc_only, 512, ema=True)
+    ema = {k[len("model."):]: v for k, v in meta.items() if k.startswith("model.")}
+    W.check_tokenizer_state_dict(dict(enc_only, ema_state_dict=ema), 512, ema=True)
+    with pytest.raises(RuntimeError, match="strict"):
+        W.check_tokenizer_state_dict(dict(enc_only, ema_state_dict={k: v for k, v in list(ema.items())[1:]}), 512, ema=True)
+    with pytest.raises(RuntimeError, match="strict"):
+        W.check_tokenizer_state_dict(dict(enc_only, ema_state_dict=dict(ema, extra=torch.empty(1, device="meta"))), 512, ema=True)
+
+
+def test_vae_checkpoint_layouts_and_validation(tmp_path):
+    from safetensors.torch import save_file
+    shapes = W.vae_shapes()
+    full = {k: torch.zeros(v, dtype=torch.bfloat16) for k, v in shapes.items()}
+    W.check_vae_state_dict(full)
+    with pytest.raises(RuntimeError, match="missing"):
+        W.check_vae_state_dict({k: v for k, v in full.items() if k != "decoder.conv_out.bias"})
+    # fp16-variant filename and .bin are found; an empty vae folder is a clear error
+    (tmp_path / "a" / "vae").mkdir(parents=True)
+    save_file({k: v for k, v in list(full.items())[:3]}, str(tmp_path / "a" / "vae" / "diffusion_pytorch_model.fp16.safetensors"))
+    assert len(W.load_vae_checkpoint(str(tmp_path / "a"))) == 3
+    (tmp_path / "b" / "vae").mkdir(parents=True)
+    torch.save({k: v for k, v in list(full.items())[:2]}, str(tmp_path / "b" / "vae" / "diffusion_pytorch_model.bin"))
+    assert len(W.load_vae_checkpoint(str(tmp_path / "b"))) == 2
+    (tmp_path / "c" / "vae").mkdir(parents=True)
+    with pytest.raises(FileNotFoundError):
+        W.load_vae_checkpoint(str(tmp_path / "c"))
+
+
+def test_ar_order_and_prefix_helpers():
+    from selftoktokenizer_amd import tokens as T
+    ids = synth.synthetic_token_ids(2, 512)
+    ar = T.to_ar_order(ids)
+    assert np.array_equal(ar[:, 0], ids[:, -1]) and np.array_equal(T.from_ar_order(ar), ids)
+    padded, k = T.pad_prefix(ids[:, :100], 512)
+    assert k == 100 and padded.shape == (2, 512) and padded.dtype == np.int64
+    assert np.array_equal(padded[:, :100], ids[:, :100]) and not padded[:, 100:].any()
+    with pytest.raises(ValueError):
+        T.pad_prefix(ids, 256)
+
+
+def test_unsupported_config_knobs_are_refused_not_ignored():
+    """cut_of_k < 1 / parameterization 'x0' change the reference's result; the pipeline must refuse them before touching a GPU"""
+    src = open(os.path.join(ROOT, "selftoktokenizer_amd", "pipeline.py")).read()
+    assert "cut_of_k < 1" in src and "parameterization" in src and src.count("raise NotImplementedError") >= 3
+    if torch.cuda.is_available():
+        from mimogpt.infer.SelftokPipeline import SelftokPipeline
+        cfg = config.default_config(512)
+        cfg.tokenizer.params.noise_schedule_config.parameterization = "x0"
+        with pytest.raises(NotImplementedError):
+            SelftokPipeline(cfg, None, None, device="cuda", state_dict={}, vae_state_dict={})
+
+
+def test_save_image_uses_the_tensor_dtype_arithmetic(tmp_path):
+    """torchvision.utils.save_image computes x*255+0.5 in the tensor's dtype; the reference hands it the bf16 decode output"""
+    from PIL import Image
+    from selftoktokenizer_amd import preprocess
+    x = torch.linspace(0, 1, 3 * 8 * 8).reshape(3, 8, 8)
+    preprocess.save_image(x.to(torch.bfloat16), str(tmp_path / "b.png"))
+    got = np.array(Image.open(str(tmp_path / "b.png")))
+    want = x.to(torch.bfloat16).clone().mul_(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    assert np.array_equal(got, want)
+    preprocess.save_image(x, str(tmp_path / "f.png"))
+    want32 = x.clone().mul_(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    assert np.array_equal(np.array(Image.open(str(tmp_path / "f.png"))), want32)

@@ -56,7 +56,7 @@ def test_encoder_features_and_ids(encoder):
     ids = ids.cpu().numpy()
     mism = ids != g["ids"]
     print("e2e token match", 1.0 - mism.mean(), "gaps of mismatches", g["gap"][mism])
-    assert mism.mean() <= 0.01
+    assert mism.sum() <= 1                      # measured: 1024 / 1024; one flip allowed, and only at a near-tie of the reference
     assert (g["gap"][mism] < GAP_TOL).all()
     # kernel boundary: feeding the reference's own features must give the reference's ids exactly
     ids_k = ops.vq_encode(torch.from_numpy(g["z"]).cuda(), encoder.codebook_packed, packed=True).cpu().numpy()

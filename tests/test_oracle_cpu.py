@@ -154,3 +154,35 @@ def test_pinning_report_is_committed():
     for k in ("dit_a", "dit_b", "dit_c"):
         assert rep[k]["v_maxdiff"] == 0.0
     assert rep["renderer"]["maxdiff"] == 0.0
+    for k in ("cfg_step0", "cfg_step1"):
+        assert rep[k]["lat_maxdiff"] == 0.0
+    assert rep["cfg_velocities"]["uncond_maxdiff"] == 0.0 and rep["cfg_velocities"]["cond_maxdiff"] == 0.0
+
+
+@pytest.mark.slow
+def test_cfg_oracle_matches_reference(dit_sd):
+    """classifier-free guidance: the reference's sample_one_step(cfg_scale=2) -> cfg_inference + conditional forward, one guided
+    step and the two velocities at schedule entry 30 (golden cfg_b1.npz, generated by tools/oracle/gen_golden.py cfg)"""
+    g = gold("cfg_b1.npz")
+    sd = dit_sd
+    ids = torch.from_numpy(g["ids"])
+    ehs = OM.codes_from_ids(sd, ids)
+    x = synth.synthetic_noise(1, first_index=11)
+    tables = OM.dit_ctx_tables(sd, 512)
+    sch = OS.make_schedule(50)
+    stg, kps = OS.parse_stages("200,400,600,800,1000", "192,184,72,48,16")
+    ks = OS.k_table(50, stg, kps, 512)
+    mask0 = torch.arange(512)[None] <= int(ks[0])
+    x1 = OM.sample_one_step(sd, x, 0, ehs, mask0, sch, tables, cfg_scale=float(g["scale"]))
+    assert float((x1 - torch.from_numpy(g["lat_after_1"])).abs().max()) <= 1e-6
+    i = int(g["index"])
+    assert int(ks[i]) == int(g["k"])
+    t = torch.full((1,), float(sch["scheduled_t"][i]))
+    vu = OM.cfg_uncond_forward(sd, x, t, 512, tables)
+    assert float((vu - torch.from_numpy(g["v_uncond"])).abs().max()) <= 1e-5
+    vc = OM.dit_forward(sd, x, t, ehs, torch.arange(512)[None] <= int(ks[i]), False, tables)
+    assert float((vc - torch.from_numpy(g["v_cond"])).abs().max()) <= 1e-5
+    # partial-prefix decode = the same loop with mask * super_mask: a full-length prefix changes nothing
+    full = OM.decode_latent(sd, ids, x, stg, kps, 50, tables, max_steps=1, prefix_k=512)
+    plain = OM.decode_latent(sd, ids, x, stg, kps, 50, tables, max_steps=1)
+    assert torch.equal(full, plain)

@@ -38,7 +38,7 @@ def test_encoding_vs_reference(pipe):
     assert tokens.dtype == torch.int64 and tokens.is_cuda and tuple(tokens.shape) == (1, 512)
     match = float((tokens.cpu().numpy() == g["tokens"]).mean())
     print("e2e token-id exact match vs reference pipeline (bf16 VAE upstream):", match)
-    assert match >= 0.98
+    assert match >= 511 / 512                   # measured 512 / 512 (the oracle itself matches the reference 511 / 512 through its CPU bf16 VAE)
 
 
 @pytest.mark.parametrize("gemm", ["fp32", "f16x2"])
@@ -96,10 +96,82 @@ def test_decode_is_deterministic_and_batch_independent(pipe):
     assert float((a.float() - a2.float()).abs().max()) < 0.05
 
 
-def test_cfg_branch_runs(pipe):
+@pytest.mark.parametrize("gemm", ["fp32", "f16x2"])
+def test_cfg_vs_reference(pipe, gemm):
+    """classifier-free guidance against the reference's own sampler (golden cfg_b1.npz = RectifiedFlow.sample_one_step with
+    cfg_scale = 2 calling MMDiT.cfg_inference and the conditional forward without context_see_xt): latents after one and two
+    guided steps, and the unconditional / conditional velocities alone at schedule entry 30 (k = 375)."""
+    g = np.load(os.path.join(GOLD, "cfg_b1.npz"))
+    assert pipe.set_gemm(gemm) == gemm
+    try:
+        noise = synth.synthetic_noise(1, first_index=11)
+        trace = []
+        real = pipe.flow.p_sample_loop
+        pipe.flow.p_sample_loop = lambda *a, **k: real(*a, trace=trace, **k)
+        try:
+            pipe.decoding(g["ids"], noise=noise, max_steps=2, uncond_scale=float(g["scale"]))
+        finally:
+            pipe.flow.p_sample_loop = real
+        for n in (1, 2):
+            err = float((trace[n - 1].cpu() - torch.from_numpy(g[f"lat_after_{n}"])).abs().max())
+            print(f"[{gemm}] guided latent after {n} steps: max abs err {err:.3e}")
+            assert err < 1e-5
+        dit, enc = pipe.model.model, pipe.model.encoder
+        i, k = int(g["index"]), int(g["k"])
+        assert int(pipe.k_table[i]) == k
+        x = noise.cuda()
+        ctx0 = dit.embed_context(enc.codes_ln(torch.from_numpy(g["ids"]).cuda()))
+        yc = dit.velocity_tokens(x, pipe.flow.t_freq[i:i + 1].contiguous(), ctx0, k + 1, False)
+        yu = dit.velocity_tokens(x, pipe.flow.t_freq_uncond[i:i + 1].contiguous(), ctx0, 0, False)
+        from selftoktokenizer_amd import ops
+        for name, y in (("v_cond", yc), ("v_uncond", yu)):
+            v = ops.unpatchify_cfg_euler(y, C=16, hp=16, wp=16)[1]
+            err = float((v.cpu() - torch.from_numpy(g[name])).abs().max())
+            print(f"[{gemm}] {name} at schedule entry {i}: max abs err {err:.3e}")
+            assert err < 5e-5
+    finally:
+        pipe.set_gemm("fp32")
+
+
+def test_decoding_accepts_every_integer_wire_format(pipe):
+    """tokens.py advertises uint16; torch.from_numpy also takes int16/int32 arrays: all must decode like int64"""
     ids = synth.synthetic_token_ids(1)
-    rec, lat = pipe.decoding(ids, noise=synth.synthetic_noise(1), return_latent=True, max_steps=2, uncond_scale=2.0)
-    assert torch.isfinite(lat).all()
+    noise = synth.synthetic_noise(1)
+    _, ref = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=1)
+    for dt in (np.uint16, np.int32, np.uint32):
+        _, lat = pipe.decoding(ids.astype(dt), noise=noise, return_latent=True, max_steps=1)
+        assert torch.equal(lat, ref), dt
+    _, lat = pipe.decoding(torch.from_numpy(ids).to(torch.int16).clamp(min=0), noise=noise, return_latent=True, max_steps=1)
+    assert lat.shape == ref.shape
+    with pytest.raises(TypeError):
+        pipe.decoding(ids.astype(np.float32), noise=noise, max_steps=1)
+
+
+@pytest.mark.parametrize("prefix_k", [20, 376])
+def test_partial_prefix_decode_vs_oracle(pipe, prefix_k):
+    """decode from the first prefix_k tokens only (the reference loop's super_mask hook with a prefix mask; README.md:241):
+    equals the oracle's p_sample_loop with mask * super_mask, and does not depend on the ids beyond the prefix"""
+    from oracle import model as OM, schedule as OS
+    from selftoktokenizer_amd import tokens as T
+    ids = synth.synthetic_token_ids(1, first_index=4)
+    noise = synth.synthetic_noise(1, first_index=4)
+    _, lat = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=2, prefix_k=prefix_k)
+    padded, k = T.pad_prefix(T.from_ar_order(T.to_ar_order(ids))[:, :prefix_k], 512)
+    assert k == prefix_k
+    _, lat_pad = pipe.decoding(padded, noise=noise, return_latent=True, max_steps=2, prefix_k=k)
+    assert torch.equal(lat, lat_pad)                       # invisible ids are never read
+    _, lat_full = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=2)
+    assert not torch.equal(lat, lat_full)
+    dit_sd = {k_: v.cpu() for k_, v in pipe.model.model.w.items()}
+    dit_sd.update({k_: v.cpu() for k_, v in pipe.model.encoder.w.items() if "final_layer_norm3" in k_})
+    dit_sd["encoder.quantizer._codebook.embed"] = pipe.model.encoder.codebook.cpu()[None]
+    stg, kps = OS.parse_stages("200,400,600,800,1000", "192,184,72,48,16")
+    ref = OM.decode_latent(dit_sd, torch.from_numpy(ids), noise, stg, kps, 50, max_steps=2, prefix_k=prefix_k)
+    err = float((lat.cpu() - ref).abs().max())
+    print(f"prefix_k={prefix_k}: latent after 2 steps vs oracle max abs err {err:.3e}")
+    assert err < 1e-4
+    with pytest.raises(ValueError):
+        pipe.decoding(ids, noise=noise, prefix_k=513)
 
 
 def test_k1024_and_renderer_configs_run():

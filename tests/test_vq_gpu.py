@@ -104,6 +104,40 @@ def test_vq_full_size_properties(cb):
     np.testing.assert_array_equal(best_m[sel].cpu().numpy().view(np.uint32), best_ref.view(np.uint32))
 
 
+_ORACLE_CACHE = {}
+
+
+def _oracle_full(n, cb):
+    """every row through the C oracle (threaded over row chunks), cached per N for the launch-shape sweep"""
+    if n not in _ORACLE_CACHE:
+        from oracle import clib
+        z = synth.synthetic_vq_rows(n, seed=0x5EED + n)
+        z[n // 3] = 0.0                                   # an all-zero row and an exact-code row inside every size
+        z[n // 2] = cb[(7 * n) % 32768] * 1.5
+        _ORACLE_CACHE[n] = (z,) + tuple(clib.vq_encode_mt(z.numpy(), cb.numpy()))
+    return _ORACLE_CACHE[n]
+
+
+@pytest.mark.parametrize("n", [8192, 12288, 16384, 32768, 65536, 131072])
+def test_vq_mfma_every_launch_shape_full_n(cb, n):
+    """BASELINE row counts (B*K for configs[1..3]) and the sizes in between, EVERY row against the oracle, for every wave-tile
+    variant vq_mfma_kernel<1|2|4> (the automatic choice is <2> for 8192 <= N < 32768) and several code-split counts
+    (1 = no split, odd, maximal); the inline-asm max3 scan behind the MFMAs must give the same bits in all of them."""
+    z, ids_ref, best_ref = _oracle_full(n, cb)
+    zc = z.cuda()
+    pk = ops.vq_pack_codebook(cb.cuda())
+    combos = [(0, 0)] + [(rt, sp) for rt in (1, 2, 4) for sp in (0, 1, 7, 64)]
+    if n > 32768:                                         # keep the big sizes to the variants that differ in code path
+        combos = [(0, 0), (1, 0), (2, 7), (4, 64), (4, 1)]
+    for rt, sp in combos:
+        ids, best = ops.vq_encode(zc, pk, packed=True, return_best=True, rt=rt, split=sp)
+        torch.cuda.synchronize()
+        assert np.array_equal(ids.cpu().numpy(), ids_ref), f"ids differ at N={n} rt={rt} split={sp}"
+        assert np.array_equal(best.cpu().numpy().view(np.uint32), best_ref.view(np.uint32)), f"top-1 score bits differ at N={n} rt={rt} split={sp}"
+    ids_v = ops.vq_encode(zc, cb.cuda())                  # the generic VALU kernel on the same rows
+    assert np.array_equal(ids_v.cpu().numpy(), ids_ref)
+
+
 def test_code_gather_ln(cb):
     ids = torch.from_numpy(synth.synthetic_token_ids(3, 512)).cuda()
     cbc = cb.cuda()
@@ -114,6 +148,14 @@ def test_code_gather_ln(cb):
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
     plain = ops.code_gather_ln(ids.int(), cbc)
     assert torch.equal(plain.cpu(), cb[ids.cpu()])
+    # every integer wire format reads the same codes (a uint16 / int16 buffer must not be read as int64)
+    for dt in (torch.int16, torch.uint8, torch.int64):
+        small = (ids % 200).to(dt) if dt != torch.int64 else ids % 200
+        assert torch.equal(ops.code_gather_ln(small, cbc).cpu(), cb[(ids % 200).cpu()])
+    u16 = torch.from_numpy((ids.cpu().numpy() % 32768).astype(np.uint16)).cuda()
+    assert torch.equal(ops.code_gather_ln(u16, cbc).cpu(), cb[ids.cpu()])
+    with pytest.raises(TypeError):
+        ops.code_gather_ln(ids.float(), cbc)
 
 
 def test_vq_empty_and_bad_arguments(cb):

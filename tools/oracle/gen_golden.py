@@ -1,7 +1,7 @@
 """Generate tests/golden/*.npz by running the REFERENCE (read-only import, build container only) on the
 hash-generated synthetic weights/inputs, and report how oracle/ compares on the same inputs.
 
-    python tools/oracle/gen_golden.py [stage ...]      stages: keys vq schedule encoder dit vae pipeline renderer
+    python tools/oracle/gen_golden.py [stage ...]      stages: keys vq schedule encoder dit vae pipeline renderer cfg k1024
 
 A golden file holds only data: inputs that cannot be regenerated from a seed, and the reference's
 outputs.  Weights/images/noise are regenerated from selftoktokenizer_amd.synth by name/seed.
@@ -114,6 +114,7 @@ def stage_vq():
 
 
 def stage_schedule():
+    H.install()                      # stand-alone run: make sure `mimogpt` resolves to the reference, not to the repo's shim
     from mimogpt.models.selftok.sd3.rectified_flow import RectifiedFlow
     from mimogpt.models.selftok.diti_utils import DiTi_cont
     out = {}
@@ -306,13 +307,101 @@ def stage_renderer():
     np.savez_compressed(os.path.join(GOLD, "renderer_b1.npz"), ids=ids.numpy(), latent=out.numpy())
 
 
+def _ref_flow(steps=50):
+    H.install()
+    from mimogpt.models.selftok.sd3.rectified_flow import RectifiedFlow
+    return RectifiedFlow(steps, 1.0, None, val_schedule="uniform", shift=1.0, schedule="log_norm",
+                         parameterization="velocity", m=0.0, s=1.0, force_recon=False, is_eval=True)
+
+
+def stage_cfg():
+    """classifier-free guidance exactly as the reference's sampler runs it (sd3/rectified_flow.py:258-294 calling
+    MMDiT.cfg_inference sd3/mmdit.py:1117-1163): two sampler steps at uncond_scale = 2 from the first schedule entries, plus the
+    unconditional / conditional velocities alone at a mid-schedule entry (k = 375)."""
+    cfg, model, sd = tokenizer(CFG_256)
+    flow = _ref_flow()
+    diti = model.diti if hasattr(model, "diti") else None
+    from mimogpt.models.selftok.diti_utils import DiTi_cont
+    diti = DiTi_cont(1000, 512, cfg.tokenizer.params.stages, cfg.tokenizer.params.k_per_stage)
+    ids = torch.from_numpy(synth.synthetic_token_ids(1, first_index=11))
+    with torch.no_grad():
+        codes = model.encoder.quantizer.get_output_from_indices(ids)
+        ehs = model.encoder.final_layer_norm3(codes.reshape(1, -1, 16))
+    x = synth.synthetic_noise(1, first_index=11)
+    stg, kps = OS.parse_stages(cfg.tokenizer.params.stages, cfg.tokenizer.params.k_per_stage)
+    sch = OS.make_schedule(50)
+    tables = OM.dit_ctx_tables(sd, 512)
+    out = {"ids": ids.numpy(), "scale": np.float32(2.0)}
+    xr, xo = x.clone(), x.clone()
+    for i in (0, 1):
+        t = torch.tensor([flow.scheduled_t[i]] * 1)
+        k = diti.to_indices(torch.tensor([flow.timestep_map[i]]).long())
+        mask = model.encoder.get_encoder_mask(x, k)
+        kw = dict(encoder_hidden_states=ehs, mask=mask, context_see_xt=True)
+        with torch.no_grad():
+            xr, _ = flow.sample_one_step(model.model, xr, t, index=i, model_kwargs=kw, cfg_scale=2.0)
+        xo = OM.sample_one_step(sd, xo, i, ehs, mask, sch, tables, cfg_scale=2.0)
+        report(f"cfg_step{i}", lat_maxdiff=maxdiff(xr, xo), k=int(k[0]))
+        out[f"lat_after_{i + 1}"] = xr.numpy()
+    i = 30
+    t = torch.tensor([flow.scheduled_t[i]])
+    k = diti.to_indices(torch.tensor([flow.timestep_map[i]]).long())
+    mask = model.encoder.get_encoder_mask(x, k)
+    with torch.no_grad():
+        vu = model.model.cfg_inference(x, t, None, None, mask=torch.zeros(mask.size(), dtype=torch.int), shape=512)
+        vc, _ = model.model(x, t, None, ehs, mask=mask, shape=512)
+    vu_o = OM.cfg_uncond_forward(sd, x, t, 512, tables)
+    vc_o = OM.dit_forward(sd, x, t, ehs, mask, False, tables)
+    report("cfg_velocities", uncond_maxdiff=maxdiff(vu, vu_o), cond_maxdiff=maxdiff(vc, vc_o), k=int(k[0]), index=i)
+    out.update(v_uncond=vu.numpy(), v_cond=vc.numpy(), index=np.int64(i), k=np.int64(int(k[0])))
+    np.savez_compressed(os.path.join(GOLD, "cfg_b1.npz"), **out)
+
+
+def stage_k1024():
+    """BASELINE configs[2]: the reference's own ImageTokenizer built with k = 1024 (query_tokens / context_pos_embed grow, stage
+    split ASSUMED 384,368,144,96,32 -- the reference ships no 1024 config): encoder features + ids, and one MMDiT.forward."""
+    cfg = H.load_cfg(CFG_256)
+    cfg.tokenizer.params.k = 1024
+    cfg.tokenizer.params.k_per_stage = "384,368,144,96,32"
+    t0 = time.time()
+    model, ref_sd = H.build_tokenizer(cfg)
+    sd = dict(model.state_dict())
+    print(f"[ref] built k=1024 tokenizer in {time.time() - t0:.1f}s", flush=True)
+    mine = W.expected_shapes(1024)
+    ref_nd = {k: tuple(v.shape) for k, v in sd.items() if not k.startswith("diffusion.")}
+    assert set(ref_nd) == set(mine) and all(tuple(mine[k]) == ref_nd[k] for k in mine)
+    x0 = synth.synthetic_latents(1, first_index=5)
+    cap = {}
+    hk = model.encoder.quantizer.project_in.register_forward_hook(lambda m, i, o: cap.__setitem__("z", o.detach().clone()))
+    with torch.no_grad():
+        outs_q, ids = model.encoder(x0, d=None)
+    hk.remove()
+    z_o = OM.encoder_features(sd, x0)
+    ids_o = OM.vq_ids(sd, z_o)
+    report("k1024_encoder", z_maxdiff=maxdiff(z_o, cap["z"]), ids_match=float((ids_o == ids).float().mean()))
+    cb = sd["encoder.quantizer._codebook.embed"][0]
+    xn = torch.nn.functional.normalize(cap["z"].reshape(-1, 16), dim=-1)
+    top2 = (xn @ cb.T).topk(2, dim=-1).values
+    gap = (top2[:, 0] - top2[:, 1]).reshape(1, 1024)
+    x = synth.synthetic_noise(1, first_index=5)
+    tval, k = 0.62, 750
+    t = torch.full((1,), tval)
+    mask = torch.arange(1024)[None] <= k
+    with torch.no_grad():
+        v, _ = model.model(x, t, encoder_hidden_states=outs_q, mask=mask, context_see_xt=True)
+    v_o = OM.dit_forward(sd, x, t, outs_q, mask, True)
+    report("k1024_dit", v_maxdiff=maxdiff(v, v_o), v_absmax=float(v.abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "k1024_b1.npz"), z=cap["z"].numpy(), ids=ids.numpy(), gap=gap.numpy(), outs_q=outs_q.numpy(),
+                        v=v.numpy(), t=np.float32(tval), k=np.int64(k))
+
+
 STAGES = dict(keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
-              vae=stage_vae, pipeline=stage_pipeline, renderer=stage_renderer)
+              vae=stage_vae, pipeline=stage_pipeline, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024)
 
 if __name__ == "__main__":
     torch.set_grad_enabled(False)
     os.makedirs(GOLD, exist_ok=True)
-    names = sys.argv[1:] or ["vq", "schedule", "encoder", "dit", "vae", "pipeline", "keys", "renderer"]
+    names = sys.argv[1:] or ["vq", "schedule", "encoder", "dit", "vae", "pipeline", "keys", "renderer", "cfg", "k1024"]
     for n in names:
         t0 = time.time()
         STAGES[n]()
