@@ -137,6 +137,7 @@ int selftok_linear_f16x2_f32(const float* A, long lda, const void* packed, const
  * Row r of a segment: ptr + b*bs + r*rs + head*head_dim.  seg[0] keys j visible iff j <= kvis[b] (kvis NULL: all);
  * seg[1] keys visible to seg[1] rows, and to seg[0] rows iff seg0_sees_seg1.  q==NULL: keys/values only.
  * seg[0] rows beyond kvis[b] are dead in the reference and are not written. */
+#define SELFTOK_ATTN_F16X2 1
 typedef struct selftok_attn_seg {
     const float* q; const float* k; const float* v; float* o;
     int len;
@@ -149,6 +150,9 @@ typedef struct selftok_attn_desc {
     const int* kvis;
     int seg0_sees_seg1;
     float scale;
+    int mode;            /* 0: fp32-input MFMA (exact fp32 products); SELFTOK_ATTN_F16X2: both contractions as f16x2-split
+                            products on the f16 matrix cores (head_dim 64 only; see selftok_linear_f16x2_f32) */
+    int* overflow;       /* f16x2 mode: device int, bit 2 is OR-ed if |q|, |k| or |v| >= 65504 (result invalid); may be NULL */
 } selftok_attn_desc;
 int selftok_attn_f32(const selftok_attn_desc* desc, hipStream_t stream);
 

@@ -53,7 +53,7 @@ class AttnSeg(C.Structure):
 
 class AttnDesc(C.Structure):
     _fields_ = [("seg", AttnSeg * 2), ("B", _i), ("H", _i), ("head_dim", _i), ("kvis", _vp),
-                ("seg0_sees_seg1", _i), ("scale", _f)]
+                ("seg0_sees_seg1", _i), ("scale", _f), ("mode", _i), ("overflow", _vp)]
 
 _lib = None
 

@@ -237,6 +237,263 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
 }
 
 // ---------------------------------------------------------------------------------------
+// attn64_f16x2_kernel: the same attention with both contractions on the f16 matrix cores ("f16x2 split", see
+// gemm_split.hip): every fp32 operand x is split into x0 = fp16(x) and x1 = fp16(x - x0) and a product keeps the three
+// terms x0 y0 + x0 y1 + x1 y0 (exact fp16 products, fp32 accumulate).  S^T = K Q^T and O^T = V^T P^T then cost 12 + 12
+// v_mfma_f32_32x32x16_f16 per 32-key tile (768 matrix-pipe cycles) instead of 64 fp32-input MFMAs (4096 cycles that also
+// occupy the fp32 VALU lanes), and the softmax VALU work runs beside them on its own pipe.  The residual parts are NOT
+// rescaled here (one accumulator per product): an operand below 2^-14 * 2^11 of... loses nothing that matters -- its
+// absolute error is bounded by the fp16 subnormal spacing 6e-8 against O(1) rows -- and probabilities are in [0, 1].
+// |q|, |k|, |v| >= 65504 cannot be represented: *overflow gets bit 2 and the caller recomputes with attn64_kernel.
+//
+// LDS images are MFMA-fragment ordered, 16 B (8 halfs) per lane and plane:
+//   K  : [plane][d-group g = d/8 (8)][key (32)]           A operand of S^T = K Q^T   (rows = keys,  k = d)
+//   V^T: [plane][key-group (4)][d' (64)]                  A operand of O^T = V^T P^T (rows = d',    k = keys)
+// The key order inside a V^T entry is the order in which a lane holds its 16 probabilities (accumulator register r <->
+// key (r&3) + 8 (r>>2) + 4 half), so P^T goes from the softmax registers straight into the B operand; d' = (d&3)*16 + d/4
+// makes the transposing ds_write_b64 of the staging pass bank-conflict free and still lets the epilogue store float4s.
+// ---------------------------------------------------------------------------------------
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int KG_STRIDE = 32 * 16 + 16;          // bytes between d-groups of the K image (padded: conflict-free b128 staging writes)
+constexpr int K_PLANE = 8 * KG_STRIDE;           // 4224
+constexpr int V_PLANE = 4 * 64 * 16;             // 4096
+constexpr int KV_BUF = 2 * K_PLANE + 2 * V_PLANE;   // 16640 bytes per staged tile
+
+__device__ __forceinline__ void split_pair(float a, float b, h16x2& hi, h16x2& lo, float& mx)
+{
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    hi[0] = ha; hi[1] = hb;
+    lo[0] = (_Float16)(a - (float)ha);
+    lo[1] = (_Float16)(b - (float)hb);
+    mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));
+}
+
+__global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int* __restrict__ overflow)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_kv[2 * KV_BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    int qt, h, b;
+    {
+        const int T = gridDim.x, orig = blockIdx.x;
+        const int q8 = T >> 3, r8 = T & 7, xcd = orig & 7, idx = orig >> 3;
+        const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        qt = w % P.qtiles;
+        h = (w / P.qtiles) % P.H;
+        b = w / (P.qtiles * P.H);
+    }
+    int n0 = P.seg[0].len;
+    if (P.kvis) { int kv = P.kvis[b] + 1; n0 = kv < n0 ? (kv < 0 ? 0 : kv) : n0; }
+    const int rows0 = P.seg[0].q ? n0 : 0;
+    int s, r0;
+    {
+        const int t0 = P.seg[0].q ? (P.seg[0].len + QROWS - 1) / QROWS : 0;
+        if (qt < t0) { s = 0; r0 = qt * QROWS; }
+        else { s = 1; r0 = (qt - t0) * QROWS; }
+    }
+    const int rows_live = (s == 0) ? rows0 : (P.seg[1].q ? P.seg[1].len : 0);
+    if (r0 >= rows_live) return;
+    const AttnSeg& qs = P.seg[s];
+    const int n1 = (s == 1 || P.seg0_sees_seg1) ? P.seg[1].len : 0;
+
+    float mxabs = 0.f;
+    // ---- Q fragments (B operand of S^T = K Q^T): lane (half, col) holds Q[row col][d = 16 ks + 8 half + j] ----
+    const int my_row = r0 + wave * 32 + col;
+    const bool row_ok = my_row < rows_live;
+    h16x8 q0[4], q1[4];
+    {
+        const float* qp = qs.q + (size_t)b * qs.q_bs + (size_t)(row_ok ? my_row : (rows_live - 1)) * qs.q_rs + h * 64 + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float4 a = *reinterpret_cast<const float4*>(qp + 16 * ks);
+            const float4 c4 = *reinterpret_cast<const float4*>(qp + 16 * ks + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h16x2 hi, lo;
+                split_pair(v[2 * j], v[2 * j + 1], hi, lo, mxabs);
+                q0[ks][2 * j] = hi[0]; q0[ks][2 * j + 1] = hi[1];
+                q1[ks][2 * j] = lo[0]; q1[ks][2 * j + 1] = lo[1];
+            }
+        }
+    }
+
+    f32x16 o0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 o1 = o0;
+    const float c = P.scale * 1.4426950408889634f;   // scores are tracked in the log2 domain
+    float m_run = -__builtin_inff(), l_run = 0.f;
+
+    // ---- staging: threads 0..127 own the K tile (key = t>>2, 16 d each), threads 128..255 the V tile (4 keys x 4 d each) ----
+    const bool is_k = tid < 128;
+    const int u = tid & 127;
+    const int st_key = is_k ? (u >> 2) : 4 * (u >> 4);       // first key this thread loads
+    const int st_d = is_k ? 16 * (u & 3) : 4 * (u & 15);     // first d
+    float4 rg[4];
+    const float* sp = nullptr;
+    long s_step = 0, s_row = 0;
+    auto set_segment = [&](int seg) {
+        const AttnSeg& ks = P.seg[seg];
+        if (is_k) { sp = ks.k + (size_t)b * ks.k_bs + (size_t)st_key * ks.k_rs + h * 64 + st_d; s_step = (long)KT * ks.k_rs; s_row = 0; }
+        else { sp = ks.v + (size_t)b * ks.v_bs + (size_t)st_key * ks.v_rs + h * 64 + st_d; s_step = (long)KT * ks.v_rs; s_row = ks.v_rs; }
+    };
+    auto issue_loads = [&](int key0, int nkeys) {
+        if (is_k) {
+            const bool ok = key0 + st_key < nkeys;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rg[i] = ok ? *reinterpret_cast<const float4*>(sp + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rg[i] = (key0 + st_key + i < nkeys) ? *reinterpret_cast<const float4*>(sp + i * s_row) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        sp += s_step;
+    };
+    auto write_tile = [&](int buf) {
+        unsigned char* base = s_kv + buf * KV_BUF;
+        if (is_k) {   // 16 consecutive d of one key -> two 8-half entries per plane
+            const float v[16] = {rg[0].x, rg[0].y, rg[0].z, rg[0].w, rg[1].x, rg[1].y, rg[1].z, rg[1].w,
+                                 rg[2].x, rg[2].y, rg[2].z, rg[2].w, rg[3].x, rg[3].y, rg[3].z, rg[3].w};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                h16x8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h16x2 a, bb;
+                    split_pair(v[8 * e + 2 * j], v[8 * e + 2 * j + 1], a, bb, mxabs);
+                    hi[2 * j] = a[0]; hi[2 * j + 1] = a[1];
+                    lo[2 * j] = bb[0]; lo[2 * j + 1] = bb[1];
+                }
+                const int g = (st_d >> 3) + e;
+                *reinterpret_cast<h16x8*>(base + g * KG_STRIDE + st_key * 16) = hi;
+                *reinterpret_cast<h16x8*>(base + K_PLANE + g * KG_STRIDE + st_key * 16) = lo;
+            }
+        } else {      // 4 keys x 4 d block, transposed: per d one run of 4 consecutive keys
+            const float v[4][4] = {{rg[0].x, rg[0].y, rg[0].z, rg[0].w}, {rg[1].x, rg[1].y, rg[1].z, rg[1].w},
+                                   {rg[2].x, rg[2].y, rg[2].z, rg[2].w}, {rg[3].x, rg[3].y, rg[3].z, rg[3].w}};
+            // key run k0..k0+3 (k0 = st_key, multiple of 4) sits in key-group (k0>>4)*2 + ((k0>>2)&1), half-entry (k0>>3)&1
+            const int kg = ((st_key >> 4) << 1) + ((st_key >> 2) & 1), hb = (st_key >> 3) & 1;
+            unsigned char* vb = base + 2 * K_PLANE + kg * (64 * 16) + hb * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {              // d = st_d + i  ->  d' = (d&3)*16 + d/4 = i*16 + st_d/4
+                h16x4 hi, lo;
+                h16x2 a, bb;
+                split_pair(v[0][i], v[1][i], a, bb, mxabs);
+                hi[0] = a[0]; hi[1] = a[1]; lo[0] = bb[0]; lo[1] = bb[1];
+                split_pair(v[2][i], v[3][i], a, bb, mxabs);
+                hi[2] = a[0]; hi[3] = a[1]; lo[2] = bb[0]; lo[3] = bb[1];
+                const int dp = i * 16 + (st_d >> 2);
+                *reinterpret_cast<h16x4*>(vb + dp * 16) = hi;
+                *reinterpret_cast<h16x4*>(vb + V_PLANE + dp * 16) = lo;
+            }
+        }
+    };
+
+    const int nt0 = (n0 + KT - 1) / KT, nt1 = (n1 + KT - 1) / KT;
+    const int ntiles = nt0 + nt1;
+    if (ntiles == 0) return;
+    set_segment(nt0 > 0 ? 0 : 1);
+    issue_loads(0, nt0 > 0 ? n0 : n1);
+    write_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int seg = t < nt0 ? 0 : 1;
+        const int key0 = (seg == 0 ? t : t - nt0) * KT;
+        const int nkeys = seg == 0 ? n0 : n1;
+        const unsigned char* sb = s_kv + (t & 1) * KV_BUF;
+        if (t + 1 < ntiles) {
+            const int seg_n = (t + 1) < nt0 ? 0 : 1;
+            if (t + 1 == nt0) set_segment(1);
+            issue_loads((seg_n == 0 ? t + 1 : t + 1 - nt0) * KT, seg_n == 0 ? n0 : n1);
+        }
+
+        // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]: 4 k-steps of 16 d, three f16 MFMAs each ----
+        f32x16 sc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const h16x8 k0 = *reinterpret_cast<const h16x8*>(sb + (2 * ks + half) * KG_STRIDE + col * 16);
+            const h16x8 k1 = *reinterpret_cast<const h16x8*>(sb + K_PLANE + (2 * ks + half) * KG_STRIDE + col * 16);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q0[ks], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q1[ks], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, q0[ks], sc, 0, 0, 0);
+        }
+        // sc[r] = S[q = col][key = key0 + (r&3) + 8*(r>>2) + 4*half]
+        if (key0 + KT > nkeys) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= nkeys) sc[r] = -__builtin_inff();
+        }
+        float mx;
+        {
+            float m0 = fmaxf(fmaxf(sc[0], sc[1]), sc[2]), m1 = fmaxf(fmaxf(sc[3], sc[4]), sc[5]);
+            float m2 = fmaxf(fmaxf(sc[6], sc[7]), sc[8]), m3 = fmaxf(fmaxf(sc[9], sc[10]), sc[11]);
+            float m4 = fmaxf(fmaxf(sc[12], sc[13]), sc[14]);
+            mx = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), sc[15]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+        const float m_new = fmaxf(m_run, mx * c);
+        float psum = 0.f;
+        h16x8 p0[2], p1[2];                                     // P^T fragments: k-step ks2 holds registers 8 ks2 .. 8 ks2 + 7
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float pa = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c, -m_new));
+            const float pb = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r + 1], c, -m_new));
+            psum += pa;
+            psum += pb;
+            const _Float16 ha = (_Float16)pa, hb = (_Float16)pb;
+            p0[r >> 3][r & 7] = ha; p0[r >> 3][(r & 7) + 1] = hb;
+            p1[r >> 3][r & 7] = (_Float16)(pa - (float)ha); p1[r >> 3][(r & 7) + 1] = (_Float16)(pb - (float)hb);
+        }
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            m_run = m_new;
+        }
+        l_run += psum;
+
+        // ---- O^T[d'][q] += sum_key V[key][d'] P[q][key]: 2 k-steps of 16 keys x 2 blocks of 32 d' ----
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            const unsigned char* vb = sb + 2 * K_PLANE + (2 * ks2 + half) * (64 * 16) + col * 16;
+            const h16x8 va0 = *reinterpret_cast<const h16x8*>(vb), va1 = *reinterpret_cast<const h16x8*>(vb + V_PLANE);
+            const h16x8 vb0 = *reinterpret_cast<const h16x8*>(vb + 32 * 16), vb1 = *reinterpret_cast<const h16x8*>(vb + V_PLANE + 32 * 16);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va0, p0[ks2], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb0, p0[ks2], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va0, p1[ks2], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb0, p1[ks2], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va1, p0[ks2], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb1, p0[ks2], o1, 0, 0, 0);
+        }
+        if (t + 1 < ntiles) write_tile((t + 1) & 1);
+        __syncthreads();
+    }
+
+    if (overflow && !(wave_max(mxabs) < 65504.f) && lane == 0) atomicOr(overflow, 4);
+
+    // ---- epilogue: o_db[r] = O[q = col][d' = 32 db + (r&3) + 8 (r>>2) + 4 half],  d = 4 (d' & 15) + (d' >> 4) ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, WAVE);
+    const float inv = 1.0f / l_tot;
+    if (row_ok) {
+        float* op = qs.o + (size_t)b * qs.o_bs + (size_t)my_row * qs.o_rs + h * 64;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                // registers a + 4 bb (+8): d' = a + 8 bb + 4 half (+16)  ->  d = 4 (a + 8 bb + 4 half) + {0, 1} + 2 db
+                const int r = a + 4 * bb;
+                *reinterpret_cast<float4*>(op + 4 * (a + 8 * bb + 4 * half)) =
+                    make_float4(o0[r] * inv, o0[r + 8] * inv, o1[r] * inv, o1[r + 8] * inv);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // head_dim 16 self-attention of the encoder's latent stream (modules.py:235-238): 4 heads x 256 tokens,
 // 4 MFLOP per (sample, head) -- far too small for matrix cores to matter.  One workgroup per
 // (batch, head): K and V of the head sit in LDS, every thread owns one query row and runs the online
@@ -313,6 +570,11 @@ int selftok_attn_f32(const selftok_attn_desc* d, hipStream_t stream)
         if (t0 + t1 == 0) return SELFTOK_OK;
         P.qtiles = t0 + t1;
         P.xcd_remap = 1;
+        if (d->mode == SELFTOK_ATTN_F16X2) {
+            hipLaunchKernelGGL(attn64_f16x2_kernel, dim3((t0 + t1) * d->H * d->B), dim3(256), 0, stream, P, d->overflow);
+            return check_launch("attn64_f16x2_kernel");
+        }
+        if (d->mode != 0) { set_last_error("attn: unknown mode"); return SELFTOK_EINVAL; }
         hipLaunchKernelGGL(attn64_kernel, dim3((t0 + t1) * d->H * d->B), dim3(256), 0, stream, P);
         return check_launch("attn64_kernel");
     }

@@ -272,9 +272,13 @@ def _seg(q, k, v, o):
     return s
 
 
-def attention(seg0, seg1, heads, head_dim, kvis=None, seg0_sees_seg1=True, scale=None):
+ATTN_F16X2 = 1
+
+
+def attention(seg0, seg1, heads, head_dim, kvis=None, seg0_sees_seg1=True, scale=None, mode: int = 0, overflow=None):
     """seg = (q, k, v, o) tuples of [B,L,heads*head_dim] views (q and o None: keys/values only; seg None: empty).
-    Writes into the `o` views.  kvis: int32 [B] or None."""
+    Writes into the `o` views.  kvis: int32 [B] or None.  mode = ATTN_F16X2: f16x2-split matrix products (head_dim 64),
+    `overflow` (int32 [1] device tensor) gets bit 2 if an operand is outside the fp16 range."""
     lib = _lib.load()
     d = _lib.AttnDesc()
     ref = seg1 if seg1 is not None else seg0
@@ -287,6 +291,8 @@ def attention(seg0, seg1, heads, head_dim, kvis=None, seg0_sees_seg1=True, scale
         d.kvis = kvis.data_ptr()
     d.seg0_sees_seg1 = 1 if seg0_sees_seg1 else 0
     d.scale = float(scale if scale is not None else head_dim ** -0.5)
+    d.mode = int(mode) if head_dim == 64 else 0
+    d.overflow = _p(overflow)
     import ctypes
     _lib.check(lib.selftok_attn_f32(ctypes.byref(d), _stream()), "selftok_attn_f32")
 
