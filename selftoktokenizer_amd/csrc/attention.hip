@@ -242,9 +242,11 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
 // terms x0 y0 + x0 y1 + x1 y0 (exact fp16 products, fp32 accumulate).  S^T = K Q^T and O^T = V^T P^T then cost 12 + 12
 // v_mfma_f32_32x32x16_f16 per 32-key tile (768 matrix-pipe cycles) instead of 64 fp32-input MFMAs (4096 cycles that also
 // occupy the fp32 VALU lanes), and the softmax VALU work runs beside them on its own pipe.  The residual parts are NOT
-// rescaled here (one accumulator per product): an operand below 2^-14 * 2^11 of... loses nothing that matters -- its
-// absolute error is bounded by the fp16 subnormal spacing 6e-8 against O(1) rows -- and probabilities are in [0, 1].
-// |q|, |k|, |v| >= 65504 cannot be represented: *overflow gets bit 2 and the caller recomputes with attn64_kernel.
+// rescaled here (one accumulator per product): what a residual below the fp16 normal range loses is bounded in ABSOLUTE terms
+// by the subnormal spacing 6e-8, against rows whose large entries are O(1), and probabilities live in [0, 1].
+// |q|, |k|, |v| >= 65504 cannot be represented: the output turns non-finite, *overflow gets bit 2 and the caller recomputes
+// with attn64_kernel.  Measured against fp64 softmax attention this kernel is slightly MORE accurate than the fp32-MFMA one
+// (tests/test_kernels_gpu.py::test_attention_f16x2_accuracy_gate_and_range_flag).
 //
 // LDS images are MFMA-fragment ordered, 16 B (8 halfs) per lane and plane:
 //   K  : [plane][d-group g = d/8 (8)][key (32)]           A operand of S^T = K Q^T   (rows = keys,  k = d)
@@ -254,22 +256,27 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
 // makes the transposing ds_write_b64 of the staging pass bank-conflict free and still lets the epilogue store float4s.
 // ---------------------------------------------------------------------------------------
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KG_STRIDE = 32 * 16 + 16;          // bytes between d-groups of the K image (padded: conflict-free b128 staging writes)
 constexpr int K_PLANE = 8 * KG_STRIDE;           // 4224
 constexpr int V_PLANE = 4 * 64 * 16;             // 4096
 constexpr int KV_BUF = 2 * K_PLANE + 2 * V_PLANE;   // 16640 bytes per staged tile
 
-__device__ __forceinline__ void split_pair(float a, float b, h16x2& hi, h16x2& lo, float& mx)
+// (a, b) -> packed fp16 pair hi = rne(a, b) and the packed residual lo = rne(a - hi.x, b - hi.y).  Plain C++ on purpose: an
+// inline-asm version around v_fma_mix_f32 (4 ops per pair instead of 6) measured 12 % SLOWER -- every asm statement costs
+// boundary s_nops and v_movs to gather its scalar outputs into the 128-bit MFMA operands.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+struct HiLo { unsigned hi, lo; };
+__device__ __forceinline__ HiLo split_pair(float a, float b)
 {
-    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
-    hi[0] = ha; hi[1] = hb;
-    lo[0] = (_Float16)(a - (float)ha);
-    lo[1] = (_Float16)(b - (float)hb);
-    mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));
+    const h16x2 h = {(_Float16)a, (_Float16)b};
+    const h16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    return HiLo{__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, l)};
 }
+__device__ __forceinline__ h16x8 as_h8(const u32x4& v) { return __builtin_bit_cast(h16x8, v); }
 
 __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int* __restrict__ overflow)
 {
@@ -300,31 +307,26 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
     const AttnSeg& qs = P.seg[s];
     const int n1 = (s == 1 || P.seg0_sees_seg1) ? P.seg[1].len : 0;
 
-    float mxabs = 0.f;
-    // ---- Q fragments (B operand of S^T = K Q^T): lane (half, col) holds Q[row col][d = 16 ks + 8 half + j] ----
+    // ---- Q fragments (B operand of S^T = K Q^T): lane (half, col) holds Q[row col][d = 16 ks + 8 half + j], pre-multiplied
+    // by scale * log2(e) so that the scores come out of the matrix pipe in the log2 domain ----
+    const float c = P.scale * 1.4426950408889634f;
     const int my_row = r0 + wave * 32 + col;
     const bool row_ok = my_row < rows_live;
-    h16x8 q0[4], q1[4];
+    u32x4 q0[4], q1[4];
     {
         const float* qp = qs.q + (size_t)b * qs.q_bs + (size_t)(row_ok ? my_row : (rows_live - 1)) * qs.q_rs + h * 64 + 8 * half;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const float4 a = *reinterpret_cast<const float4*>(qp + 16 * ks);
             const float4 c4 = *reinterpret_cast<const float4*>(qp + 16 * ks + 4);
-            const float v[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+            const float v[8] = {a.x * c, a.y * c, a.z * c, a.w * c, c4.x * c, c4.y * c, c4.z * c, c4.w * c};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                h16x2 hi, lo;
-                split_pair(v[2 * j], v[2 * j + 1], hi, lo, mxabs);
-                q0[ks][2 * j] = hi[0]; q0[ks][2 * j + 1] = hi[1];
-                q1[ks][2 * j] = lo[0]; q1[ks][2 * j + 1] = lo[1];
-            }
+            for (int j = 0; j < 4; ++j) { const HiLo t_ = split_pair(v[2 * j], v[2 * j + 1]); q0[ks][j] = t_.hi; q1[ks][j] = t_.lo; }
         }
     }
 
     f32x16 o0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     f32x16 o1 = o0;
-    const float c = P.scale * 1.4426950408889634f;   // scores are tracked in the log2 domain
     float m_run = -__builtin_inff(), l_run = 0.f;
 
     // ---- staging: threads 0..127 own the K tile (key = t>>2, 16 d each), threads 128..255 the V tile (4 keys x 4 d each) ----
@@ -332,13 +334,15 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
     const int u = tid & 127;
     const int st_key = is_k ? (u >> 2) : 4 * (u >> 4);       // first key this thread loads
     const int st_d = is_k ? 16 * (u & 3) : 4 * (u & 15);     // first d
+    // Keys past the end of a segment are staged as zeros (their scores are masked to -inf, their probabilities are exactly 0).
+    // Measured: clamping the row index instead (no v_cndmask) costs 12 % -- the extra address registers and the branch hurt more.
     float4 rg[4];
-    const float* sp = nullptr;
-    long s_step = 0, s_row = 0;
+    const float* sp = nullptr;         // running pointer: row key0 + st_key of the next tile to load
+    long s_rs = 0;
     auto set_segment = [&](int seg) {
         const AttnSeg& ks = P.seg[seg];
-        if (is_k) { sp = ks.k + (size_t)b * ks.k_bs + (size_t)st_key * ks.k_rs + h * 64 + st_d; s_step = (long)KT * ks.k_rs; s_row = 0; }
-        else { sp = ks.v + (size_t)b * ks.v_bs + (size_t)st_key * ks.v_rs + h * 64 + st_d; s_step = (long)KT * ks.v_rs; s_row = ks.v_rs; }
+        if (is_k) { sp = ks.k + (size_t)b * ks.k_bs + (size_t)st_key * ks.k_rs + h * 64 + st_d; s_rs = ks.k_rs; }
+        else { sp = ks.v + (size_t)b * ks.v_bs + (size_t)st_key * ks.v_rs + h * 64 + st_d; s_rs = ks.v_rs; }
     };
     auto issue_loads = [&](int key0, int nkeys) {
         if (is_k) {
@@ -348,9 +352,9 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                rg[i] = (key0 + st_key + i < nkeys) ? *reinterpret_cast<const float4*>(sp + i * s_row) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rg[i] = (key0 + st_key + i < nkeys) ? *reinterpret_cast<const float4*>(sp + i * s_rs) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        sp += s_step;
+        sp += (long)KT * s_rs;
     };
     auto write_tile = [&](int buf) {
         unsigned char* base = s_kv + buf * KV_BUF;
@@ -359,17 +363,12 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
                                  rg[2].x, rg[2].y, rg[2].z, rg[2].w, rg[3].x, rg[3].y, rg[3].z, rg[3].w};
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                h16x8 hi, lo;
+                u32x4 hi, lo;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    h16x2 a, bb;
-                    split_pair(v[8 * e + 2 * j], v[8 * e + 2 * j + 1], a, bb, mxabs);
-                    hi[2 * j] = a[0]; hi[2 * j + 1] = a[1];
-                    lo[2 * j] = bb[0]; lo[2 * j + 1] = bb[1];
-                }
+                for (int j = 0; j < 4; ++j) { const HiLo t_ = split_pair(v[8 * e + 2 * j], v[8 * e + 2 * j + 1]); hi[j] = t_.hi; lo[j] = t_.lo; }
                 const int g = (st_d >> 3) + e;
-                *reinterpret_cast<h16x8*>(base + g * KG_STRIDE + st_key * 16) = hi;
-                *reinterpret_cast<h16x8*>(base + K_PLANE + g * KG_STRIDE + st_key * 16) = lo;
+                *reinterpret_cast<u32x4*>(base + g * KG_STRIDE + st_key * 16) = hi;
+                *reinterpret_cast<u32x4*>(base + K_PLANE + g * KG_STRIDE + st_key * 16) = lo;
             }
         } else {      // 4 keys x 4 d block, transposed: per d one run of 4 consecutive keys
             const float v[4][4] = {{rg[0].x, rg[0].y, rg[0].z, rg[0].w}, {rg[1].x, rg[1].y, rg[1].z, rg[1].w},
@@ -379,15 +378,12 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
             unsigned char* vb = base + 2 * K_PLANE + kg * (64 * 16) + hb * 8;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {              // d = st_d + i  ->  d' = (d&3)*16 + d/4 = i*16 + st_d/4
-                h16x4 hi, lo;
-                h16x2 a, bb;
-                split_pair(v[0][i], v[1][i], a, bb, mxabs);
-                hi[0] = a[0]; hi[1] = a[1]; lo[0] = bb[0]; lo[1] = bb[1];
-                split_pair(v[2][i], v[3][i], a, bb, mxabs);
-                hi[2] = a[0]; hi[3] = a[1]; lo[2] = bb[0]; lo[3] = bb[1];
+                u32x2 hi, lo;
+                { const HiLo t_ = split_pair(v[0][i], v[1][i]); hi[0] = t_.hi; lo[0] = t_.lo; }
+                { const HiLo t_ = split_pair(v[2][i], v[3][i]); hi[1] = t_.hi; lo[1] = t_.lo; }
                 const int dp = i * 16 + (st_d >> 2);
-                *reinterpret_cast<h16x4*>(vb + dp * 16) = hi;
-                *reinterpret_cast<h16x4*>(vb + V_PLANE + dp * 16) = lo;
+                *reinterpret_cast<u32x2*>(vb + dp * 16) = hi;
+                *reinterpret_cast<u32x2*>(vb + V_PLANE + dp * 16) = lo;
             }
         }
     };
@@ -411,17 +407,17 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
             issue_loads((seg_n == 0 ? t + 1 : t + 1 - nt0) * KT, seg_n == 0 ? n0 : n1);
         }
 
-        // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]: 4 k-steps of 16 d, three f16 MFMAs each ----
+        // ---- S^T[key][q] = sum_d K[key][d] Q'[q][d]: 4 k-steps of 16 d, three f16 MFMAs each ----
         f32x16 sc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const h16x8 k0 = *reinterpret_cast<const h16x8*>(sb + (2 * ks + half) * KG_STRIDE + col * 16);
             const h16x8 k1 = *reinterpret_cast<const h16x8*>(sb + K_PLANE + (2 * ks + half) * KG_STRIDE + col * 16);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q0[ks], sc, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, q1[ks], sc, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, q0[ks], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, as_h8(q0[ks]), sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, as_h8(q1[ks]), sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, as_h8(q0[ks]), sc, 0, 0, 0);
         }
-        // sc[r] = S[q = col][key = key0 + (r&3) + 8*(r>>2) + 4*half]
+        // sc[r] = log2(e) * scale * S[q = col][key = key0 + (r&3) + 8*(r>>2) + 4*half]
         if (key0 + KT > nkeys) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -435,18 +431,16 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
             mx = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), sc[15]));
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
-        const float m_new = fmaxf(m_run, mx * c);
-        float psum = 0.f;
-        h16x8 p0[2], p1[2];                                     // P^T fragments: k-step ks2 holds registers 8 ks2 .. 8 ks2 + 7
+        const float m_new = fmaxf(m_run, mx);
+        const f32x2 mm = {m_new, m_new};
+        f32x2 psum = {0.f, 0.f};
+        u32x4 p0[2], p1[2];                                     // P^T fragments: k-step ks2 holds registers 8 ks2 .. 8 ks2 + 7
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            const float pa = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c, -m_new));
-            const float pb = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r + 1], c, -m_new));
-            psum += pa;
-            psum += pb;
-            const _Float16 ha = (_Float16)pa, hb = (_Float16)pb;
-            p0[r >> 3][r & 7] = ha; p0[r >> 3][(r & 7) + 1] = hb;
-            p1[r >> 3][r & 7] = (_Float16)(pa - (float)ha); p1[r >> 3][(r & 7) + 1] = (_Float16)(pb - (float)hb);
+            const f32x2 a = f32x2{sc[r], sc[r + 1]} - mm;        // v_pk_add_f32
+            const f32x2 p = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+            psum += p;                                           // v_pk_add_f32
+            { const HiLo t_ = split_pair(p[0], p[1]); p0[r >> 3][(r & 7) >> 1] = t_.hi; p1[r >> 3][(r & 7) >> 1] = t_.lo; }
         }
         if (__any(m_new != m_run)) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -455,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
             for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
             m_run = m_new;
         }
-        l_run += psum;
+        l_run += psum[0] + psum[1];
 
         // ---- O^T[d'][q] += sum_key V[key][d'] P[q][key]: 2 k-steps of 16 keys x 2 blocks of 32 d' ----
 #pragma unroll
@@ -463,22 +457,26 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
             const unsigned char* vb = sb + 2 * K_PLANE + (2 * ks2 + half) * (64 * 16) + col * 16;
             const h16x8 va0 = *reinterpret_cast<const h16x8*>(vb), va1 = *reinterpret_cast<const h16x8*>(vb + V_PLANE);
             const h16x8 vb0 = *reinterpret_cast<const h16x8*>(vb + 32 * 16), vb1 = *reinterpret_cast<const h16x8*>(vb + V_PLANE + 32 * 16);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va0, p0[ks2], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb0, p0[ks2], o1, 0, 0, 0);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va0, p1[ks2], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb0, p1[ks2], o1, 0, 0, 0);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va1, p0[ks2], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb1, p0[ks2], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va0, as_h8(p0[ks2]), o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb0, as_h8(p0[ks2]), o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va0, as_h8(p1[ks2]), o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb0, as_h8(p1[ks2]), o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va1, as_h8(p0[ks2]), o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vb1, as_h8(p0[ks2]), o1, 0, 0, 0);
         }
         if (t + 1 < ntiles) write_tile((t + 1) & 1);
         __syncthreads();
     }
 
-    if (overflow && !(wave_max(mxabs) < 65504.f) && lane == 0) atomicOr(overflow, 4);
-
     // ---- epilogue: o_db[r] = O[q = col][d' = 32 db + (r&3) + 8 (r>>2) + 4 half],  d = 4 (d' & 15) + (d' >> 4) ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, WAVE);
     const float inv = 1.0f / l_tot;
+    // an operand beyond the fp16 range became inf in its high part: it shows up as a non-finite output (0 * inf = NaN below).
+    // Non-finite INPUTS also land here; the caller's fp32 recomputation then reproduces their NaN/inf honestly.
+    float chk = l_tot * 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { chk = __builtin_fmaf(o0[r], 0.f, chk); chk = __builtin_fmaf(o1[r], 0.f, chk); }
+    if (overflow && row_ok && chk != 0.f) atomicOr(overflow, 4);
     if (row_ok) {
         float* op = qs.o + (size_t)b * qs.o_bs + (size_t)my_row * qs.o_rs + h * 64;
 #pragma unroll

@@ -60,10 +60,12 @@ class MMDiTGPU:
 
     # ---- GEMM arithmetic of the block Linears ---------------------------------------------------
     def set_gemm(self, mode: str) -> str:
-        """'fp32': hipBLASLt fp32 GEMMs (PyTorch-ROCm).  'f16x2': the qkv / proj / fc1 / fc2 Linears of the 24 joint blocks
-        (99.6 % of the decode FLOPs) run on ops.linear_f16x2 -- fp32-equivalent split arithmetic on the f16 matrix cores,
-        more accurate than the fp32 library GEMM (tests/test_gemm_gpu.py).  Weights are split once, here.  If a weight is
-        outside the fp16 range the mode stays 'fp32'.  Returns the mode in force."""
+        """'fp32': hipBLASLt fp32 GEMMs (PyTorch-ROCm) + the fp32-input-MFMA attention kernel.  'f16x2': the qkv / proj / fc1 / fc2
+        Linears of the 24 joint blocks (99.6 % of the decode FLOPs) run on ops.linear_f16x2 and the joint attention on
+        attn64_f16x2_kernel -- fp32-equivalent split arithmetic on the f16 matrix cores, measured MORE accurate against fp64 than the
+        fp32 kernels they replace (tests/test_gemm_gpu.py, tests/test_kernels_gpu.py).  Weights are split once, here.  If a weight
+        is outside the fp16 range the mode stays 'fp32'; activations outside it raise `self.overflow` (checked once per decode
+        call by the pipeline, which then recomputes in 'fp32').  Returns the mode in force."""
         if mode not in self.GEMM_MODES:
             raise ValueError(f"gemm mode {mode!r}: expected one of {self.GEMM_MODES}")
         if mode == "f16x2" and not self._packed:
@@ -131,6 +133,7 @@ class MMDiTGPU:
         B, nx, _ = xe.shape
         n = 0 if ctx is None else ctx.shape[1]
         has_ctx = n > 0
+        amode = ops.ATTN_F16X2 if self.gemm == "f16x2" else 0   # 'f16x2': the joint attention runs as split products too
         sc = ops.silu(c)                                     # every adaLN_modulation starts with SiLU(c)
         mods_x = [self.lin(f"model.joint_blocks.{i}.x_block.adaLN_modulation.1", sc) for i in range(DIT_DEPTH)]   # [B,6H]
         mods_c_last = self.lin(f"model.joint_blocks.{DIT_DEPTH - 1}.context_block.adaLN_modulation.1", sc) if has_ctx else None  # [B,2H]
@@ -154,9 +157,9 @@ class MMDiTGPU:
                 else:
                     oc = (torch.zeros if kvis is not None else torch.empty)(B, n, H, device=x.device)
                     seg0 = (cqkv[..., :H], cqkv[..., H:2 * H], cqkv[..., 2 * H:], oc)
-                ops.attention(seg0, seg1, NH, 64, kvis=kvis, seg0_sees_seg1=seg0_sees_seg1)
+                ops.attention(seg0, seg1, NH, 64, kvis=kvis, seg0_sees_seg1=seg0_sees_seg1, mode=amode, overflow=self.overflow)
             else:
-                ops.attention(None, seg1, NH, 64)
+                ops.attention(None, seg1, NH, 64, mode=amode, overflow=self.overflow)
             # ---- context stream post-attention (sd3/mmdit.py:485-496, 'pos_emb') ----
             if has_ctx and not last:
                 t = tab[i]

@@ -116,9 +116,13 @@ def _ref_joint_attention(ctx_qkv, x_qkv, H, kvis, see):
     return a.transpose(1, 2).reshape(B, S, H * 64)
 
 
+ATTN_MODES = [0, ops.ATTN_F16X2]      # fp32-input MFMA kernel / f16x2-split kernel (csrc/attention.hip)
+
+
+@pytest.mark.parametrize("mode", ATTN_MODES)
 @pytest.mark.parametrize("see", [True, False])
 @pytest.mark.parametrize("kv", [None, [511, 19], [300, 0]])
-def test_joint_attention_vs_masked_sdpa(see, kv):
+def test_joint_attention_vs_masked_sdpa(see, kv, mode):
     B, H, Kc, nx = 2, 3, 512, 256
     ctx = U(20, (B, Kc, 3 * H * 64), -1.5, 1.5)
     xs = U(21, (B, nx, 3 * H * 64), -1.5, 1.5)
@@ -129,7 +133,7 @@ def test_joint_attention_vs_masked_sdpa(see, kv):
     o_c = torch.zeros(B, Kc, D, device="cuda")
     o_x = torch.zeros(B, nx, D, device="cuda")
     ops.attention((cc[..., :D], cc[..., D:2 * D], cc[..., 2 * D:], o_c), (xc[..., :D], xc[..., D:2 * D], xc[..., 2 * D:], o_x),
-                  H, 64, kvis=None if kvis is None else kvis.int().cuda(), seg0_sees_seg1=see)
+                  H, 64, kvis=None if kvis is None else kvis.int().cuda(), seg0_sees_seg1=see, mode=mode)
     torch.testing.assert_close(o_x.cpu(), ref[:, Kc:], rtol=2e-5, atol=2e-5)
     for b in range(B):
         live = Kc if kvis is None else int(kvis[b]) + 1
@@ -137,7 +141,8 @@ def test_joint_attention_vs_masked_sdpa(see, kv):
         assert torch.count_nonzero(o_c[b, live:]) == 0     # dead context rows are not written
 
 
-def test_encoder_query_attention():
+@pytest.mark.parametrize("mode", ATTN_MODES)
+def test_encoder_query_attention(mode):
     """queries attend to cat(to_query_kv(x), query_kv): 8 heads x 64, no mask (modules.py:255-266)"""
     B, N, K, H = 2, 256, 512, 8
     kv = U(22, (B, N, 2 * H * 64), -1.5, 1.5)
@@ -149,11 +154,12 @@ def test_encoder_query_attention():
     ref = F.scaled_dot_product_attention(hd(qq[..., :D]), hd(k2), hd(v2)).transpose(1, 2).reshape(B, K, D)
     kvc, qc = kv.cuda(), qq.cuda()
     o = torch.empty(B, K, D, device="cuda")
-    ops.attention((None, kvc[..., :D], kvc[..., D:], None), (qc[..., :D], qc[..., D:2 * D], qc[..., 2 * D:], o), H, 64)
+    ops.attention((None, kvc[..., :D], kvc[..., D:], None), (qc[..., :D], qc[..., D:2 * D], qc[..., 2 * D:], o), H, 64, mode=mode)
     torch.testing.assert_close(o.cpu(), ref, rtol=2e-5, atol=2e-5)
 
 
-def test_attention_ragged_lengths():
+@pytest.mark.parametrize("mode", ATTN_MODES)
+def test_attention_ragged_lengths(mode):
     """K = 1024-token tokenizer length and a non-multiple-of-32 segment"""
     B, H = 1, 2
     for Kc, nx in ((1024, 256), (77, 45)):
@@ -162,8 +168,39 @@ def test_attention_ragged_lengths():
         cc, xc = ctx.cuda(), xs.cuda()
         D = H * 64
         o_c, o_x = torch.empty(B, Kc, D, device="cuda"), torch.empty(B, nx, D, device="cuda")
-        ops.attention((cc[..., :D], cc[..., D:2 * D], cc[..., 2 * D:], o_c), (xc[..., :D], xc[..., D:2 * D], xc[..., 2 * D:], o_x), H, 64)
+        ops.attention((cc[..., :D], cc[..., D:2 * D], cc[..., 2 * D:], o_c), (xc[..., :D], xc[..., D:2 * D], xc[..., 2 * D:], o_x), H, 64, mode=mode)
         torch.testing.assert_close(torch.cat([o_c, o_x], 1).cpu(), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_attention_f16x2_accuracy_gate_and_range_flag():
+    """the f16x2-split attention may stand in for the fp32-MFMA kernel only if it is as close to the exact (fp64) softmax
+    attention; operands beyond the fp16 range must raise the flag (bit 2), ordinary ones must not"""
+    B, H, Kc, nx = 2, 4, 358, 256
+    D = H * 64
+    g = torch.Generator().manual_seed(7)
+    ctx = torch.randn(B, Kc, 3 * D, generator=g) * 1.5
+    xs = torch.randn(B, nx, 3 * D, generator=g) * 1.5
+    qkv = torch.cat([ctx, xs], 1).double()
+    q, k, v = qkv.reshape(B, Kc + nx, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, Kc + nx, D)
+    cc, xc = ctx.cuda(), xs.cuda()
+    errs = {}
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for mode in ATTN_MODES:
+        o_c, o_x = torch.empty(B, Kc, D, device="cuda"), torch.empty(B, nx, D, device="cuda")
+        ops.attention((cc[..., :D], cc[..., D:2 * D], cc[..., 2 * D:], o_c), (xc[..., :D], xc[..., D:2 * D], xc[..., 2 * D:], o_x), H, 64,
+                      mode=mode, overflow=flag)
+        e = torch.cat([o_c, o_x], 1).cpu().double() - ref
+        errs[mode] = (float(e.abs().max()), float(e.pow(2).mean().sqrt()))
+    print("attention error vs fp64 (max, rms): fp32-MFMA", errs[0], " f16x2", errs[ops.ATTN_F16X2])
+    assert int(flag.item()) == 0
+    assert errs[ops.ATTN_F16X2][1] <= 2.0 * errs[0][1] + 1e-8 and errs[ops.ATTN_F16X2][0] <= 4.0 * errs[0][0] + 1e-7
+    xc2 = xc.clone()
+    xc2[0, 5, D + 7] = 1.0e5                                   # one key element beyond the fp16 range
+    o_c, o_x = torch.empty(B, Kc, D, device="cuda"), torch.empty(B, nx, D, device="cuda")
+    ops.attention((cc[..., :D], cc[..., D:2 * D], cc[..., 2 * D:], o_c), (xc2[..., :D], xc2[..., D:2 * D], xc2[..., 2 * D:], o_x), H, 64,
+                  mode=ops.ATTN_F16X2, overflow=flag)
+    assert int(flag.item()) & 4
 
 
 def test_attention_head_dim16():
