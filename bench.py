@@ -201,6 +201,11 @@ def kernel_roofs(pipe, B, K, k_table):
     out.append({"kernel": "attn64_kernel", "bound": "mfma(fp32)", "shape": f"B={B} heads=24 S={n}+256", "avg_launch_ms": round(ms, 4),
                 "achieved": round(fl / ms / 1e9, 1), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
                 "launches_per_step": 24 * 50})
+    ms = event_time_ms(lambda: ops.attention(seg0, seg1, NH, 64, mode=ops.ATTN_F16X2))
+    out.append({"kernel": "attn64_f16x2_kernel", "bound": "valu (softmax + operand split beside 24 f16 MFMAs per 32-key tile)",
+                "shape": f"B={B} heads=24 S={n}+256", "avg_launch_ms": round(ms, 4), "achieved": round(3 * fl / ms / 1e9, 1), "peak": F16_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s (f16 MFMA: 3 per fp32 product)", "frac": round(3 * fl / ms / 1e9 / F16_MFMA_PEAK_TFLOPS, 4),
+                "fp32_equivalent_TFLOPs": round(fl / ms / 1e9, 1), "launches_per_step": 24 * 50})
     # fused residual + LayerNorm + modulate on the context stream
     x, y = torch.randn(B, n, H, device=dev), torch.randn(B, n, H, device=dev)
     tab = torch.randn(n, 6 * H, device=dev)
@@ -381,8 +386,8 @@ def main(argv=None):
             "hbm_achieved_GBs": round(alg_bytes / (vq_ms * 1e-3) / 1e9, 2), "hbm_frac": round(alg_bytes / (vq_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
             "note": "N*C*D = %d x 32768 x 16 fp32 FMA chain is ~7.9 kFLOP/B: matrix-core bound, not HBM bound (SURVEY.md 8d)" % n_vq}
     arith = {"fp32": "fp32 Q-Former/VQ/MMDiT (hipBLASLt fp32 GEMMs), bf16 SD3-VAE (reference dtypes)",
-             "f16x2": "fp32 Q-Former/VQ/MMDiT with the MMDiT block Linears on the f16x2-split kernel (fp32-equivalent: error vs fp64 below the "
-                      "fp32 library GEMM's, tests/test_gemm_gpu.py), bf16 SD3-VAE"}
+             "f16x2": "fp32 Q-Former/VQ/MMDiT with the MMDiT block Linears and joint attention as f16x2-split products on the f16 matrix cores "
+                      "(fp32-equivalent: error vs fp64 below the fp32 kernels', tests/test_gemm_gpu.py, test_kernels_gpu.py), bf16 SD3-VAE"}
     line = {
         "metric": "images/sec encode+decode, 256x256 %d-token" % K, "value": round(world * B * args.steps / elapsed, 4),
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

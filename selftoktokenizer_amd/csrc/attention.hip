@@ -258,7 +258,6 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KG_STRIDE = 32 * 16 + 16;          // bytes between d-groups of the K image (padded: conflict-free b128 staging writes)
 constexpr int K_PLANE = 8 * KG_STRIDE;           // 4224
@@ -269,11 +268,13 @@ constexpr int KV_BUF = 2 * K_PLANE + 2 * V_PLANE;   // 16640 bytes per staged ti
 // inline-asm version around v_fma_mix_f32 (4 ops per pair instead of 6) measured 12 % SLOWER -- every asm statement costs
 // boundary s_nops and v_movs to gather its scalar outputs into the 128-bit MFMA operands.
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct HiLo { unsigned hi, lo; };
 __device__ __forceinline__ HiLo split_pair(float a, float b)
 {
-    const h16x2 h = {(_Float16)a, (_Float16)b};
-    const h16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    const f32x2 x = {a, b};
+    const h16x2 h = __builtin_convertvector(x, h16x2);                                             // v_cvt_pk_f16_f32
+    const h16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), h16x2);         // 2 cvt + v_pk_add + v_cvt_pk
     return HiLo{__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, l)};
 }
 __device__ __forceinline__ h16x8 as_h8(const u32x4& v) { return __builtin_bit_cast(h16x8, v); }

@@ -18,8 +18,8 @@
 // load time into the kernel's own tile order (selftok_linear_f16x2_pack_weight), so a weight tile reaches LDS by
 // direct LDS-DMA (global_load_lds, 16 B per lane, no VGPR round trip) as one linear 16 KiB copy.
 //
-// Range: fp16 overflows at 65504.  |activation| >= 65504 raises *overflow (device int, caller-owned, sticky) and the
-// caller redoes the work with the fp32 library GEMM; weights are checked at pack time.  Values below the fp16 normal
+// Range: fp16 overflows at 65504.  An |activation| >= 65504 turns the output non-finite, which raises *overflow (device int,
+// caller-owned, sticky) and the caller redoes the work with the fp32 library GEMM; weights are checked at pack time.  Values below the fp16 normal
 // range are carried by the scaled low part (tests cover 1e-7..1e-3).
 //
 // Tiling: workgroup = 8 waves = 256 (M) x 128 (N) outputs, K step 32, two LDS stages (2 x 48.25 KiB); each wave owns
@@ -64,18 +64,30 @@ __device__ __forceinline__ float gelu_tanh_f(float x)   // same formula as selft
     return 0.5f * x * (1.0f + tanhf(inner));
 }
 
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// four fp32 -> four (hi, lo) fp16 pairs, written with 2-wide vectors so that the residual and its 2^11 scaling are packed
+// VALU ops (v_pk_add_f32 / v_pk_mul_f32): a wave64 VALU instruction occupies its SIMD for 8 cycles, and with two waves per SIMD
+// the split would otherwise keep the VALU pipe as busy as the matrix pipe.  `mx` (optional) tracks max |x| for the range check.
+template <typename V4>
+__device__ __forceinline__ void split4(const V4& v, f16x4& hi, f16x4& lo)
+{
+    // __builtin_convertvector keeps the pair packed: v_cvt_pk_f16_f32, v_cvt_f32_f16 (+ one SDWA form for the upper half),
+    // v_pk_add_f32, v_pk_mul_f32, v_cvt_pk_f16_f32 = 3 VALU ops per element (element-wise casts compile to 4.5)
+    const f32x2v a = {v.x, v.y}, b = {v.z, v.w};
+    const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+    const f32x2v ra = (a - __builtin_convertvector(ha, f32x2v)) * LO_SCALE;                        // exact residual, then 2^11
+    const f32x2v rb = (b - __builtin_convertvector(hb, f32x2v)) * LO_SCALE;
+    const f16x2 la = __builtin_convertvector(ra, f16x2), lb = __builtin_convertvector(rb, f16x2);
+    hi[0] = ha[0]; hi[1] = ha[1]; hi[2] = hb[0]; hi[3] = hb[1];
+    lo[0] = la[0]; lo[1] = la[1]; lo[2] = lb[0]; lo[3] = lb[1];
+}
 template <typename V4>
 __device__ __forceinline__ void split4(const V4& v, f16x4& hi, f16x4& lo, float& mx)
 {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const _Float16 h = (_Float16)x[j];
-        const float r = x[j] - (float)h;               // exact
-        hi[j] = h;
-        lo[j] = (_Float16)(r * LO_SCALE);
-        mx = fmaxf(mx, fabsf(x[j]));
-    }
+    split4(v, hi, lo);
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
 }
 
 // W [N,K] fp32 row-major -> packed[(nb*KT + kt)][plane][g][n][8]  (halfs), nb = n/128, kt = k/32, g = (k%32)/8
@@ -150,7 +162,6 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_kernel(const float* __res
     const _Float16* w_src = Wp + (size_t)nb * KT * (W_BYTES / 2) + (size_t)wave * 512 + lane * 8;   // chunk `wave`; +8 chunks for the second
 
     f32x4v preA[4], preB[4];                                       // the two register sets of activation rows in flight
-    float mx = 0.f;
     // The row loads are inline asm: hipcc waits vmcnt(0) at the first use of an ordinary load while LDS-DMAs are in flight
     // (it would drain the whole prefetch pipeline every iteration); hidden from it, they are waited for by the counted
     // `wait_rows` below, which names the registers so that no use can be scheduled above it.
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f16x4 h, l;
-            split4(pre[i], h, l, mx);
+            split4(pre[i], h, l);
             *reinterpret_cast<f16x4*>(base + i * 64 * 16) = h;
             *reinterpret_cast<f16x4*>(base + i * 64 * 16 + A_P) = l;
         }
@@ -283,9 +294,10 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_kernel(const float* __res
     if (kt < KT) iteration(kt, preB, wc, ring(wc + 1), ring(wc + W_AHEAD));
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(preA[0]), "+v"(preA[1]), "+v"(preA[2]), "+v"(preA[3]), "+v"(preB[0]), "+v"(preB[1]), "+v"(preB[2]), "+v"(preB[3])::"memory");
 
-    if (overflow && !(mx < F16_MAX)) atomicOr(overflow, 1);
-
-    // ---- epilogue: D[i = (r&3) + 8 (r>>2) + 4 lh][j = l31] of each 32x32 block ----
+    // ---- epilogue: D[i = (r&3) + 8 (r>>2) + 4 lh][j = l31] of each 32x32 block.  An activation beyond the fp16 range became inf
+    // in its high part and surfaces here as a non-finite output (0 * inf = NaN in `chk`): flagged, the caller recomputes in fp32
+    // (which also reproduces honestly whatever a non-finite INPUT gives) ----
+    float chk = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + l31;
@@ -298,10 +310,11 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_kernel(const float* __res
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 float v = hi[i][j][r] + lo[i][j][r] * LO_INV + bv;
                 if (ACT == 1) v = gelu_tanh_f(v);
-                if (row < M) out[(size_t)row * ldo + col] = v;
+                if (row < M) { out[(size_t)row * ldo + col] = v; chk = __builtin_fmaf(v, 0.f, chk); }
             }
         }
     }
+    if (overflow && chk != 0.f) atomicOr(overflow, 1);
 }
 
 }  // namespace selftok
