@@ -75,6 +75,16 @@ int selftok_vq_finalize_packed(const void* workspace, const float* z, const floa
 int selftok_code_gather_ln_f32(const void* ids, const float* codebook, const float* ln_w, const float* ln_b,
                                float* out, int n, int C, int D, float eps, int flags, hipStream_t stream);
 
+/* ---- training-side codebook maintenance --------------------------------------
+ * Replaces the one-hot contractions of CosineSimCodebook.forward in training mode (vector_quantize_pytorch.py:583-594:
+ * `bins = embed_onehot.sum(1)`, `embed_sum = einsum('h n d, h n c -> h c d', flatten, embed_onehot)`): bins [C] and
+ * embed_sum [C,16], zeroed by the caller, receive += 1 and += l2norm(z[row]) at ids[row] (z as for selftok_vq_encode_f32;
+ * flags: SELFTOK_IDS_I32, SELFTOK_PRENORMED).  The caller all-reduces both over ranks (:588, :594) and applies the EMA. */
+int selftok_vq_ema_accumulate_f32(const float* z, const void* ids, float* bins, float* embed_sum, int N, int C, int D, int flags, hipStream_t stream);
+/* timestep_p_over_c [K,C] <- lerp(itself, mean_b one_hot(ids[b,k]), weight)  (:568-578, ema_inplace :66-72) with ids [B,K]
+ * (the ids of ALL ranks: gather the ids instead of all-reducing the dense [K,C] mean); C % 4 == 0. */
+int selftok_vq_tpc_update_f32(float* tpc, const void* ids, int B, int K, int C, float weight, int flags, hipStream_t stream);
+
 /* ---- fused residual + LayerNorm + adaLN modulate ---------------------------------------------
  *   x' = x + gate*y ;  n = LN(x') * (1 + scale) + shift          (LN: no affine, eps)
  * Replaces modulate()/gate() and the nn.LayerNorm calls around them:

@@ -584,6 +584,64 @@ __global__ void code_gather_ln_kernel(const IdT* __restrict__ ids, const float* 
     for (int q = 0; q < 4; ++q) o4[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
+// ---------------------------------------------------------------------------------------
+// training-side codebook maintenance (vector_quantize_pytorch.py:568-611): the reference builds a one-hot [N, C] tensor and
+// contracts it with the features (a second N x C x D GEMM plus 4 B N C of one-hot traffic).  Here the ids of the argmax kernel
+// are scattered directly:   bins[c] += 1,  embed_sum[c][:] += l2norm(z[row])   (fp32 L2 atomics; contention is low, N rows
+// spread over C = 32768 codes).  The caller zeroes bins / embed_sum and all-reduces them across ranks.
+// ---------------------------------------------------------------------------------------
+template <typename IdT>
+__global__ __launch_bounds__(256) void vq_ema_accumulate_kernel(const float* __restrict__ z, const IdT* __restrict__ ids, float* __restrict__ bins,
+                                                                float* __restrict__ embed_sum, int N, int C, int normalize)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;   // (row, quarter of the 16-d code)
+    const int row = g >> 2, part = g & 3;
+    if (row >= N) return;
+    long id = (long)ids[row];
+    if (id < 0 || id >= C) return;                         // never produced by the argmax kernel; ignore foreign ids
+    float zz[D], xx[D];
+    load_row16(z + (size_t)row * D, zz);
+    if (normalize) l2norm16(zz, xx);
+    else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) xx[k] = zz[k];
+    }
+    float* dst = embed_sum + (size_t)id * D + part * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = xx[0];
+#pragma unroll
+        for (int k = 1; k < D; ++k) v = (k == part * 4 + j) ? xx[k] : v;     // select without an indexed (scratch) access
+        unsafeAtomicAdd(dst + j, v);
+    }
+    if (part == 0) unsafeAtomicAdd(bins + id, 1.0f);
+}
+
+// timestep_p_over_c [K, C] <- lerp(tpc, batch one-hot mean, w)  (vector_quantize_pytorch.py:568-578, ema_inplace :66-72) without the
+// [B, K, C] one-hot: a dense decay pass (the lerp against 0) and a sparse pass adding w / B at (k, id) for every token.
+__global__ __launch_bounds__(256) void vq_tpc_decay_kernel(float* __restrict__ tpc, long n4, float w)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = reinterpret_cast<float4*>(tpc)[i];
+    if (w < 0.5f) {           // torch.lerp: self + w * (end - self), end = 0
+        v.x = __builtin_fmaf(w, -v.x, v.x); v.y = __builtin_fmaf(w, -v.y, v.y); v.z = __builtin_fmaf(w, -v.z, v.z); v.w = __builtin_fmaf(w, -v.w, v.w);
+    } else {                  //             end - (end - self) * (1 - w)
+        const float k = 1.0f - w;
+        v.x *= k; v.y *= k; v.z *= k; v.w *= k;
+    }
+    reinterpret_cast<float4*>(tpc)[i] = v;
+}
+template <typename IdT>
+__global__ __launch_bounds__(256) void vq_tpc_scatter_kernel(float* __restrict__ tpc, const IdT* __restrict__ ids, int n, int K, int C, float add)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // token (b, k)
+    if (i >= n) return;
+    const long id = (long)ids[i];
+    if (id < 0 || id >= C) return;
+    unsafeAtomicAdd(tpc + (size_t)(i % K) * C + id, add);
+}
+
 }  // namespace selftok
 
 using namespace selftok;
@@ -741,6 +799,33 @@ int selftok_code_gather_ln_f32(const void* ids, const float* codebook, const flo
     if (flags & 1) hipLaunchKernelGGL(code_gather_ln_kernel<int32_t>, dim3((n + 255) / 256), dim3(256), 0, stream, (const int32_t*)ids, codebook, ln_w, ln_b, out, n, C, eps);
     else hipLaunchKernelGGL(code_gather_ln_kernel<long long>, dim3((n + 255) / 256), dim3(256), 0, stream, (const long long*)ids, codebook, ln_w, ln_b, out, n, C, eps);
     return check_launch("code_gather_ln_kernel");
+}
+
+// bins [C] and embed_sum [C,16] (both zeroed by the caller) += the batch's one-hot statistics (see the kernel comment)
+int selftok_vq_ema_accumulate_f32(const float* z, const void* ids, float* bins, float* embed_sum, int N, int C, int Dm, int flags, hipStream_t stream)
+{
+    if (N == 0) return SELFTOK_OK;
+    if (Dm != D || N < 0 || C <= 0 || !z || !ids || !bins || !embed_sum) { set_last_error("vq_ema_accumulate: bad argument"); return SELFTOK_EINVAL; }
+    const int norm = (flags & 2) ? 0 : 1;
+    const unsigned grid = (unsigned)(((long)N * 4 + 255) / 256);
+    if (flags & 1) hipLaunchKernelGGL(vq_ema_accumulate_kernel<int32_t>, dim3(grid), dim3(256), 0, stream, z, (const int32_t*)ids, bins, embed_sum, N, C, norm);
+    else hipLaunchKernelGGL(vq_ema_accumulate_kernel<long long>, dim3(grid), dim3(256), 0, stream, z, (const long long*)ids, bins, embed_sum, N, C, norm);
+    return check_launch("vq_ema_accumulate_kernel");
+}
+
+// tpc [K,C] <- lerp(tpc, mean over the B samples of one_hot(ids [B,K]), weight)
+int selftok_vq_tpc_update_f32(float* tpc, const void* ids, int B, int K, int C, float weight, int flags, hipStream_t stream)
+{
+    if (!tpc || K <= 0 || C <= 0 || (C & 3) || B < 0 || (B > 0 && !ids)) { set_last_error("vq_tpc_update: bad argument (C % 4 == 0)"); return SELFTOK_EINVAL; }
+    const long n4 = (long)K * C / 4;
+    hipLaunchKernelGGL(vq_tpc_decay_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, tpc, n4, weight);
+    int rc = check_launch("vq_tpc_decay_kernel");
+    if (rc || B == 0) return rc;
+    const int n = B * K;
+    const float add = weight / (float)B;
+    if (flags & 1) hipLaunchKernelGGL(vq_tpc_scatter_kernel<int32_t>, dim3((n + 255) / 256), dim3(256), 0, stream, tpc, (const int32_t*)ids, n, K, C, add);
+    else hipLaunchKernelGGL(vq_tpc_scatter_kernel<long long>, dim3((n + 255) / 256), dim3(256), 0, stream, tpc, (const long long*)ids, n, K, C, add);
+    return check_launch("vq_tpc_scatter_kernel");
 }
 
 }  // extern "C"

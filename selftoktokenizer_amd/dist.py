@@ -65,6 +65,33 @@ def all_gather_ids(ids_local: torch.Tensor) -> torch.Tensor:
     return torch.cat([bufs[r][: counts[r]] for r in range(world)]).to(ids_local.dtype).to(out_device)
 
 
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
+    """in-place SUM over ranks (RCCL all-reduce on the GPU box; the training-side VQ's bins / embed_sum); no-op with one rank"""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "gloo" and t.is_cuda:
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "gloo" and t.is_cuda:
+            c = t.cpu()
+            dist.broadcast(c, src=src)
+            t.copy_(c)
+        else:
+            dist.broadcast(t, src=src)
+    return t
+
+
 def backend_name():
     """'nccl' (= RCCL on ROCm) / 'gloo' / None when there is a single rank"""
     return dist.get_backend() if dist.is_initialized() and dist.get_world_size() > 1 else None

@@ -76,6 +76,36 @@ def vq_encode(z: torch.Tensor, codebook: torch.Tensor, *, packed: bool = False, 
     return ids
 
 
+def vq_ema_accumulate(z: torch.Tensor, ids: torch.Tensor, C: int, prenormed: bool = False):
+    """(bins [C], embed_sum [C,16]) of one batch: bins[c] = #rows with id c, embed_sum[c] = sum of their l2-normalised features
+    (the reference's one-hot contractions, vector_quantize_pytorch.py:587-593)."""
+    _need_cuda(z, ids)
+    zz = z.contiguous().float().reshape(-1, z.shape[-1])
+    flat = ids.contiguous().reshape(-1)
+    if flat.dtype not in (torch.int32, torch.int64):
+        flat = flat.to(torch.int64)
+    assert flat.numel() == zz.shape[0]
+    bins = torch.zeros(C, dtype=torch.float32, device=z.device)
+    esum = torch.zeros(C, zz.shape[1], dtype=torch.float32, device=z.device)
+    flags = (IDS_I32 if flat.dtype == torch.int32 else 0) | (PRENORMED if prenormed else 0)
+    _lib.check(_lib.load().selftok_vq_ema_accumulate_f32(_p(zz), _p(flat), _p(bins), _p(esum), zz.shape[0], C, zz.shape[1], flags, _stream()),
+               "selftok_vq_ema_accumulate_f32")
+    return bins, esum
+
+
+def vq_tpc_update_(tpc: torch.Tensor, ids: torch.Tensor, weight: float) -> torch.Tensor:
+    """in place: tpc [K,C] <- lerp(tpc, mean over samples of one_hot(ids [B,K]), weight)  (vector_quantize_pytorch.py:568-578)"""
+    _need_cuda(tpc, ids)
+    assert tpc.is_contiguous() and tpc.dtype == torch.float32 and ids.dim() == 2 and ids.shape[1] == tpc.shape[0]
+    flat = ids.contiguous()
+    if flat.dtype not in (torch.int32, torch.int64):
+        flat = flat.to(torch.int64)
+    K, C = tpc.shape
+    _lib.check(_lib.load().selftok_vq_tpc_update_f32(_p(tpc), _p(flat), flat.shape[0], K, C, float(weight), IDS_I32 if flat.dtype == torch.int32 else 0,
+                                                     _stream()), "selftok_vq_tpc_update_f32")
+    return tpc
+
+
 def code_gather_ln(ids: torch.Tensor, codebook: torch.Tensor, ln_w=None, ln_b=None, eps: float = 1e-6) -> torch.Tensor:
     """ids [...] (int64/int32) -> LayerNorm16(codebook[ids]) [...,16]"""
     _need_cuda(ids, codebook)

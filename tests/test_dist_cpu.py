@@ -89,3 +89,42 @@ def test_bench_launch_command_is_one_rank_per_gpu():
     cmd = m.launch_command(8, ["--gpus", "8", "--steps", "3"], 29999)
     assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "8", "--steps", "3"] and cmd[-5].endswith("bench.py")
+
+
+def _vq_worker(rank, world, port, q):
+    """data-parallel codebook update: each rank holds half of the batch, all-reduces bins / embed_sum / one-hot means over gloo
+    (what distributed.all_reduce does in the reference, vector_quantize_pytorch.py:573,588,594) -> every rank must end with the
+    state a single process computes from the whole batch"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init_from_env("gloo")
+    from oracle import vq_train as VT
+    C, Dm, K, B = 512, 16, 8, 8
+    embed0 = VT.l2norm(synth.hash_normalish(0xE0, (C, Dm)))
+    x = VT.l2norm(synth.hash_normalish(0xE1, (B, K, Dm)))
+    st = VT.new_state(embed0, K)
+    lo, hi = D.shard_range(B, rank, world)
+    ids = VT.train_step(st, x[lo:hi], 0.99, world=world, all_reduce=D.all_reduce_sum_)
+    full = VT.new_state(embed0, K)
+    ids_full = VT.train_step(full, x, 0.99)
+    ok = bool(torch.equal(ids, ids_full[lo:hi]))
+    for name in ("embed", "embed_avg", "cluster_size", "timestep_p_over_c"):
+        ok = ok and float((st[name] - full[name]).abs().max()) < 1e-6
+    t = torch.full((3,), float(rank))
+    D.broadcast_(t, src=1)
+    ok = ok and bool((t == 1.0).all()) and D.world_size() == world
+    q.put((rank, ok))
+    torch.distributed.destroy_process_group()
+
+
+def test_codebook_update_is_data_parallel_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_vq_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

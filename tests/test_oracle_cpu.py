@@ -186,3 +186,33 @@ def test_cfg_oracle_matches_reference(dit_sd):
     full = OM.decode_latent(sd, ids, x, stg, kps, 50, tables, max_steps=1, prefix_k=512)
     plain = OM.decode_latent(sd, ids, x, stg, kps, 50, tables, max_steps=1)
     assert torch.equal(full, plain)
+
+
+def test_vq_train_oracle_matches_reference():
+    """training-side codebook maintenance: oracle/vq_train.py against the reference's CosineSimCodebook in train() mode
+    (golden vqtrain.npz: three EMA steps, smart-reactivation weights, dead-code mask, one k-means iteration)"""
+    from oracle import vq_train as VT
+    g = gold("vqtrain.npz")
+    C, D, K, B = 2048, 16, 32, 16
+    decay = float(g["decay"])
+    st = VT.new_state(torch.from_numpy(g["embed0"]), K)
+    for step in range(3):
+        x = VT.l2norm(synth.hash_normalish(0x7A11 + step, (B, K, D)))
+        ids = VT.train_step(st, x, decay)
+        np.testing.assert_array_equal(ids.numpy(), g[f"ids_{step}"])
+        for name in ("embed", "embed_avg", "cluster_size", "timestep_p_over_c"):
+            assert float((st[name] - torch.from_numpy(g[f"{name}_{step}"])).abs().max()) <= 1e-6, (name, step)      # MKL summation order varies with the thread count
+        assert abs(float(st["delta_embed"]) - float(g[f"delta_embed_{step}"])) <= 1e-5 * max(1.0, float(g[f"delta_embed_{step}"]))
+    assert float((VT.timestep_weight(st) - torch.from_numpy(g["timestep_weight"])).abs().max()) <= 1e-7
+    thr, reset = VT.scaled_thresholds(0.2, 0.2, B, K, 1, C)
+    assert abs(thr - float(g["thr_abs"])) < 1e-7 and abs(reset - float(g["reset_abs"])) < 1e-7
+    np.testing.assert_array_equal(VT.expired_codes(st, thr).numpy(), g["expired"])
+    samples = VT.l2norm(synth.hash_normalish(0x5EED5, (4096, D)))
+    means, bins = VT.kmeans_iteration(samples, samples[:256].clone())
+    np.testing.assert_array_equal(bins.numpy(), g["kmeans_bins"])
+    assert float((means - torch.from_numpy(g["kmeans_means"])).abs().max()) <= 1e-7
+    # change_code bookkeeping (:479-486)
+    idx = torch.tensor([3, 77])
+    VT.change_code(st, idx, samples[:2], reset)
+    assert torch.equal(st["embed"][idx], samples[:2]) and torch.allclose(st["embed_avg"][idx], samples[:2] * reset)
+    assert float(st["cluster_size"][3]) == pytest.approx(reset)

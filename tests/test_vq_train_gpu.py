@@ -1,0 +1,84 @@
+"""-m gpu: training-side codebook maintenance on the GPU (selftoktokenizer_amd/vq_train.py + the scatter kernels of csrc/vq.hip)
+against the golden captured from the reference's CosineSimCodebook in train() mode (tests/golden/vqtrain.npz) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from selftoktokenizer_amd import ops, synth
+from selftoktokenizer_amd.vq_train import CodebookEMA, l2norm
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+C, D, K, B = 2048, 16, 32, 16
+
+
+def test_ema_steps_vs_reference():
+    """three training steps: ids bit-exact, every buffer within fp32 scatter-order noise of the reference"""
+    g = np.load(os.path.join(GOLD, "vqtrain.npz"))
+    cb = CodebookEMA(torch.from_numpy(g["embed0"]).cuda(), K, decay=float(g["decay"]), threshold_ema_dead_code=0.0)
+    for step in range(3):
+        z = synth.hash_normalish(0x7A11 + step, (B, K, D)) * (1.0 + step)          # pre-norm features: any positive scale
+        quant, ids, n = cb.step(z.cuda())
+        assert n == 0
+        np.testing.assert_array_equal(ids.cpu().numpy(), g[f"ids_{step}"])
+        for name in ("embed", "embed_avg", "cluster_size", "timestep_p_over_c"):
+            err = float((getattr(cb, name).cpu() - torch.from_numpy(g[f"{name}_{step}"])).abs().max())
+            assert err <= 2e-6, (name, step, err)
+        assert abs(float(cb.delta_embed) - float(g[f"delta_embed_{step}"])) <= 1e-4 * max(1.0, float(g[f"delta_embed_{step}"]))
+    assert float((cb.timestep_weight().cpu() - torch.from_numpy(g["timestep_weight"])).abs().max()) <= 1e-6
+    cb.threshold_abs, cb.reset_abs = float(g["thr_abs"]), float(g["reset_abs"])
+    np.testing.assert_array_equal(cb.expired_codes().cpu().numpy(), g["expired"])
+
+
+def test_scatter_kernels_match_one_hot_contractions():
+    """bins / embed_sum / timestep_p_over_c from ids == the reference's dense one-hot formulas; shards add up (what the all-reduce sums)"""
+    n = 4096
+    z = synth.synthetic_vq_rows(n, seed=0xACC).cuda()
+    cbk = l2norm(synth.hash_normalish(0xCB, (C, D))).cuda()
+    ids = ops.vq_encode(z, cbk)
+    bins, esum = ops.vq_ema_accumulate(z, ids, C)
+    onehot = torch.nn.functional.one_hot(ids, C).float()
+    x = l2norm(z)
+    assert torch.equal(bins, onehot.sum(0))
+    torch.testing.assert_close(esum, onehot.t() @ x, rtol=1e-5, atol=1e-5)
+    b1, e1 = ops.vq_ema_accumulate(z[:1500], ids[:1500].int(), C)                      # int32 ids, uneven shards
+    b2, e2 = ops.vq_ema_accumulate(z[1500:], ids[1500:], C)
+    assert torch.equal(b1 + b2, bins)
+    torch.testing.assert_close(e1 + e2, esum, rtol=1e-5, atol=1e-5)
+    # timestep_p_over_c: both lerp branches (w = 0.7 on the first step, 0.01 afterwards)
+    idk = ids.reshape(-1, K)
+    for w in (0.7, 0.01):
+        tpc = torch.rand(K, C, device="cuda")
+        ref = tpc.clone().lerp_(torch.nn.functional.one_hot(idk, C).float().mean(0), w)
+        ops.vq_tpc_update_(tpc, idk, w)
+        torch.testing.assert_close(tpc, ref, rtol=1e-6, atol=1e-7)
+
+
+def test_dead_code_reactivation_invariants():
+    """with the tokenizer's thresholds nearly every code is dead after the first small batch: all of them are replaced by unit-norm
+    batch vectors, their statistics reset (change_code, vector_quantize_pytorch.py:479-486), live codes untouched"""
+    cb = CodebookEMA(l2norm(synth.hash_normalish(0xD1, (C, D))).cuda(), K, threshold_ema_dead_code=0.2, reset_cluster_size=0.2)
+    z = synth.hash_normalish(0xD2, (B, K, D)).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    _, ids, n = cb.step(z, generator=gen)
+    assert cb.threshold_abs == pytest.approx(0.2 * B * K / C) and n > 0
+    x = l2norm(z).reshape(-1, D)
+    replaced = cb.cluster_size == cb.reset_abs
+    assert int(replaced.sum()) >= n - 1
+    dots = cb.embed[replaced] @ x.t()
+    assert float((dots.max(dim=1).values - 1.0).abs().max()) < 1e-5                   # every replacement IS a batch vector
+    torch.testing.assert_close(cb.embed_avg[replaced], cb.embed[replaced] * cb.reset_abs)
+    assert float((cb.embed.norm(dim=-1) - 1).abs().max()) < 1e-5
+    _, ids2, _ = cb.step(z, generator=gen)                                             # the refreshed code book is what the next step uses
+    assert ids2.shape == ids.shape
+
+
+def test_kmeans_iteration_vs_reference():
+    g = np.load(os.path.join(GOLD, "vqtrain.npz"))
+    samples = l2norm(synth.hash_normalish(0x5EED5, (4096, D))).cuda()
+    cb = CodebookEMA(samples[:256].clone(), K)
+    means, bins = cb.kmeans_iteration(samples, samples[:256].clone())
+    np.testing.assert_array_equal(bins.cpu().numpy().astype(np.int64), g["kmeans_bins"])
+    assert float((means.cpu() - torch.from_numpy(g["kmeans_means"])).abs().max()) <= 2e-6

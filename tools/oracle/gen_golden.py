@@ -1,7 +1,7 @@
 """Generate tests/golden/*.npz by running the REFERENCE (read-only import, build container only) on the
 hash-generated synthetic weights/inputs, and report how oracle/ compares on the same inputs.
 
-    python tools/oracle/gen_golden.py [stage ...]      stages: keys vq schedule encoder dit vae pipeline renderer cfg k1024
+    python tools/oracle/gen_golden.py [stage ...]      stages: keys vq schedule encoder dit vae pipeline renderer cfg k1024 vqtrain
 
 A golden file holds only data: inputs that cannot be regenerated from a seed, and the reference's
 outputs.  Weights/images/noise are regenerated from selftoktokenizer_amd.synth by name/seed.
@@ -395,8 +395,61 @@ def stage_k1024():
                         v=v.numpy(), t=np.float32(tval), k=np.int64(k))
 
 
+def stage_vqtrain():
+    """training-side codebook maintenance: the reference's own CosineSimCodebook in train() mode, three EMA steps (dead-code expiry
+    off so that every number is deterministic), then the dead-code mask / sampling weights of a fourth state, and one k-means
+    iteration from given seeds.  Pins oracle/vq_train.py."""
+    H.install()
+    import torch.distributed as dist
+    from oracle import vq_train as VT
+    from mimogpt.models.selftok.vector_quantize_pytorch import CosineSimCodebook, gumbel_sample, kmeans, l2norm
+    from functools import partial
+    if not dist.is_initialized():                                  # the training forward calls distributed.get_world_size()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    C, D, K, B, decay = 2048, 16, 32, 16, 0.99
+    gs = partial(gumbel_sample, stochastic=False, reinmax=False, straight_through=False)
+    cb = CosineSimCodebook(dim=D, codebook_size=C, kmeans_init=False, decay=decay, threshold_ema_dead_code=0, use_ddp=False,
+                           gumbel_sample=gs, sample_codebook_temp=1.0, smart_re_K=K)
+    embed0 = l2norm(synth.hash_normalish(0xC0DEB00C, (C, D)))
+    cb.embed.data.copy_(embed0[None]); cb.embed_avg.data.copy_(embed0[None])
+    cb.train()
+    st = VT.new_state(embed0, K)
+    out = {"embed0": embed0.numpy(), "decay": np.float32(decay)}
+    worst = 0.0
+    for step in range(3):
+        z = synth.hash_normalish(0x7A11 + step, (B, K, D))
+        x = l2norm(z)
+        with torch.no_grad():
+            _, ids, _, _ = cb(x)
+        ids_o = VT.train_step(st, x, decay)
+        assert torch.equal(ids_o, ids), step
+        for name in ("embed", "embed_avg", "cluster_size", "timestep_p_over_c"):
+            ref = getattr(cb, name)[0]
+            worst = max(worst, maxdiff(ref, st[name]))
+            out[f"{name}_{step}"] = ref.numpy().copy()
+        out[f"ids_{step}"] = ids.numpy()
+        out[f"delta_embed_{step}"] = np.float32(float(cb.delta_embed))
+    report("vqtrain_ema", steps=3, worst_maxdiff=worst)
+    w_ref = cb.compute_timestep_weight()[0]
+    out["timestep_weight"] = w_ref.numpy()
+    thr, reset = VT.scaled_thresholds(0.2, 0.2, B, K, 1, C)
+    out["thr_abs"], out["reset_abs"] = np.float32(thr), np.float32(reset)
+    out["expired"] = (cb.cluster_size[0] < thr).numpy()
+    report("vqtrain_weights", tw_maxdiff=maxdiff(w_ref, VT.timestep_weight(st)), expired=int(out["expired"].sum()),
+           expired_equal=bool(torch.equal(VT.expired_codes(st, thr), torch.from_numpy(out["expired"]))))
+    # one k-means iteration from given seeds (kmeans samples its seeds at random: inject them)
+    samples = l2norm(synth.hash_normalish(0x5EED5, (1, 4096, D)))
+    seeds = samples[:, :256].clone()
+    means, bins = kmeans(samples, 256, num_iters=1, use_cosine_sim=True, sample_fn=lambda s, n: seeds)
+    m_o, b_o = VT.kmeans_iteration(samples[0], seeds[0])
+    report("vqtrain_kmeans", means_maxdiff=maxdiff(means[0], m_o), bins_equal=bool(torch.equal(bins[0], b_o)))
+    out["kmeans_means"], out["kmeans_bins"] = means[0].numpy(), bins[0].numpy()
+    np.savez_compressed(os.path.join(GOLD, "vqtrain.npz"), **out)
+
+
 STAGES = dict(keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
-              vae=stage_vae, pipeline=stage_pipeline, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024)
+              vae=stage_vae, pipeline=stage_pipeline, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024, vqtrain=stage_vqtrain)
 
 if __name__ == "__main__":
     torch.set_grad_enabled(False)
