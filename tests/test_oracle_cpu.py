@@ -203,14 +203,14 @@ def test_vq_train_oracle_matches_reference():
         for name in ("embed", "embed_avg", "cluster_size", "timestep_p_over_c"):
             assert float((st[name] - torch.from_numpy(g[f"{name}_{step}"])).abs().max()) <= 1e-6, (name, step)      # MKL summation order varies with the thread count
         assert abs(float(st["delta_embed"]) - float(g[f"delta_embed_{step}"])) <= 1e-5 * max(1.0, float(g[f"delta_embed_{step}"]))
-    assert float((VT.timestep_weight(st) - torch.from_numpy(g["timestep_weight"])).abs().max()) <= 1e-7
+    assert float((VT.timestep_weight(st) - torch.from_numpy(g["timestep_weight"])).abs().max()) <= 1e-6
     thr, reset = VT.scaled_thresholds(0.2, 0.2, B, K, 1, C)
     assert abs(thr - float(g["thr_abs"])) < 1e-7 and abs(reset - float(g["reset_abs"])) < 1e-7
     np.testing.assert_array_equal(VT.expired_codes(st, thr).numpy(), g["expired"])
     samples = VT.l2norm(synth.hash_normalish(0x5EED5, (4096, D)))
     means, bins = VT.kmeans_iteration(samples, samples[:256].clone())
     np.testing.assert_array_equal(bins.numpy(), g["kmeans_bins"])
-    assert float((means - torch.from_numpy(g["kmeans_means"])).abs().max()) <= 1e-7
+    assert float((means - torch.from_numpy(g["kmeans_means"])).abs().max()) <= 1e-6
     # change_code bookkeeping (:479-486)
     idx = torch.tensor([3, 77])
     VT.change_code(st, idx, samples[:2], reset)
