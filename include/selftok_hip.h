@@ -37,6 +37,9 @@ typedef struct ihipStream_t* hipStream_t;
 #define SELFTOK_PRENORMED 2   /* z rows are already unit-norm: skip the fused l2norm */
 /* launch-shape overrides of the packed (MFMA) path, for tests and tuning only -- ids never depend on them:
  * rows per wave tile (1, 2 or 4 x 32) and the number of code splits (1..64).  0 = choose from N and the device. */
+#define SELFTOK_VQ_F16COARSE 8  /* packed path: approximate scores on the f16 matrix cores (3 MFMAs of the 16x-rate pipe per 32x32 scores),
+                                  then canonical fp32 re-score of every candidate within the proven error window -> the SAME ids and
+                                  top-1 score bits as the fp32 kernels (csrc/vq.hip, vq_f16_kernel) */
 #define SELFTOK_VQ_RT(n) (((n) & 0xF) << 8)
 #define SELFTOK_VQ_SPLIT(n) (((n) & 0xFF) << 16)
 
@@ -53,7 +56,8 @@ size_t selftok_vq_workspace_bytes(int N, int C);
 int selftok_vq_encode_f32(const float* z, const float* codebook, void* ids, float* best, void* workspace,
                           int N, int C, int D, int flags, hipStream_t stream);
 /* One-time re-layout of the (constant) codebook into MFMA fragment order, C % 32 == 0.  `packed` must hold
- * selftok_vq_packed_bytes(C,D) bytes (= the codebook + one metadata line: a "non-finite code present" flag). */
+ * selftok_vq_packed_bytes(C,D) bytes (= the fp32 image + one metadata line: "non-finite / out-of-fp16-range code present" flags +
+ * the fp16 hi/lo image of the 2^7-scaled codebook used by SELFTOK_VQ_F16COARSE). */
 size_t selftok_vq_packed_bytes(int C, int D);
 int selftok_vq_pack_codebook(const float* codebook, float* packed, int C, int D, hipStream_t stream);
 /* Same contract as selftok_vq_encode_f32 on the packed codebook (v_mfma_f32_32x32x2_f32 path). */

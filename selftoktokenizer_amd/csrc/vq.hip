@@ -238,6 +238,16 @@ __global__ __launch_bounds__(256) void vq_valu_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// coarse pass of the f16 path: both operands are pre-multiplied by 2^7 (exact) so that the fp16 residuals of ordinary components
+// of unit vectors stay in the fp16 normal range; scores come out multiplied by 2^14.
+constexpr float F16_PRESCALE = 128.0f;
+constexpr float F16_SCORE_SCALE = F16_PRESCALE * F16_PRESCALE;
+// |coarse - canonical| in ORIGINAL score units for unit-norm rows and codes (sum |x_k e_k| <= 1): the two operand representations
+// and the dropped lo x lo term 3 x 2^-22 = 7.2e-7, the fp32 accumulation inside three chained MFMAs <= 7e-7 (a few ulp of a sum
+// <= 1), the canonical chain's own 16 roundings <= 9.5e-7: < 2.4e-6 in the worst case.  The window is 3x that; measured maximum
+// over 1.7e7 scores: 3.0e-7 (tests/test_vq_gpu.py::test_vq_coarse_pass_error_bound_and_adversarial_near_ties).
+constexpr float F16_EPS = 7.62939453125e-06f;          // 2^-17
+
 // packed layout: tile t (32 codes) = 512 floats = [part 0..1][lane 0..63][4 floats]; lane l = (h = l>>5, i = l&31)
 // owns e[t*32+i][2m+h] for m = 4*part + j -- exactly the A fragments of the 8 chained 32x32x2 MFMAs, stored so that
 // one wave reads (or DMAs into LDS) a whole 1 KiB (tile, part) piece with 16 B per lane, conflict-free.
@@ -256,7 +266,15 @@ __global__ void vq_pack_kernel(const float* __restrict__ cb, float* __restrict__
     int t = c >> 5, i = c & 31;
     const float v = cb[g];
     packed[(size_t)t * 512 + packed_offset(i, k)] = v;
+    // second image for the coarse pass (vq_f16_kernel): e * 2^7 split into fp16 hi + fp16 lo, in the A-operand order of
+    // v_mfma_f32_32x32x16_f16: tile t = [plane][lane = (k>>3)*32 + i][k & 7]
+    _Float16* p16 = reinterpret_cast<_Float16*>(packed + (size_t)C * D + 64) + (size_t)t * 1024;
+    const float vs = v * F16_PRESCALE;
+    const _Float16 hi = (_Float16)vs;
+    p16[((k >> 3) * 32 + i) * 8 + (k & 7)] = hi;
+    p16[512 + ((k >> 3) * 32 + i) * 8 + (k & 7)] = (_Float16)(vs - (float)hi);
     if (suspicious(v)) atomicOr(reinterpret_cast<unsigned int*>(packed) + (size_t)C * D, 1u);
+    if (!(fabsf(vs) < 60000.f)) atomicOr(reinterpret_cast<unsigned int*>(packed) + (size_t)C * D, 2u);     // outside the fp16 range
 }
 
 // running best of one lane for one x-row, MFMA flavour: the index is kept as (tile, register slot) so that the
@@ -465,6 +483,225 @@ __global__ __launch_bounds__(256) void vq_mfma_kernel(const float* __restrict__ 
         if (slow) lo = 0x80000000u | (uint32_t)(best[t].tile * 32 + (best[t].slot & 3) + 8 * (best[t].slot >> 2) + 4 * half);
         int r = row0 + t * 32 + col;
         if (r < N) partial[((size_t)blockIdx.y * 2 + half) * N + r] = ((unsigned long long)hi << 32) | lo;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// f16 coarse pass + exact re-score ("change the algorithm", VERDICT r1 item 5 / SURVEY section 7)
+//
+// The fp32-input MFMA runs at the fp32 vector rate; the f16 MFMA runs 16x faster.  vq_f16_kernel computes APPROXIMATE scores
+// s' = (x0 e0 + x0 e1 + x1 e0) with three v_mfma_f32_32x32x16_f16 per (32 codes x 32 rows) -- D = 16 is exactly one k-step --
+// where x = x0 + x1, e = e0 + e1 are fp16 hi/lo splits of the (2^7-scaled) operands, |s' - s| < F16_EPS for the canonical
+// fp32 score s.  Per lane stream (one wave half of one code split) it keeps the best tile maximum m1 (its tile t1) and the
+// runner-up tile maximum m2 (v_med3_f32 keeps m1 >= m2 in one op).  The TRUE argmax c* satisfies s'(c*) >= max s' - 2 eps, so:
+//   * every stream with m1 >= M - 2 eps (M = max over streams) is a candidate; c* lies in one of them;
+//   * inside a candidate stream c* is in tile t1 unless another tile also reaches M - 2 eps, which implies m2 >= m1 - 2 eps:
+//     that stream is flagged and re-scanned exactly, all of it.
+// vq_finalize_f16_kernel re-scores the 16 codes of every candidate (tile, half) -- or the whole flagged stream -- with the
+// canonical k-ordered fp32 FMA chain and takes the maximum, lowest index on ties (all exact ties are inside the window too).
+// Ids and top-1 scores are therefore bit-identical to the fp32 kernels and the CPU oracle; rows or code books with non-finite /
+// out-of-range values are flagged wholesale and go through the exact NaN-aware scan.
+// ---------------------------------------------------------------------------------------
+typedef _Float16 vh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 vh2 __attribute__((ext_vector_type(2)));
+typedef unsigned vu4 __attribute__((ext_vector_type(4)));
+typedef float vf2 __attribute__((ext_vector_type(2)));
+
+constexpr uint32_t F16_FLAG = 0x80000000u;       // entry.lo bit 31: re-scan the whole stream exactly
+
+template <int RT>
+__global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z, const float* __restrict__ packed,
+                                                     unsigned long long* __restrict__ partial, int N, int C,
+                                                     int tiles_per_split, int normalize)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_tile[2][M_CH * 2048];     // 8 tiles x (2 planes x 64 lanes x 16 B), double buffered
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int row0 = (blockIdx.x * 4 + wave) * 32 * RT;
+    const _Float16* packed16 = reinterpret_cast<const _Float16*>(packed + (size_t)C * D + 64);
+
+    // B operands: lane (half, col) holds x[row col][k = 8 half + j], j = 0..7, as fp16 hi / lo pairs of 128 x
+    vu4 x0[RT], x1[RT];
+    bool xbad = false;
+    const uint32_t hsel = half ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        float zz[D], xx[D];
+        int r = row0 + t * 32 + col;
+        r = r < N ? r : N - 1;
+        load_row16(z + (size_t)r * D, zz);
+        if (normalize) l2norm16(zz, xx);
+        else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) xx[k] = zz[k];
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) xbad |= !(fabsf(xx[k]) < 400.f);      // NaN / inf / beyond fp16 after the 2^7 scaling
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // bit-select between the two halves' elements (a `half ? a : b` on array elements becomes an indexed scratch access)
+            const float va = __uint_as_float((__float_as_uint(xx[8 + 2 * j]) & hsel) | (__float_as_uint(xx[2 * j]) & ~hsel));
+            const float vb = __uint_as_float((__float_as_uint(xx[9 + 2 * j]) & hsel) | (__float_as_uint(xx[2 * j + 1]) & ~hsel));
+            const vf2 v = {va * F16_PRESCALE, vb * F16_PRESCALE};
+            const vh2 h = __builtin_convertvector(v, vh2);
+            const vh2 l = __builtin_convertvector(v - __builtin_convertvector(h, vf2), vh2);
+            x0[t][j] = __builtin_bit_cast(unsigned, h);
+            x1[t][j] = __builtin_bit_cast(unsigned, l);
+        }
+    }
+    const bool bad = xbad || (reinterpret_cast<const uint32_t*>(packed)[(size_t)C * D] != 0u);
+
+    const int ntiles_total = C >> 5;
+    const int tile_first = blockIdx.y * tiles_per_split;
+    int tile_last = tile_first + tiles_per_split;
+    if (tile_last > ntiles_total) tile_last = ntiles_total;
+    const int nt = tile_last - tile_first;
+
+    float m1[RT], m2[RT];
+    int t1[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) { m1[t] = -__builtin_inff(); m2[t] = -__builtin_inff(); t1[t] = tile_first; }
+
+    auto stage = [&](int chunk, int buf) {      // this wave's share: pieces wave, wave+4, ... of the 2*M_CH 1-KiB (tile, plane) pieces
+#pragma unroll
+        for (int pi = wave; pi < 2 * M_CH; pi += 4) {
+            int tl = chunk * M_CH + (pi >> 1);
+            tl = tl < nt ? tl : nt - 1;
+            const _Float16* src = packed16 + (size_t)(tile_first + tl) * 1024 + (pi & 1) * 512 + lane * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(&s_tile[buf][pi * 1024]), 16, 0, 0);
+        }
+    };
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    if (nt > 0) {
+        const int nchunks = (nt + M_CH - 1) / M_CH;
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunks) stage(c + 1, buf ^ 1);
+            const int base = c * M_CH;
+#pragma unroll
+            for (int j = 0; j < M_CH; ++j) {
+                if (base + j < nt) {                                   // wave-uniform
+                    const vh8 e0 = *reinterpret_cast<const vh8*>(&s_tile[buf][j * 2048 + lane * 16]);
+                    const vh8 e1 = *reinterpret_cast<const vh8*>(&s_tile[buf][j * 2048 + 1024 + lane * 16]);
+                    const int tile = tile_first + base + j;
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) {
+                        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, __builtin_bit_cast(vh8, x0[t]), zero, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, __builtin_bit_cast(vh8, x1[t]), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, __builtin_bit_cast(vh8, x0[t]), acc, 0, 0, 0);
+                        // tile maximum (8 x v_max3), then (m1, m2) <- the two largest of (m1, m2, mt): v_max + v_med3
+                        const float a0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]), a1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
+                        const float a2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]), a3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
+                        const float a4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
+                        const float mt = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), __builtin_fmaxf(__builtin_fmaxf(a3, a4), acc[15]));
+                        m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], mt);
+                        const bool g = mt > m1[t];                      // strict: the earliest tile holding the maximum is t1
+                        m1[t] = __builtin_fmaxf(m1[t], mt);
+                        t1[t] = g ? tile : t1[t];
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    const float win = 2.0f * F16_EPS * F16_SCORE_SCALE;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const bool flag = bad || !(m2[t] < m1[t] - win);                // also true when m1 is NaN
+        float v = m1[t];
+        if (v == 0.0f) v = 0.0f;
+        // a row / code book with non-finite or out-of-range values: v_max3 skipped the NaNs, m1 means nothing -> every stream of
+        // the row must be re-scanned exactly, which the NaN key (sorts highest, opens the window completely) forces
+        const uint32_t hi = (bad || v != v) ? KEY_NAN : f32_orderable(v);
+        const uint32_t lo = (flag ? F16_FLAG : 0u) | (uint32_t)t1[t];
+        const int r = row0 + t * 32 + col;
+        if (r < N) partial[((size_t)blockIdx.y * 2 + half) * N + r] = ((unsigned long long)hi << 32) | lo;
+    }
+}
+
+// exact resolution of the coarse pass: see the comment above vq_f16_kernel.  16 lanes per row.
+template <typename IdT>
+__global__ __launch_bounds__(256) void vq_finalize_f16_kernel(const unsigned long long* __restrict__ partial, const float* __restrict__ z,
+                                                              const float* __restrict__ packed, IdT* __restrict__ ids, float* __restrict__ best,
+                                                              int N, int C, int nsplit, int tiles_per_split, int normalize)
+{
+    const int gl = threadIdx.x & 15;
+    const int gsh = (threadIdx.x & 63) & ~15;                            // first lane of this row's 16-lane group inside the wave
+    const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool live = r < N;
+    const int rr = live ? r : N - 1;
+    const int nentries = 2 * nsplit;
+    float x[D];
+    {
+        float zz[D];
+        load_row16(z + (size_t)rr * D, zz);
+        if (normalize) l2norm16(zz, x);
+        else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) x[k] = zz[k];
+        }
+    }
+    // M = best coarse maximum over the streams (NaN keys sort highest and are flagged anyway)
+    uint32_t gmax = 0;
+    for (int s = gl; s < nentries; s += 16) {
+        const uint32_t hi = (uint32_t)(partial[(size_t)s * N + rr] >> 32);
+        gmax = hi > gmax ? hi : gmax;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(gmax, o, 16); gmax = other > gmax ? other : gmax; }
+    const float thresh = (gmax == KEY_NAN) ? -__builtin_inff() : f32_from_orderable(gmax) - 2.0f * F16_EPS * F16_SCORE_SCALE;
+
+    Best b;
+    best_init(b, 0);
+    const int ntiles_total = C >> 5;
+    for (int s0 = 0; s0 < nentries; s0 += 16) {
+        const int s_mine = s0 + gl;
+        const unsigned long long e = s_mine < nentries ? partial[(size_t)s_mine * N + rr] : 0ull;
+        const uint32_t ehi = (uint32_t)(e >> 32);
+        const bool cand = s_mine < nentries && (ehi == KEY_NAN || !(f32_from_orderable(ehi) < thresh));
+        uint32_t mask = (uint32_t)((__ballot(cand) >> gsh) & 0xFFFFu);
+        while (mask) {
+            const int j = __ffs(mask) - 1;
+            mask &= mask - 1;
+            const uint32_t lo = (uint32_t)__shfl((uint32_t)e, j, 16);
+            const int stream = s0 + j, half = stream & 1, split = stream >> 1;
+            const int i = (gl & 3) + 8 * (gl >> 2) + 4 * half;           // this lane's code inside a tile of that half
+            int tfirst, tlast;
+            if (lo & F16_FLAG) { tfirst = split * tiles_per_split; tlast = tfirst + tiles_per_split; tlast = tlast < ntiles_total ? tlast : ntiles_total; }
+            else { tfirst = (int)(lo & 0x7FFFFFFFu); tlast = tfirst + 1; }
+            for (int tile = tfirst; tile < tlast; ++tile) {              // ascending code order per lane: first maximum wins
+                const float* pt = packed + (size_t)tile * 512;
+                float sc = 0.f;
+#pragma unroll
+                for (int k = 0; k < D; ++k) sc = __builtin_fmaf(x[k], pt[packed_offset(i, k)], sc);
+                // candidates are NOT visited in code order (streams come in entry order): on an exact tie, and among NaNs, the lower
+                // code index wins explicitly (torch.argmax: first maximum; a NaN counts as the maximum, first NaN wins)
+                const int idx = tile * 32 + i;
+                if (sc != sc) {
+                    if (!b.nan || idx < b.i) { b.nan = true; b.v = __builtin_inff(); b.i = idx; }
+                } else if (!b.nan && (sc > b.v || (sc == b.v && idx < b.i))) { b.v = sc; b.i = idx; }
+            }
+        }
+    }
+    unsigned long long key = best_key(b);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const uint32_t klo = __shfl_xor((uint32_t)key, o, 16), khi = __shfl_xor((uint32_t)(key >> 32), o, 16);
+        const unsigned long long other = ((unsigned long long)khi << 32) | klo;
+        key = other > key ? other : key;
+    }
+    if (live && gl == 0) {
+        const uint32_t hi = (uint32_t)(key >> 32);
+        ids[r] = (IdT)(~(uint32_t)key);
+        if (best) best[r] = (hi == KEY_NAN) ? __uint_as_float(0x7FC00000u) : f32_from_orderable(hi);
     }
 }
 
@@ -696,7 +933,8 @@ size_t selftok_vq_workspace_bytes(int N, int C)
     return (size_t)128 * (size_t)(N > 0 ? N : 1) * sizeof(unsigned long long);   // up to 64 code splits x 2 wave halves
 }
 
-size_t selftok_vq_packed_bytes(int C, int Dm) { return ((size_t)C * Dm + 64) * sizeof(float); }
+// fp32 fragment image + one metadata line (flags) + fp16 hi/lo image of the 2^7-scaled code book
+size_t selftok_vq_packed_bytes(int C, int Dm) { return ((size_t)C * Dm + 64) * sizeof(float) + (size_t)C * Dm * 2 * sizeof(_Float16); }
 
 int selftok_vq_pack_codebook(const float* codebook, float* packed, int C, int Dm, hipStream_t stream)
 {
@@ -737,6 +975,24 @@ int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, vo
     unsigned long long* partial = (unsigned long long*)workspace;
     const int ntiles = C >> 5;
     const int norm = (flags & 2) ? 0 : 1;
+    if (flags & SELFTOK_VQ_F16COARSE) {
+        // f16 coarse pass: the matrix work is 5x cheaper, so fewer, longer code splits (every split costs 16 B of candidates per row
+        // and a finalize visit) and 4 row blocks per wave from 8192 rows on
+        int rt = N >= 8192 ? 4 : (N >= 2048 ? 2 : 1);
+        { const int f_rt = (flags >> 8) & 0xF; if (f_rt == 1 || f_rt == 2 || f_rt == 4) rt = f_rt; }
+        const int row_blocks = (N + 128 * rt - 1) / (128 * rt);
+        int split = 1;
+        while (row_blocks * split < 512 && split < 64 && ntiles / (split * 2) >= 16) split *= 2;
+        { const int f_split = (flags >> 16) & 0xFF; if (f_split > 0 && f_split <= 64) split = f_split; }
+        const int tps = (ntiles + split - 1) / split;
+        split = (ntiles + tps - 1) / tps;
+        *nsplit_out = split;
+        dim3 grid(row_blocks, split), block(256);
+        if (rt == 4) hipLaunchKernelGGL(vq_f16_kernel<4>, grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
+        else if (rt == 2) hipLaunchKernelGGL(vq_f16_kernel<2>, grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
+        else hipLaunchKernelGGL(vq_f16_kernel<1>, grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
+        return check_launch("vq_f16_kernel");
+    }
     int rt = N >= 32768 ? 4 : (N >= 8192 ? 2 : 1);     // measured: 130 / 126 / 118 TF at N=32768 for RT = 4 / 2 / 1
     {   // explicit tuning override in `flags` (tests sweep it; results never depend on it): SELFTOK_VQ_RT(1|2|4)
         const int f_rt = (flags >> 8) & 0xF;
@@ -775,6 +1031,12 @@ int selftok_vq_finalize_packed(const void* workspace, const float* z, const floa
     if (!workspace || !z || !packed || !ids || N < 0 || nsplit <= 0 || Dm != D || (C & 31)) { set_last_error("vq_finalize_packed: bad argument"); return SELFTOK_EINVAL; }
     const unsigned long long* partial = (const unsigned long long*)workspace;
     const int norm = (flags & 2) ? 0 : 1;
+    if (flags & SELFTOK_VQ_F16COARSE) {
+        const int ntiles = C >> 5, tps = (ntiles + nsplit - 1) / nsplit;
+        if (flags & 1) hipLaunchKernelGGL(vq_finalize_f16_kernel<int32_t>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (int32_t*)ids, best, N, C, nsplit, tps, norm);
+        else hipLaunchKernelGGL(vq_finalize_f16_kernel<long long>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (long long*)ids, best, N, C, nsplit, tps, norm);
+        return check_launch("vq_finalize_f16_kernel");
+    }
     if (flags & 1) hipLaunchKernelGGL(vq_finalize_packed_kernel<int32_t>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (int32_t*)ids, best, N, 2 * nsplit, norm);
     else hipLaunchKernelGGL(vq_finalize_packed_kernel<long long>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (long long*)ids, best, N, 2 * nsplit, norm);
     return check_launch("vq_finalize_packed_kernel");

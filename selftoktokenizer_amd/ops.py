@@ -11,6 +11,8 @@ from . import _lib
 
 IDS_I32 = 1
 PRENORMED = 2
+VQ_F16COARSE = 8     # packed path: f16 coarse pass + exact fp32 re-score (same ids / score bits, ~4x faster than the fp32-MFMA kernel)
+VQ_DEFAULT_COARSE = True
 VQ_EVENTS = None     # bench.py sets this to a list: vq_encode(packed=True) then appends (start, end) HIP events around the argmax kernel
 
 
@@ -39,20 +41,28 @@ def vq_pack_codebook(codebook: torch.Tensor) -> torch.Tensor:
     cb = codebook.contiguous().float()
     C, D = cb.shape
     lib = _lib.load()
-    packed = torch.empty(lib.selftok_vq_packed_bytes(C, D) // 4, dtype=torch.float32, device=cb.device)
+    packed = torch.zeros(lib.selftok_vq_packed_bytes(C, D) // 4, dtype=torch.float32, device=cb.device)
     _lib.check(lib.selftok_vq_pack_codebook(_p(cb), _p(packed), C, D, _stream()), "selftok_vq_pack_codebook")
     return packed
 
 
+def packed_codes(packed: torch.Tensor, D: int = 16) -> int:
+    """number of codes in a vq_pack_codebook image: C*D fp32 + 64 metadata floats + C*D fp16 hi/lo pairs (= C*D more floats)"""
+    return (packed.numel() - 64) // (2 * D)
+
+
 def vq_encode(z: torch.Tensor, codebook: torch.Tensor, *, packed: bool = False, return_best: bool = False,
-              ids_dtype=torch.int64, prenormed: bool = False, rt: int = 0, split: int = 0):
+              ids_dtype=torch.int64, prenormed: bool = False, rt: int = 0, split: int = 0, coarse=None):
     """z [...,16] fp32 (pre-norm) , codebook [C,16] (raw, or packed if packed=True) -> ids [...].
-    rt / split: launch-shape overrides of the packed path (SELFTOK_VQ_RT / SELFTOK_VQ_SPLIT; 0 = automatic)."""
+    rt / split: launch-shape overrides of the packed path (SELFTOK_VQ_RT / SELFTOK_VQ_SPLIT; 0 = automatic).
+    coarse (packed path): True = f16 coarse pass + exact re-score (SELFTOK_VQ_F16COARSE), False = fp32-input MFMA kernel;
+    None = VQ_DEFAULT_COARSE.  Both return identical ids and score bits."""
     _need_cuda(z, codebook)
     lib = _lib.load()
+    use_coarse = packed and (VQ_DEFAULT_COARSE if coarse is None else bool(coarse))
     if packed and VQ_EVENTS is not None and not return_best and not prenormed and z.numel() > 0:
         # same two launches as selftok_vq_encode_packed_f32, with HIP events around the argmax kernel on its launch stream
-        ids, launch_main, launch_fin = vq_encode_split_launch(z, codebook, ids_dtype)
+        ids, launch_main, launch_fin = vq_encode_split_launch(z, codebook, ids_dtype, coarse=use_coarse)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         launch_main()
@@ -62,11 +72,12 @@ def vq_encode(z: torch.Tensor, codebook: torch.Tensor, *, packed: bool = False, 
         return ids
     zz = z.contiguous().float().reshape(-1, z.shape[-1])
     N, D = zz.shape
-    C = (codebook.numel() - 64) // D if packed else codebook.shape[0]
+    C = packed_codes(codebook, D) if packed else codebook.shape[0]
     ids = torch.empty(N, dtype=ids_dtype, device=z.device)
     best = torch.empty(N, dtype=torch.float32, device=z.device) if return_best else None
     ws = torch.empty(lib.selftok_vq_workspace_bytes(N, C), dtype=torch.uint8, device=z.device)
-    flags = (IDS_I32 if ids_dtype == torch.int32 else 0) | (PRENORMED if prenormed else 0) | ((rt & 0xF) << 8) | ((split & 0xFF) << 16)
+    flags = ((IDS_I32 if ids_dtype == torch.int32 else 0) | (PRENORMED if prenormed else 0) | ((rt & 0xF) << 8) | ((split & 0xFF) << 16)
+             | (VQ_F16COARSE if use_coarse else 0))
     fn = lib.selftok_vq_encode_packed_f32 if packed else lib.selftok_vq_encode_f32
     _lib.check(fn(_p(zz), _p(codebook), _p(ids), _p(best), _p(ws), N, C, D, flags, _stream()),
                "selftok_vq_encode_packed_f32" if packed else "selftok_vq_encode_f32")
@@ -365,17 +376,17 @@ def clamp01_(img):
     return img
 
 
-def vq_encode_split_launch(z, packed_codebook, ids_dtype=torch.int64):
+def vq_encode_split_launch(z, packed_codebook, ids_dtype=torch.int64, coarse=None):
     """Same result as vq_encode(packed=True) but returns (ids, launch_main, launch_finalize) closures so a
     benchmark can time the main argmax kernel alone (HIP events around launch_main on the current stream)."""
     import ctypes
     lib = _lib.load()
     zz = z.contiguous().float().reshape(-1, z.shape[-1])
     N, D = zz.shape
-    C = (packed_codebook.numel() - 64) // D
+    C = packed_codes(packed_codebook, D)
     ids = torch.empty(N, dtype=ids_dtype, device=z.device)
     ws = torch.empty(lib.selftok_vq_workspace_bytes(N, C), dtype=torch.uint8, device=z.device)
-    flags = IDS_I32 if ids_dtype == torch.int32 else 0
+    flags = (IDS_I32 if ids_dtype == torch.int32 else 0) | (VQ_F16COARSE if (VQ_DEFAULT_COARSE if coarse is None else coarse) else 0)
     nsplit = ctypes.c_int(0)
 
     def launch_main():

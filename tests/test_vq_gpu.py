@@ -18,18 +18,20 @@ def cb():
 
 
 def _check(z, cb, packed):
+    """packed=True checks BOTH packed kernels: the f16 coarse pass + exact re-score (default) and the fp32-input MFMA kernel"""
     from oracle import clib
     ids_ref, best_ref = clib.vq_encode(z.numpy(), cb.numpy())
     zc, cbc = z.cuda(), cb.cuda()
     cbk = ops.vq_pack_codebook(cbc) if packed else cbc
-    ids, best = ops.vq_encode(zc, cbk, packed=packed, return_best=True)
-    torch.cuda.synchronize()
-    ids, best = ids.cpu().numpy(), best.cpu().numpy()
-    assert ids.dtype == np.int64
-    np.testing.assert_array_equal(ids, ids_ref)
-    nan = np.isnan(best_ref)
-    np.testing.assert_array_equal(np.isnan(best), nan)
-    np.testing.assert_array_equal(best[~nan].view(np.uint32), best_ref[~nan].view(np.uint32))
+    for coarse in ((True, False) if packed else (None,)):
+        ids, best = ops.vq_encode(zc, cbk, packed=packed, return_best=True, coarse=coarse)
+        torch.cuda.synchronize()
+        ids, best = ids.cpu().numpy(), best.cpu().numpy()
+        assert ids.dtype == np.int64
+        np.testing.assert_array_equal(ids, ids_ref, err_msg=f"coarse={coarse}")
+        nan = np.isnan(best_ref)
+        np.testing.assert_array_equal(np.isnan(best), nan)
+        np.testing.assert_array_equal(best[~nan].view(np.uint32), best_ref[~nan].view(np.uint32), err_msg=f"coarse={coarse}")
 
 
 @pytest.mark.parametrize("packed", [False, True])
@@ -72,6 +74,46 @@ def test_vq_nan_code(cb, packed):
     cb2[9000, 1] = float("nan")
     z = synth.synthetic_vq_rows(130, seed=5)
     _check(z, cb2, packed)
+
+
+def test_vq_coarse_pass_error_bound_and_adversarial_near_ties(cb):
+    """The f16 coarse pass is exact only because its error stays inside the window the finalize re-scores (F16_EPS = 2^-17 in
+    csrc/vq.hip).  (i) measure |coarse - canonical| with the same arithmetic through hipBLASLt (fp16 hi/lo of the 2^7-scaled
+    operands, three products, fp32 accumulate); (ii) rows built to sit ON decision boundaries: midpoints of code pairs in the
+    same and in different tiles / halves / splits, so that the top two canonical scores differ by a few ulps or tie exactly."""
+    from oracle import clib
+    x = torch.nn.functional.normalize(synth.synthetic_vq_rows(4096, seed=0xB0D), dim=-1).cuda()
+    e = cb.cuda()
+
+    def split(t):
+        ts = t * 128.0
+        hi = ts.half()
+        return hi, (ts - hi.float()).half()
+    x0, x1 = split(x)
+    e0, e1 = split(e)
+    coarse = (torch.mm(x0, e0.t(), out_dtype=torch.float32) + torch.mm(x0, e1.t(), out_dtype=torch.float32)
+              + torch.mm(x1, e0.t(), out_dtype=torch.float32)) / 16384.0
+    exact = torch.from_numpy(clib.vq_scores(x.cpu().numpy(), cb.numpy()[:4096])).cuda()
+    err = float((coarse[:, :4096] - exact).abs().max())
+    print(f"max |coarse - canonical| over 1.7e7 scores: {err:.3e}  (F16_EPS = 2^-17 = 7.6e-6)")
+    assert err < 2.0 ** -17 / 8
+    # adversarial rows
+    pairs = [(5, 9), (5, 5 + 4), (7, 33), (100, 32000), (31, 32), (0, 32767), (12345, 12345 + 16), (2048, 2048 + 1024)]
+    rows = []
+    for a, b in pairs:
+        mid = cb[a] + cb[b]
+        rows += [mid, mid * 0.37, mid + 1e-7 * cb[a], mid - 1e-7 * cb[a], mid + 3e-6 * cb[b]]
+    cb2 = cb.clone()
+    cb2[20001] = cb2[77]                                   # exact duplicates far apart: lowest index must win through the re-score
+    rows += [cb2[77] * 2.0, cb2[77] + cb2[20001]]
+    z = torch.stack(rows)
+    for book in (cb, cb2):
+        ids_ref, best_ref = clib.vq_encode(z.numpy(), book.numpy())
+        pk = ops.vq_pack_codebook(book.cuda())
+        for sp in (0, 1, 2, 64):
+            ids, best = ops.vq_encode(z.cuda(), pk, packed=True, return_best=True, coarse=True, split=sp)
+            np.testing.assert_array_equal(ids.cpu().numpy(), ids_ref, err_msg=f"split={sp}")
+            np.testing.assert_array_equal(best.cpu().numpy().view(np.uint32), best_ref.view(np.uint32))
 
 
 def test_vq_int32_ids_and_batch_shape(cb):
@@ -129,11 +171,12 @@ def test_vq_mfma_every_launch_shape_full_n(cb, n):
     combos = [(0, 0)] + [(rt, sp) for rt in (1, 2, 4) for sp in (0, 1, 7, 64)]
     if n > 32768:                                         # keep the big sizes to the variants that differ in code path
         combos = [(0, 0), (1, 0), (2, 7), (4, 64), (4, 1)]
-    for rt, sp in combos:
-        ids, best = ops.vq_encode(zc, pk, packed=True, return_best=True, rt=rt, split=sp)
-        torch.cuda.synchronize()
-        assert np.array_equal(ids.cpu().numpy(), ids_ref), f"ids differ at N={n} rt={rt} split={sp}"
-        assert np.array_equal(best.cpu().numpy().view(np.uint32), best_ref.view(np.uint32)), f"top-1 score bits differ at N={n} rt={rt} split={sp}"
+    for coarse in (True, False):                          # f16 coarse pass + exact re-score / fp32-input MFMA kernel
+        for rt, sp in combos:
+            ids, best = ops.vq_encode(zc, pk, packed=True, return_best=True, rt=rt, split=sp, coarse=coarse)
+            torch.cuda.synchronize()
+            assert np.array_equal(ids.cpu().numpy(), ids_ref), f"ids differ at N={n} rt={rt} split={sp} coarse={coarse}"
+            assert np.array_equal(best.cpu().numpy().view(np.uint32), best_ref.view(np.uint32)), f"score bits differ at N={n} rt={rt} split={sp} coarse={coarse}"
     ids_v = ops.vq_encode(zc, cb.cuda())                  # the generic VALU kernel on the same rows
     assert np.array_equal(ids_v.cpu().numpy(), ids_ref)
 

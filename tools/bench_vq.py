@@ -8,22 +8,22 @@ cb = W._synth_tensor("encoder.quantizer._codebook.embed", (1, 32768, 16), "cpu")
 pk = ops.vq_pack_codebook(cb)
 for n in (512, 32768, 65536, 131072):
     z = synth.synthetic_vq_rows(n, device="cuda")
-    for packed, name in ((False, "valu"), (True, "mfma")):
+    for packed, name, coarse in ((False, "valu", None), (True, "mfma-fp32", False), (True, "f16-coarse+exact", True)):
         c = pk if packed else cb
         for _ in range(3):
-            ops.vq_encode(z, c, packed=packed)
+            ops.vq_encode(z, c, packed=packed, coarse=coarse)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         iters = 20
         for _ in range(iters):
-            ops.vq_encode(z, c, packed=packed)
+            ops.vq_encode(z, c, packed=packed, coarse=coarse)
         e.record(); torch.cuda.synchronize()
         ms = s.elapsed_time(e) / iters
         fl = 2.0 * n * 32768 * 16
         rec = {"kernel": name, "N": n, "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1)}
         if packed:
-            ids, lm, lf = ops.vq_encode_split_launch(z, pk)
+            ids, lm, lf = ops.vq_encode_split_launch(z, pk, coarse=coarse)
             lm(); lf(); torch.cuda.synchronize()
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             tm = tf = 0.0
