@@ -981,8 +981,12 @@ int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, vo
         int rt = N >= 8192 ? 4 : (N >= 2048 ? 2 : 1);
         { const int f_rt = (flags >> 8) & 0xF; if (f_rt == 1 || f_rt == 2 || f_rt == 4) rt = f_rt; }
         const int row_blocks = (N + 128 * rt - 1) / (128 * rt);
-        int split = 1;
-        while (row_blocks * split < 512 && split < 64 && ntiles / (split * 2) >= 16) split *= 2;
+        // code splits: 64 tiles (2048 codes) per split -- the exact re-scan of a flagged stream walks its tiles one after the other,
+        // so stream length, not occupancy, sets the finalize time (measured at N = 32768: 8 / 16 / 32 splits -> 0.129 / 0.115 /
+        // 0.112 ms in total, tools/sweep_vq_f16.py); small batches split further to fill the chip
+        int split = ntiles / 64 > 0 ? ntiles / 64 : 1;
+        while (row_blocks * split < 512 && split < 64 && ntiles / (split * 2) >= 8) split *= 2;
+        if (split > 64) split = 64;
         { const int f_split = (flags >> 16) & 0xFF; if (f_split > 0 && f_split <= 64) split = f_split; }
         const int tps = (ntiles + split - 1) / split;
         split = (ntiles + tps - 1) / tps;
