@@ -13,7 +13,7 @@ IDS_I32 = 1
 PRENORMED = 2
 VQ_F16COARSE = 8     # packed path: f16 coarse pass + exact fp32 re-score (same ids / score bits, ~4x faster than the fp32-MFMA kernel)
 VQ_DEFAULT_COARSE = True
-VQ_EVENTS = None     # bench.py sets this to a list: vq_encode(packed=True) then appends (start, end) HIP events around the argmax kernel
+VQ_EVENTS = None     # bench.py sets this to a list: vq_encode(packed=True) then appends (start, after main kernel, after finalize) HIP events
 
 
 def _stream():
@@ -63,12 +63,13 @@ def vq_encode(z: torch.Tensor, codebook: torch.Tensor, *, packed: bool = False, 
     if packed and VQ_EVENTS is not None and not return_best and not prenormed and z.numel() > 0:
         # same two launches as selftok_vq_encode_packed_f32, with HIP events around the argmax kernel on its launch stream
         ids, launch_main, launch_fin = vq_encode_split_launch(z, codebook, ids_dtype, coarse=use_coarse)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
         launch_main()
         e1.record()
         launch_fin()
-        VQ_EVENTS.append((e0, e1))
+        e2.record()
+        VQ_EVENTS.append((e0, e1, e2))
         return ids
     zz = z.contiguous().float().reshape(-1, z.shape[-1])
     N, D = zz.shape

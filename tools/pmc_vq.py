@@ -7,6 +7,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 cb = W._synth_tensor("encoder.quantizer._codebook.embed", (1, 32768, 16), "cpu")[0].contiguous().cuda()
 pk = ops.vq_pack_codebook(cb)
 z = synth.synthetic_vq_rows(n, device="cuda")
+coarse = not (len(sys.argv) > 2 and sys.argv[2] == "fp32")      # default: f16 coarse pass + exact re-score; "fp32": round-1 kernel
 for _ in range(5):
-    ops.vq_encode(z, pk, packed=True)
+    ops.vq_encode(z, pk, packed=True, coarse=coarse)
 torch.cuda.synchronize()
