@@ -245,7 +245,7 @@ def token_match(pipe, images, tokens_gpu, sd_gpu, vsd_gpu, K, n_check=4):
         z = enc.features(x0)
         ids_gpu = tokens_gpu.cpu().numpy()
         cb = enc.codebook.cpu().numpy()
-        ids_c, _ = clib.vq_encode(z.reshape(-1, 16).cpu().numpy(), cb)
+        ids_c, _ = clib.vq_encode_mt(z.reshape(-1, 16).cpu().numpy(), cb)          # every row, threaded over row chunks
         kb = float((ids_c.reshape(ids_gpu.shape) == ids_gpu).mean())
         sd = {k: v.detach().cpu() for k, v in sd_gpu.items() if k.startswith("encoder.")}
         vsd = {k: v.detach().cpu() for k, v in vsd_gpu.items() if k.startswith("encoder.") or k.startswith("quant_conv")}
