@@ -15,14 +15,15 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_kernels_compile_for_gfx950_without_scratch(tmp_path):
     import __graft_entry__ as G
-    srcs = sorted(glob.glob(os.path.join(G.CSRC, "*.hip")))
-    assert len(srcs) >= 5
-    flags = [f for f in G.HIPCC_FLAGS if f not in ("-shared",)]
-    cmd = [HIPCC] + flags + ["-shared", "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(ROOT, "include"),
-                             "-o", str(tmp_path / "lib.so")] + srcs
-    out = subprocess.run(cmd, cwd=G.CSRC, capture_output=True, text=True)
-    assert out.returncode == 0, out.stderr[-2000:]
-    text = out.stderr
+    objs, link = G.compile_commands(objdir=str(tmp_path), lib=str(tmp_path / "lib.so"), extra=["-Rpass-analysis=kernel-resource-usage"])
+    assert len(objs) >= 5
+    procs = [subprocess.Popen(cmd, cwd=G.CSRC, stderr=subprocess.PIPE, text=True) for _, _, cmd in objs]
+    text = ""
+    for p in procs:
+        err = p.communicate()[1]
+        assert p.returncode == 0, err[-2000:]
+        text += err
+    assert subprocess.run(link, cwd=G.CSRC, capture_output=True).returncode == 0
     names = re.findall(r"Function Name: (\S+)", text)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", text)]
     vgprs = [int(x) for x in re.findall(r" VGPRs: (\d+)", text)]
@@ -32,6 +33,6 @@ def test_kernels_compile_for_gfx950_without_scratch(tmp_path):
     assert max(vgprs) <= 256
     # the hot kernels exist under their documented names
     joined = " ".join(names)
-    for k in ("vq_mfma_kernel", "vq_valu_kernel", "vq_finalize_packed_kernel", "attn64_kernel", "residual_ln_mod_kernel",
+    for k in ("linear_f16x2_kernel", "attn64_f16x2_kernel", "vq_f16_kernel", "vq_mfma_kernel", "vq_valu_kernel", "vq_finalize_packed_kernel", "attn64_kernel", "residual_ln_mod_kernel",
               "unpatchify_euler_kernel", "groupnorm_silu_bf16_kernel", "code_gather_ln_kernel"):
         assert k in joined, k
