@@ -33,6 +33,8 @@ struct AttnSeg {
     const float* k;
     const float* v;
     float* o;
+    _Float16* o_hi;   // f16x2 kernel: split-activation output planes (or NULL)
+    _Float16* o_lo;
     int len;          // rows in this segment
     long q_rs, k_rs, v_rs, o_rs;   // row strides (floats)
     long q_bs, k_bs, v_bs, o_bs;   // batch strides (floats)
@@ -277,6 +279,14 @@ __device__ __forceinline__ HiLo split_pair(float a, float b)
     const h16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), h16x2);         // 2 cvt + v_pk_add + v_cvt_pk
     return HiLo{__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, l)};
 }
+// the Linear kernels' form of the split (gemm_split.hip `split4`): the residual is carried scaled by 2^11
+__device__ __forceinline__ HiLo split_pair_scaled(float a, float b)
+{
+    const f32x2 x = {a, b};
+    const h16x2 h = __builtin_convertvector(x, h16x2);
+    const h16x2 l = __builtin_convertvector((x - __builtin_convertvector(h, f32x2)) * 2048.0f, h16x2);
+    return HiLo{__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, l)};
+}
 __device__ __forceinline__ h16x8 as_h8(const u32x4& v) { return __builtin_bit_cast(h16x8, v); }
 
 __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int* __restrict__ overflow)
@@ -479,15 +489,21 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
     for (int r = 0; r < 16; ++r) { chk = __builtin_fmaf(o0[r], 0.f, chk); chk = __builtin_fmaf(o1[r], 0.f, chk); }
     if (overflow && row_ok && chk != 0.f) atomicOr(overflow, 4);
     if (row_ok) {
-        float* op = qs.o + (size_t)b * qs.o_bs + (size_t)my_row * qs.o_rs + h * 64;
+        const size_t off = (size_t)b * qs.o_bs + (size_t)my_row * qs.o_rs + h * 64;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
                 // registers a + 4 bb (+8): d' = a + 8 bb + 4 half (+16)  ->  d = 4 (a + 8 bb + 4 half) + {0, 1} + 2 db
                 const int r = a + 4 * bb;
-                *reinterpret_cast<float4*>(op + 4 * (a + 8 * bb + 4 * half)) =
-                    make_float4(o0[r] * inv, o0[r + 8] * inv, o1[r] * inv, o1[r + 8] * inv);
+                const int d = 4 * (a + 8 * bb + 4 * half);
+                if (qs.o_hi) {       // split activation for the proj Linear (gemm_split.hip); |o| <= max |v| < 65504 here
+                    const HiLo ab = split_pair_scaled(o0[r] * inv, o0[r + 8] * inv), cd = split_pair_scaled(o1[r] * inv, o1[r + 8] * inv);
+                    *reinterpret_cast<uint2*>(qs.o_hi + off + d) = make_uint2(ab.hi, cd.hi);
+                    *reinterpret_cast<uint2*>(qs.o_lo + off + d) = make_uint2(ab.lo, cd.lo);
+                } else {
+                    *reinterpret_cast<float4*>(qs.o + off + d) = make_float4(o0[r] * inv, o0[r + 8] * inv, o1[r] * inv, o1[r + 8] * inv);
+                }
             }
     }
 }
@@ -559,9 +575,11 @@ int selftok_attn_f32(const selftok_attn_desc* d, hipStream_t stream)
         AttnParams P;
         for (int s = 0; s < 2; ++s) {
             const selftok_attn_seg& a = d->seg[s];
-            if (a.len < 0 || (a.len > 0 && (!a.k || !a.v)) || (a.q && !a.o)) { set_last_error("attn: bad segment"); return SELFTOK_EINVAL; }
+            const bool osplit = d->mode == SELFTOK_ATTN_F16X2 && d->o_hi[s] != nullptr;
+            if ((d->o_hi[s] == nullptr) != (d->o_lo[s] == nullptr) || (d->o_hi[s] && d->mode != SELFTOK_ATTN_F16X2)) { set_last_error("attn: split outputs need both planes and the f16x2 mode"); return SELFTOK_EINVAL; }
+            if (a.len < 0 || (a.len > 0 && (!a.k || !a.v)) || (a.q && !a.o && !osplit)) { set_last_error("attn: bad segment"); return SELFTOK_EINVAL; }
             if (((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.q_bs | a.k_bs | a.v_bs | a.o_bs) & 3) != 0) { set_last_error("attn: strides must be multiples of 4 floats"); return SELFTOK_EINVAL; }
-            P.seg[s] = AttnSeg{a.len > 0 ? a.q : nullptr, a.k, a.v, a.o, a.len, a.q_rs, a.k_rs, a.v_rs, a.o_rs, a.q_bs, a.k_bs, a.v_bs, a.o_bs};
+            P.seg[s] = AttnSeg{a.len > 0 ? a.q : nullptr, a.k, a.v, a.o, (_Float16*)d->o_hi[s], (_Float16*)d->o_lo[s], a.len, a.q_rs, a.k_rs, a.v_rs, a.o_rs, a.q_bs, a.k_bs, a.v_bs, a.o_bs};
         }
         P.B = d->B; P.H = d->H; P.kvis = d->kvis; P.seg0_sees_seg1 = d->seg0_sees_seg1; P.scale = d->scale;
         int t0 = P.seg[0].q ? (P.seg[0].len + QROWS - 1) / QROWS : 0;

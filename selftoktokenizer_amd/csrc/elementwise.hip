@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void residual_ln_mod_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gate,
     const float* __restrict__ shift, const float* __restrict__ scale,
     float* __restrict__ x_out, float* __restrict__ n_out,
-    int rows, int T, long mod_stride_b, long mod_stride_t, long gate_stride_b, long gate_stride_t, float eps)
+    int rows, int T, long mod_stride_b, long mod_stride_t, long gate_stride_b, long gate_stride_t, float eps,
+    _Float16* __restrict__ n_hi = nullptr, _Float16* __restrict__ n_lo = nullptr, int* __restrict__ overflow = nullptr)
 {
     constexpr int H = G * VPL * 4;
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / G;   // row
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void residual_ln_mod_kernel(
             for (int i = 0; i < VPL; ++i) st4(xo + (i * G + gl) * 4, v[i]);
         }
     }
-    if (!n_out) return;
+    if (!n_out && !n_hi) return;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(256) void residual_ln_mod_kernel(
     }
     const float var = group_sum<G>(q) * (1.0f / H);
     const float rstd = 1.0f / __builtin_sqrtf(var + eps);
-    float* nr = n_out + (size_t)gid * H;
+    float* nr = n_out ? n_out + (size_t)gid * H : nullptr;
+    float mx = 0.f;
     const float* sh = shift ? shift + b * mod_stride_b + t * mod_stride_t : nullptr;
     const float* sc = scale ? scale + b * mod_stride_b + t * mod_stride_t : nullptr;
 #pragma unroll
@@ -96,8 +98,19 @@ __global__ __launch_bounds__(256) void residual_ln_mod_kernel(
             o.x = o.x * (1.0f + c4.x) + s4.x; o.y = o.y * (1.0f + c4.y) + s4.y;
             o.z = o.z * (1.0f + c4.z) + s4.z; o.w = o.w * (1.0f + c4.w) + s4.w;
         }
-        st4(nr + (i * G + gl) * 4, o);
+        if (nr) st4(nr + (i * G + gl) * 4, o);
+        if (n_hi) {      // "split activation" for the f16x2 Linear that consumes n (gemm_split.hip): hi = fp16(n), lo = fp16((n - hi) 2^11)
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 ov = {o.x, o.y, o.z, o.w};
+            const h4 hh = __builtin_convertvector(ov, h4);
+            const h4 ll = __builtin_convertvector((ov - __builtin_convertvector(hh, f4)) * 2048.0f, h4);
+            *reinterpret_cast<h4*>(n_hi + (size_t)gid * H + (i * G + gl) * 4) = hh;
+            *reinterpret_cast<h4*>(n_lo + (size_t)gid * H + (i * G + gl) * 4) = ll;
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+        }
     }
+    if (n_hi && overflow && !(mx < 65504.0f)) atomicOr(overflow, 1);
 }
 
 // in-place  h = gelu_tanh(h + bias)   (timm / sd3 Mlp act: modules.py:109,293 ; sd3/other_impls.py:82-90)
@@ -266,12 +279,13 @@ static inline int grid_for(long n, int block = 256, int cap = 256 * 16)
 
 extern "C" {
 
-int selftok_residual_ln_mod_f32(const float* x, const float* y, const float* gate, const float* shift, const float* scale,
-                                float* x_out, float* n_out, int B, int T, int H,
-                                long mod_stride_b, long mod_stride_t, long gate_stride_b, long gate_stride_t,
-                                float eps, hipStream_t stream)
+static int residual_ln_mod_launch(const float* x, const float* y, const float* gate, const float* shift, const float* scale,
+                                  float* x_out, float* n_out, _Float16* n_hi, _Float16* n_lo, int* overflow, int B, int T, int H,
+                                  long mod_stride_b, long mod_stride_t, long gate_stride_b, long gate_stride_t,
+                                  float eps, hipStream_t stream)
 {
-    if (!x || B < 0 || T < 0 || (shift == nullptr) != (scale == nullptr) || (!n_out && !(y && x_out))) {
+    if (!x || B < 0 || T < 0 || (shift == nullptr) != (scale == nullptr) || (n_hi == nullptr) != (n_lo == nullptr)
+        || (!n_out && !n_hi && !(y && x_out))) {
         set_last_error("residual_ln_mod: bad argument");
         return SELFTOK_EINVAL;
     }
@@ -280,7 +294,7 @@ int selftok_residual_ln_mod_f32(const float* x, const float* y, const float* gat
 #define LAUNCH(G, VPL)                                                                                                  \
     hipLaunchKernelGGL((residual_ln_mod_kernel<G, VPL>), dim3((rows + (256 / G) - 1) / (256 / G)), dim3(256), 0, stream, \
                        x, y, gate, shift, scale, x_out, n_out, rows, T, mod_stride_b, mod_stride_t, gate_stride_b,      \
-                       gate_stride_t, eps)
+                       gate_stride_t, eps, n_hi, n_lo, overflow)
     switch (H) {
         case 64: LAUNCH(16, 1); break;
         case 512: LAUNCH(64, 2); break;
@@ -291,6 +305,25 @@ int selftok_residual_ln_mod_f32(const float* x, const float* y, const float* gat
     }
 #undef LAUNCH
     return check_launch("residual_ln_mod_kernel");
+}
+
+int selftok_residual_ln_mod_f32(const float* x, const float* y, const float* gate, const float* shift, const float* scale,
+                                float* x_out, float* n_out, int B, int T, int H,
+                                long mod_stride_b, long mod_stride_t, long gate_stride_b, long gate_stride_t,
+                                float eps, hipStream_t stream)
+{
+    return residual_ln_mod_launch(x, y, gate, shift, scale, x_out, n_out, nullptr, nullptr, nullptr, B, T, H,
+                                  mod_stride_b, mod_stride_t, gate_stride_b, gate_stride_t, eps, stream);
+}
+
+int selftok_residual_ln_mod_split(const float* x, const float* y, const float* gate, const float* shift, const float* scale,
+                                  float* x_out, void* n_hi, void* n_lo, int* overflow, int B, int T, int H,
+                                  long mod_stride_b, long mod_stride_t, long gate_stride_b, long gate_stride_t,
+                                  float eps, hipStream_t stream)
+{
+    if (!n_hi || !n_lo) { set_last_error("residual_ln_mod_split: null output plane"); return SELFTOK_EINVAL; }
+    return residual_ln_mod_launch(x, y, gate, shift, scale, x_out, nullptr, (_Float16*)n_hi, (_Float16*)n_lo, overflow, B, T, H,
+                                  mod_stride_b, mod_stride_t, gate_stride_b, gate_stride_t, eps, stream);
 }
 
 int selftok_bias_gelu_f32(float* h, const float* bias, long rows, int cols, hipStream_t stream)

@@ -317,6 +317,203 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_kernel(const float* __res
     if (overflow && chk != 0.f) atomicOr(overflow, 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Same product with the activations ALREADY split by the kernel that produced them (residual_ln_mod, the attention epilogue,
+// or this kernel's own GELU epilogue): A arrives as two row-major fp16 planes (hi, lo; same 4 bytes per element as fp32), so the
+// activation tile reaches LDS by LDS-DMA exactly like the weight tile -- no register staging, no VALU split, no ds_write, no
+// counted waits on registers.  The split is the same function of the fp32 value as `split4`, so the results are bit-identical
+// to linear_f16x2_kernel on the un-split tensor.
+//
+// LDS image of an activation tile: [plane][row 0..255][4 slots of 16 B], slot = k-group ^ ((row >> 2) & 3).  A DMA instruction
+// writes 1 KiB = 16 rows x 4 slots in lane order (that is all the hardware offers: M0 base + lane * 16), so the swizzle is applied
+// on the SOURCE side: lane (row, slot) fetches k-group slot ^ ((row >> 2) & 3) of its row -- still the same 64 B segment of that row.
+// A fragment read (32 rows x one k-group per half wave) then touches each of the 64 banks once per 16 lanes.
+// Rings: 3 activation stages (32 KiB) + 4 weight stages (16 KiB) = the CU's whole 160 KiB; the DMAs of activation tile kt+2 and
+// weight tile kt+3 are issued at the top of iteration kt into the stages iteration kt-1 released at its barrier.
+constexpr int PA_ROW = 64;                       // bytes per row and plane of a 32-deep k-tile
+constexpr int PA_P = BM * PA_ROW;                // 16384
+constexpr int PA_BYTES = 2 * PA_P;               // 32768
+constexpr int PA_STAGES = 3, PW_STAGES = 4;
+constexpr int PW_BASE = PA_STAGES * PA_BYTES;    // 98304
+constexpr int P_LDS_BYTES = PW_BASE + PW_STAGES * W_BYTES;   // 163840
+
+template <int ACT, int OSPLIT>
+__global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo, long lda,
+                                                                  const _Float16* __restrict__ Wp, const float* __restrict__ bias,
+                                                                  float* __restrict__ out, _Float16* __restrict__ ohi, _Float16* __restrict__ olo, long ldo,
+                                                                  int M, int N, int K, int* __restrict__ overflow, int mblocks, int nblocks)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[P_LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int mb, nb;
+    {
+        const int T = gridDim.x, orig = blockIdx.x;
+        const int q8 = T >> 3, r8 = T & 7, xcd = orig & 7, idx = orig >> 3;
+        const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        const int per_group = GROUP_M * nblocks;
+        const int group = w / per_group, first_m = group * GROUP_M;
+        const int gsz = (mblocks - first_m) < GROUP_M ? (mblocks - first_m) : GROUP_M;
+        const int in = w - group * per_group;
+        mb = first_m + in % gsz;
+        nb = in / gsz;
+    }
+    const int m0 = mb * BM, n0 = nb * BN;
+    const int KT = K / BK, KL = KT - 1;
+
+    // ---- DMA maps: wave w moves rows 16w..16w+15 and 128+16w.. of both planes (4 instructions) and 2 KiB of the weight tile ----
+    const int d_g = (lane & 3) ^ ((lane >> 4) & 3);                 // source k-group of LDS slot (lane & 3) in row (lane >> 2)
+    int r0 = m0 + wave * 16 + (lane >> 2), r1 = r0 + 128;
+    r0 = r0 < M ? r0 : M - 1;                                       // ragged last row block: re-read the last row
+    r1 = r1 < M ? r1 : M - 1;
+    const _Float16* a_src[4] = {Ahi + (size_t)r0 * lda + d_g * 8, Ahi + (size_t)r1 * lda + d_g * 8,
+                                Alo + (size_t)r0 * lda + d_g * 8, Alo + (size_t)r1 * lda + d_g * 8};
+    const _Float16* w_src = Wp + (size_t)nb * KT * (W_BYTES / 2) + (size_t)wave * 512 + lane * 8;
+    auto dma_a = [&](int kt, int stage) {
+        kt = kt < KL ? kt : KL;                                     // past the end: stage the last tile again (nobody reads it)
+        unsigned char* dst = smem + stage * PA_BYTES + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + (size_t)kt * BK),
+                                             (__attribute__((address_space(3))) void*)(dst + (j & 1) * 8192 + (j >> 1) * PA_P), 16, 0, 0);
+    };
+    auto dma_w = [&](int kt, int stage) {
+        kt = kt < KL ? kt : KL;
+        const _Float16* src = w_src + (size_t)kt * (W_BYTES / 2);
+        unsigned char* dst = smem + PW_BASE + stage * W_BYTES + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 8 * 512),
+                                         (__attribute__((address_space(3))) void*)(dst + 8 * 1024), 16, 0, 0);
+    };
+
+    f32x16v hi[2][2], lo[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            hi[i][j] = f32x16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            lo[i][j] = hi[i][j];
+        }
+
+    const int a_frag = (wm * 64 + l31) * PA_ROW + ((lh ^ ((l31 >> 2) & 3)) * 16);   // k-step 1: ^ 32 (k-group + 2); + b*32*64 (+ PA_P)
+    const int w_frag = PW_BASE + lh * W_G + (wn * 64 + l31) * 16;                   // + cb*32*16 + s*2*W_G (+ W_P)
+    f16x8 af0[2][2], wf0[2][2], af1[2][2], wf1[2][2];
+    auto read_frags = [&](f16x8 (&af)[2][2], f16x8 (&wf)[2][2], int a_stage, int w_stage, int s) {
+        const unsigned char* sa = smem + a_stage * PA_BYTES + (a_frag ^ (s * 32));
+        const unsigned char* sw = smem + w_stage * W_BYTES + w_frag + s * 2 * W_G;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                af[b][p] = *reinterpret_cast<const f16x8*>(sa + b * 32 * PA_ROW + p * PA_P);
+                wf[b][p] = *reinterpret_cast<const f16x8*>(sw + b * 32 * 16 + p * W_P);
+            }
+    };
+    auto mfma_row = [&](int i, f16x8 (&af)[2][2], f16x8 (&wf)[2][2]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wf[j][0], hi[i][j], 0, 0, 0);
+                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wf[j][1], lo[i][j], 0, 0, 0);
+                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], wf[j][0], lo[i][j], 0, 0, 0);
+            }
+    };
+
+    // VM ops retire in issue order; per iteration a wave issues 4 activation DMAs (tile kt+2), then 2 weight DMAs (tile kt+3).
+    // At the barrier that ends phase A of iteration kt, tile kt+1 must have landed: its activation DMAs were issued in iteration
+    // kt-1 and may be followed by that iteration's 2 weight DMAs and this iteration's 6 -> vmcnt(8).
+    auto iteration = [&](int kt, int a_cur, int a_next, int a_new, int w_cur, int w_next, int w_new) {
+        dma_a(kt + 2, a_new);
+        dma_w(kt + 3, w_new);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(af1, wf1, a_cur, w_cur, 1);
+        mfma_row(0, af0, wf0);
+        mfma_row(1, af0, wf0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(0, af1, wf1);                                      // matrix work queued before the reads: hipcc waits lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);                          // before the first MFMA that follows a ds_read
+        read_frags(af0, wf0, a_next, w_next, 0);
+        mfma_row(1, af1, wf1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: issue order A0 W0 W1 A1 W2 so that the loop's vmcnt(8) accounting holds from iteration 0 on ----
+    dma_a(0, 0);
+    dma_w(0, 0);
+    dma_w(1, 1);
+    dma_a(1, 1);
+    dma_w(2, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                // tile 0 (4 + 2 oldest) landed; W1, A1, W2 in flight
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(af0, wf0, 0, 0, 0);
+
+    int ac = 0, wc = 0;                                             // kt % 3, kt % 4
+    for (int kt = 0; kt < KT; ++kt) {
+        const int a1 = ac == 2 ? 0 : ac + 1, a2 = a1 == 2 ? 0 : a1 + 1;
+        iteration(kt, ac, a1, a2, wc, (wc + 1) & 3, (wc + 3) & 3);
+        ac = a1;
+        wc = (wc + 1) & 3;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // nothing of mine may still be writing LDS when the wave ends
+
+    // ---- epilogue (as above); OSPLIT: the output is written as the two fp16 planes the next Linear consumes ----
+    float chk = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rbase = m0 + wm * 64 + i * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                float v = hi[i][j][r] + lo[i][j][r] * LO_INV + bv;
+                if (ACT == 1) v = gelu_tanh_f(v);
+                if (row < M) {
+                    if (OSPLIT) {
+                        const _Float16 h = (_Float16)v;
+                        const _Float16 l = (_Float16)((v - (float)h) * LO_SCALE);
+                        ohi[(size_t)row * ldo + col] = h;
+                        olo[(size_t)row * ldo + col] = l;
+                        chk = __builtin_fmaf((float)h, 0.f, chk);     // |v| beyond fp16: h = inf -> flagged here, at the producer
+                    } else {
+                        out[(size_t)row * ldo + col] = v;
+                        chk = __builtin_fmaf(v, 0.f, chk);
+                    }
+                }
+            }
+        }
+    }
+    if (overflow && chk != 0.f) atomicOr(overflow, 1);
+}
+
+// fp32 [rows, cols] (row stride ld) -> the two fp16 planes (stand-alone producer: tests, and inputs that no fused producer writes)
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, long ld, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                         long ldo, long rows, int cols, int* __restrict__ overflow)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = cols / 4;
+    if (idx >= rows * c4) return;
+    const long r = idx / c4;
+    const int c = (int)(idx % c4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+    f16x4 h, l;
+    float mx = 0.f;
+    split4(v, h, l, mx);
+    *reinterpret_cast<f16x4*>(hi + r * ldo + c) = h;
+    *reinterpret_cast<f16x4*>(lo + r * ldo + c) = l;
+    if (!(mx < F16_MAX) && overflow) atomicOr(overflow, 1);
+}
+
 }  // namespace selftok
 
 using namespace selftok;
@@ -359,6 +556,38 @@ int selftok_linear_f16x2_f32(const float* A, long lda, const void* packed, const
     else
         hipLaunchKernelGGL(linear_f16x2_kernel<0>, grid, dim3(512), 0, stream, A, lda, (const _Float16*)packed, bias, out, ldo, M, N, K, overflow, mblocks, nblocks);
     return check_launch("linear_f16x2_kernel");
+}
+
+int selftok_split_f16x2_f32(const float* x, long ld, void* hi, void* lo, long ldo, long rows, int cols, int* overflow, hipStream_t stream)
+{
+    if (rows < 0 || cols <= 0 || (cols & 3) || (ld & 3) || (ldo & 3) || ld < cols || ldo < cols) { set_last_error("split_f16x2: cols, ld, ldo must be multiples of 4, ld/ldo >= cols"); return SELFTOK_EINVAL; }
+    if (rows == 0) return SELFTOK_OK;
+    if (!x || !hi || !lo) { set_last_error("split_f16x2: null pointer"); return SELFTOK_EINVAL; }
+    const long n = rows * (cols / 4);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ld, (_Float16*)hi, (_Float16*)lo, ldo, rows, cols, overflow);
+    return check_launch("split_rows_kernel");
+}
+
+int selftok_linear_f16x2_split(const void* a_hi, const void* a_lo, long lda, const void* packed, const float* bias,
+                               float* out, void* out_hi, void* out_lo, long ldo, int M, int N, int K, int flags, int* overflow, hipStream_t stream)
+{
+    if (M < 0 || N <= 0 || K <= 0 || N % BN || K % BK) { set_last_error("linear_f16x2_split: need N % 128 == 0 and K % 32 == 0"); return SELFTOK_EINVAL; }
+    if (M == 0) return SELFTOK_OK;
+    const bool osplit = out_hi != nullptr || out_lo != nullptr;
+    if (!a_hi || !a_lo || !packed || lda < K || (lda & 7) || ldo < N || ((size_t)a_hi & 15) || ((size_t)a_lo & 15)
+        || (osplit ? (!out_hi || !out_lo || out) : !out)) {
+        set_last_error("linear_f16x2_split: bad pointers/strides (planes 16-byte aligned, lda % 8 == 0, lda >= K, ldo >= N; either out or both out planes)");
+        return SELFTOK_EINVAL;
+    }
+    const int mblocks = (M + BM - 1) / BM, nblocks = N / BN;
+    const dim3 grid((unsigned)(mblocks * nblocks));
+    const _Float16 *ah = (const _Float16*)a_hi, *al = (const _Float16*)a_lo;
+    _Float16 *oh = (_Float16*)out_hi, *ol = (_Float16*)out_lo;
+#define PRE_LAUNCH(ACT, OS) hipLaunchKernelGGL((linear_f16x2_pre_kernel<ACT, OS>), grid, dim3(512), 0, stream, ah, al, lda, (const _Float16*)packed, bias, out, oh, ol, ldo, M, N, K, overflow, mblocks, nblocks)
+    if (flags & SELFTOK_LINEAR_GELU) { if (osplit) PRE_LAUNCH(1, 1); else PRE_LAUNCH(1, 0); }
+    else { if (osplit) PRE_LAUNCH(0, 1); else PRE_LAUNCH(0, 0); }
+#undef PRE_LAUNCH
+    return check_launch("linear_f16x2_pre_kernel");
 }
 
 }  // extern "C"

@@ -33,6 +33,7 @@ from .weights import DIT_DEPTH, DIT_HEADS, DIT_HIDDEN, POS_MAX_DIT
 
 class MMDiTGPU:
     GEMM_MODES = ("fp32", "f16x2")
+    PRESPLIT = True     # f16x2 mode: producers (LN-modulate, attention, fc1+GELU) hand the next Linear its input already split
 
     def __init__(self, sd: Dict[str, torch.Tensor], device, K: int, renderer: bool = False, gemm: str = "fp32"):
         self.device, self.K, self.renderer = device, K, renderer
@@ -84,13 +85,26 @@ class MMDiTGPU:
         self.gemm = mode
         return mode
 
-    def lin(self, name, x, gelu: bool = False):
+    def lin(self, name, x, gelu: bool = False, out_split: bool = False):
+        """x fp32 [..., K], or a split activation (fp16 [2, ..., K], ops.split_f16x2) when `self._pre(name)`; out_split: return
+        the split form for the next Linear (only with a split input)."""
         w, b = self.w[name + ".weight"], self.w[name + ".bias"]
+        if x.dtype == torch.float16:
+            return ops.linear_f16x2_split(x, self._packed[name], b, w.shape[0], gelu=gelu, overflow=self.overflow, out_split=out_split)
+        assert not out_split
         if self.gemm == "f16x2" and name in self._packed:
             return ops.linear_f16x2(x, self._packed[name], b, w.shape[0], gelu=gelu, overflow=self.overflow)
         if gelu:
             return ops.linear_gelu(x, w, b)
         return F.linear(x, w, b)
+
+    def _pre(self, name) -> bool:
+        """does Linear `name` take its input as a split activation?"""
+        return self.PRESPLIT and self.gemm == "f16x2" and name in self._packed
+
+    def _ln(self, consumer, x, **kw):
+        """residual_ln_mod whose normalised output feeds Linear `consumer`: split form if that Linear takes it"""
+        return ops.residual_ln_mod(x, split=self._pre(consumer), overflow=self.overflow, **kw)
 
     def _pos_bias(self, h: int, w: int) -> torch.Tensor:
         key = (h, w)
@@ -121,7 +135,7 @@ class MMDiTGPU:
         x_t or t), so the sampler computes it once per decode instead of once per step (the reference recomputes it)."""
         H = DIT_HIDDEN
         t0 = self.ctx_tables[0][: ctx0.shape[1]]
-        _, cn = ops.residual_ln_mod(ctx0, shift=t0[:, 0:H], scale=t0[:, H:2 * H])
+        _, cn = self._ln("model.joint_blocks.0.context_block.attn.qkv", ctx0, shift=t0[:, 0:H], scale=t0[:, H:2 * H])
         return self.lin("model.joint_blocks.0.context_block.attn.qkv", cn)
 
     @torch.no_grad()
@@ -140,14 +154,21 @@ class MMDiTGPU:
         mods_f = self.lin("model.final_layer.adaLN_modulation.1", sc)                                              # [B,2H]
         tab = [t[:n] for t in self.ctx_tables]
         x = xe
-        _, xn = ops.residual_ln_mod(x, shift=mods_x[0][:, 0:H], scale=mods_x[0][:, H:2 * H], per_sample=True)
+        blk = "model.joint_blocks.{}.{}_block.{}".format
+
+        def attn_out(rows, consumer, zero=False):   # attention output buffer: split planes if the proj Linear takes them
+            if self._pre(consumer) and amode:
+                return (torch.zeros if zero else torch.empty)(2, B, rows, H, device=x.device, dtype=torch.float16)
+            return (torch.zeros if zero else torch.empty)(B, rows, H, device=x.device)
+
+        _, xn = self._ln(blk(0, "x", "attn.qkv"), x, shift=mods_x[0][:, 0:H], scale=mods_x[0][:, H:2 * H], per_sample=True)
         if has_ctx and cqkv0 is None:
-            _, cn = ops.residual_ln_mod(ctx, shift=tab[0][:, 0:H], scale=tab[0][:, H:2 * H])
+            _, cn = self._ln(blk(0, "context", "attn.qkv"), ctx, shift=tab[0][:, 0:H], scale=tab[0][:, H:2 * H])
         for i in range(DIT_DEPTH):
             pc, px = f"model.joint_blocks.{i}.context_block", f"model.joint_blocks.{i}.x_block"
             last = i == DIT_DEPTH - 1
             xqkv = self.lin(px + ".attn.qkv", xn)                                  # [B,nx,3H]
-            ox = torch.empty(B, nx, H, device=x.device)
+            ox = attn_out(nx, px + ".attn.proj")
             seg1 = (xqkv[..., :H], xqkv[..., H:2 * H], xqkv[..., 2 * H:], ox)
             if has_ctx:
                 # [B,n,3H]; block 0's is step-invariant and may come precomputed (a strided [:, :n] view is fine)
@@ -155,7 +176,7 @@ class MMDiTGPU:
                 if last:   # pre_only context block: keys/values only, its attention output is discarded (sd3/mmdit.py:544-547)
                     seg0 = (None, cqkv[..., H:2 * H], cqkv[..., 2 * H:], None)
                 else:
-                    oc = (torch.zeros if kvis is not None else torch.empty)(B, n, H, device=x.device)
+                    oc = attn_out(n, pc + ".attn.proj", zero=kvis is not None)
                     seg0 = (cqkv[..., :H], cqkv[..., H:2 * H], cqkv[..., 2 * H:], oc)
                 ops.attention(seg0, seg1, NH, 64, kvis=kvis, seg0_sees_seg1=seg0_sees_seg1, mode=amode, overflow=self.overflow)
             else:
@@ -163,25 +184,26 @@ class MMDiTGPU:
             # ---- context stream post-attention (sd3/mmdit.py:485-496, 'pos_emb') ----
             if has_ctx and not last:
                 t = tab[i]
-                ctx, cn2 = ops.residual_ln_mod(ctx, y=self.lin(pc + ".attn.proj", oc), gate=t[:, 2 * H:3 * H],
-                                               shift=t[:, 3 * H:4 * H], scale=t[:, 4 * H:5 * H])
-                h = self.lin(pc + ".mlp.fc1", cn2, gelu=True)
+                ctx, cn2 = self._ln(pc + ".mlp.fc1", ctx, y=self.lin(pc + ".attn.proj", oc), gate=t[:, 2 * H:3 * H],
+                                    shift=t[:, 3 * H:4 * H], scale=t[:, 4 * H:5 * H])
+                h = self.lin(pc + ".mlp.fc1", cn2, gelu=True, out_split=cn2.dtype == torch.float16 and self._pre(pc + ".mlp.fc2"))
                 m = self.lin(pc + ".mlp.fc2", h)
+                nq = blk(i + 1, "context", "attn.qkv")
                 if i + 1 < DIT_DEPTH - 1:
                     tn = tab[i + 1]
-                    ctx, cn = ops.residual_ln_mod(ctx, y=m, gate=t[:, 5 * H:6 * H], shift=tn[:, 0:H], scale=tn[:, H:2 * H])
+                    ctx, cn = self._ln(nq, ctx, y=m, gate=t[:, 5 * H:6 * H], shift=tn[:, 0:H], scale=tn[:, H:2 * H])
                 else:      # next block is the pre_only one: modulated per sample by c (sd3/mmdit.py:476-483)
-                    ctx, cn = ops.residual_ln_mod(ctx, y=m, gate=t[:, 5 * H:6 * H], gate_per_sample=False,
-                                                  shift=mods_c_last[:, 0:H], scale=mods_c_last[:, H:2 * H], per_sample=True)
+                    ctx, cn = self._ln(nq, ctx, y=m, gate=t[:, 5 * H:6 * H], gate_per_sample=False,
+                                       shift=mods_c_last[:, 0:H], scale=mods_c_last[:, H:2 * H], per_sample=True)
             # ---- image stream post-attention ('t_emb') ----
             mx = mods_x[i]
-            x, xn2 = ops.residual_ln_mod(x, y=self.lin(px + ".attn.proj", ox), gate=mx[:, 2 * H:3 * H],
-                                         shift=mx[:, 3 * H:4 * H], scale=mx[:, 4 * H:5 * H], per_sample=True)
-            h = self.lin(px + ".mlp.fc1", xn2, gelu=True)
+            x, xn2 = self._ln(px + ".mlp.fc1", x, y=self.lin(px + ".attn.proj", ox), gate=mx[:, 2 * H:3 * H],
+                              shift=mx[:, 3 * H:4 * H], scale=mx[:, 4 * H:5 * H], per_sample=True)
+            h = self.lin(px + ".mlp.fc1", xn2, gelu=True, out_split=xn2.dtype == torch.float16 and self._pre(px + ".mlp.fc2"))
             m = self.lin(px + ".mlp.fc2", h)
             if not last:
                 mn = mods_x[i + 1]
-                x, xn = ops.residual_ln_mod(x, y=m, gate=mx[:, 5 * H:6 * H], shift=mn[:, 0:H], scale=mn[:, H:2 * H], per_sample=True)
+                x, xn = self._ln(blk(i + 1, "x", "attn.qkv"), x, y=m, gate=mx[:, 5 * H:6 * H], shift=mn[:, 0:H], scale=mn[:, H:2 * H], per_sample=True)
             else:          # FinalLayer: LN + modulate(shift, scale = adaLN(c).chunk(2)) + Linear (sd3/mmdit.py:641-645)
                 x, xn = ops.residual_ln_mod(x, y=m, gate=mx[:, 5 * H:6 * H], shift=mods_f[:, 0:H], scale=mods_f[:, H:2 * H], per_sample=True)
         return self.lin("model.final_layer.linear", xn)

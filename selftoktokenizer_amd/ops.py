@@ -140,10 +140,11 @@ def code_gather_ln(ids: torch.Tensor, codebook: torch.Tensor, ln_w=None, ln_b=No
 # ----------------------------------------------------------------------------------------------
 
 def residual_ln_mod(x, *, y=None, gate=None, shift=None, scale=None, per_sample=False, gate_per_sample=None,
-                    want_x=True, want_n=True, eps=1e-6):
+                    want_x=True, want_n=True, eps=1e-6, split=False, overflow=None):
     """x' = x + gate*y ; n = LN(x')*(1+scale)+shift.   x,y [B,T,H].  shift/scale/gate are 2-D views
     [T,H] (per token, default) or [B,H] (per_sample=True) -- typically column slices of a [*,6H] table.
-    Returns (x', n) (either may be None)."""
+    Returns (x', n) (either may be None).  split=True: n comes back as a split activation (fp16 [2,B,T,H], see split_f16x2)
+    for linear_f16x2_split; `overflow` bit 0 is raised if |n| >= 65504."""
     _need_cuda(x)
     B, T, H = x.shape
     assert x.is_contiguous() and x.dtype == torch.float32
@@ -161,6 +162,11 @@ def residual_ln_mod(x, *, y=None, gate=None, shift=None, scale=None, per_sample=
     if y is not None:
         assert y.is_contiguous() and y.shape == x.shape
     x_out = torch.empty_like(x) if (y is not None and want_x) else None
+    if split and want_n:
+        n_s = torch.empty(2, B, T, H, dtype=torch.float16, device=x.device)
+        _lib.check(_lib.load().selftok_residual_ln_mod_split(_p(x), _p(y), _p(gate), _p(shift), _p(scale), _p(x_out), _p(n_s[0]), _p(n_s[1]),
+                                                             _p(overflow), B, T, H, msb, mst, gsb, gst, eps, _stream()), "selftok_residual_ln_mod_split")
+        return (x_out if y is not None else x), n_s
     n_out = torch.empty_like(x) if want_n else None
     _lib.check(_lib.load().selftok_residual_ln_mod_f32(_p(x), _p(y), _p(gate), _p(shift), _p(scale), _p(x_out), _p(n_out),
                                                        B, T, H, msb, mst, gsb, gst, eps, _stream()), "selftok_residual_ln_mod_f32")
@@ -224,6 +230,48 @@ def linear_f16x2(x: torch.Tensor, packed: torch.Tensor, bias, N: int, gelu: bool
     _lib.check(_lib.load().selftok_linear_f16x2_f32(_p(x2), lda, _p(packed), _p(bias), _p(out), N, M, N, K,
                                                     LINEAR_GELU if gelu else 0, _p(overflow), _stream()), "selftok_linear_f16x2_f32")
     return out.reshape(*x.shape[:-1], N)
+
+
+def split_f16x2(x: torch.Tensor, overflow: torch.Tensor = None) -> torch.Tensor:
+    """fp32 [..., K] -> "split activation" fp16 [2, ..., K]: plane 0 = fp16(x), plane 1 = fp16((x - plane0) * 2^11).  The form the
+    fused producers (residual_ln_mod / attention / linear_f16x2_split with split outputs) write directly; this stand-alone kernel
+    is for inputs no fused producer makes.  `overflow` bit 0 is raised for |x| >= 65504."""
+    _need_cuda(x)
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1 or (x2.shape[0] > 1 and (x2.stride(0) % 4 or x2.stride(0) < K)):
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    out = torch.empty(2, rows, K, dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().selftok_split_f16x2_f32(_p(x2), x2.stride(0) if rows > 1 else K, _p(out[0]), _p(out[1]), K, rows, K,
+                                                   _p(overflow), _stream()), "selftok_split_f16x2_f32")
+    return out.reshape(2, *x.shape)
+
+
+def split_to_f32(xs: torch.Tensor) -> torch.Tensor:
+    """the fp32 value a split activation stands for (tests / debugging)"""
+    return xs[0].float() + xs[1].float() * (1.0 / 2048.0)
+
+
+def linear_f16x2_split(xs: torch.Tensor, packed: torch.Tensor, bias, N: int, gelu: bool = False, overflow: torch.Tensor = None,
+                       out_split: bool = False) -> torch.Tensor:
+    """linear_f16x2 on a split activation xs [2, ..., K] fp16 (contiguous): both operands reach LDS by LDS-DMA.  Returns fp32
+    [..., N], or with out_split the split form [2, ..., N] for the next Linear.  Same results as linear_f16x2 on the fp32 tensor."""
+    _need_cuda(xs, packed)
+    K = xs.shape[-1]
+    assert xs.dtype == torch.float16 and xs.shape[0] == 2 and xs.is_contiguous() and packed.numel() * 2 == 4 * N * K
+    M = xs[0].numel() // K
+    lead = xs.shape[1:-1]
+    lib = _lib.load()
+    if out_split:
+        out = torch.empty(2, M, N, dtype=torch.float16, device=xs.device)
+        _lib.check(lib.selftok_linear_f16x2_split(_p(xs[0]), _p(xs[1]), K, _p(packed), _p(bias), None, _p(out[0]), _p(out[1]), N, M, N, K,
+                                                  LINEAR_GELU if gelu else 0, _p(overflow), _stream()), "selftok_linear_f16x2_split")
+        return out.reshape(2, *lead, N)
+    out = torch.empty(M, N, dtype=torch.float32, device=xs.device)
+    _lib.check(lib.selftok_linear_f16x2_split(_p(xs[0]), _p(xs[1]), K, _p(packed), _p(bias), _p(out), None, None, N, M, N, K,
+                                              LINEAR_GELU if gelu else 0, _p(overflow), _stream()), "selftok_linear_f16x2_split")
+    return out.reshape(*lead, N)
 
 
 def silu(x):
@@ -303,6 +351,10 @@ def _seg(q, k, v, o):
     s = _lib.AttnSeg()
     if k is None:
         return s
+    if o is not None and o.dtype == torch.float16:      # split-activation output [2,B,L,H*Dh]: planes go into the descriptor
+        assert o.dim() == 4 and o.shape[0] == 2 and o.stride(3) == 1
+        s.o_rs, s.o_bs = o.stride(2), o.stride(1)
+        o = None
     for name, t in (("q", q), ("k", k), ("v", v), ("o", o)):
         if t is None:
             continue
@@ -327,6 +379,9 @@ def attention(seg0, seg1, heads, head_dim, kvis=None, seg0_sees_seg1=True, scale
     _need_cuda(ref[1])
     d.seg[0] = _seg(*seg0) if seg0 is not None else _lib.AttnSeg()
     d.seg[1] = _seg(*seg1) if seg1 is not None else _lib.AttnSeg()
+    for i, sg in enumerate((seg0, seg1)):               # `o` given as a split activation (fp16 [2,B,L,H*Dh]); f16x2 mode only
+        if sg is not None and sg[3] is not None and sg[3].dtype == torch.float16:
+            d.o_hi[i], d.o_lo[i] = sg[3][0].data_ptr(), sg[3][1].data_ptr()
     d.B, d.H, d.head_dim = ref[1].shape[0], heads, head_dim
     if kvis is not None:
         assert kvis.dtype == torch.int32 and kvis.is_cuda and kvis.numel() == d.B

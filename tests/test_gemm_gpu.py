@@ -97,3 +97,40 @@ def test_split_linear_bad_arguments():
         ops.linear_f16x2_pack(torch.zeros(128, 48, device="cuda"))          # K % 32
     packed = ops.linear_f16x2_pack(torch.zeros(128, 64, device="cuda"))
     assert ops.linear_f16x2(torch.zeros(0, 64, device="cuda"), packed, None, 128).shape == (0, 128)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 32), (1000, 1536, 1536), (2048 + 37, 4608, 1536), (777, 1536, 6144), (3, 256, 64), (300, 128, 96)])
+def test_presplit_activations_bit_identical(M, N, K):
+    """The producer-side split (fp16 hi/lo planes, staged by LDS-DMA) is the same function of the fp32 value as the in-kernel
+    split: selftok_linear_f16x2_split must reproduce selftok_linear_f16x2_f32 bit for bit, for every k-tile count and ragged M."""
+    a, w, b = _data(M, N, K, seed=7 * M + N + K)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    packed = ops.linear_f16x2_pack(w, flag)
+    xs = ops.split_f16x2(a, flag)
+    assert xs.shape == (2, M, K) and xs.dtype == torch.float16
+    assert float((ops.split_to_f32(xs) - a).abs().max()) <= float(a.abs().max()) * 2.0 ** -21
+    ref = ops.linear_f16x2(a, packed, b, N)
+    out = ops.linear_f16x2_split(xs, packed, b, N, overflow=flag)
+    assert torch.equal(out, ref)
+    ref_g = ops.linear_f16x2(a, packed, b, N, gelu=True)
+    out_g = ops.linear_f16x2_split(xs, packed, b, N, gelu=True, overflow=flag)
+    assert torch.equal(out_g, ref_g)
+    # split outputs: exactly the split of the fp32 output
+    os_ = ops.linear_f16x2_split(xs, packed, b, N, gelu=True, overflow=flag, out_split=True)
+    assert torch.equal(os_, ops.split_f16x2(ref_g))
+    assert int(flag.item()) == 0
+
+
+def test_presplit_overflow_flag():
+    a, w, b = _data(300, 128, 64, seed=3)
+    packed = ops.linear_f16x2_pack(w)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    a[17, 5] = 7.0e4
+    ops.split_f16x2(a, flag)
+    assert int(flag.item()) & 1
+    flag.zero_()
+    big = a.clone()
+    big[17, 5] = 1.0
+    xs = ops.split_f16x2(big * 3.0e3)                      # inputs in range, outputs of the Linear beyond the fp16 range
+    ops.linear_f16x2_split(xs, ops.linear_f16x2_pack(w * 50.0), None, 128, overflow=flag, out_split=True)
+    assert int(flag.item()) & 1

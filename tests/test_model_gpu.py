@@ -105,6 +105,26 @@ def test_f16x2_gemm_gate_vs_reference(sd, encoder):
         assert errs["f16x2", case] < 5e-5
 
 
+def test_f16x2_presplit_activations_bit_identical(sd, encoder):
+    """f16x2 mode hands every block Linear its input already split by the producing kernel (LN-modulate, attention, fc1+GELU
+    epilogues) and stages it by LDS-DMA; the split is the same function of the fp32 value as the in-GEMM split, so the whole
+    forward must be bit-identical to the path that keeps fp32 activations between kernels."""
+    from selftoktokenizer_amd.mmdit import MMDiTGPU
+    d = MMDiTGPU(sd, torch.device("cuda"), 512, gemm="f16x2")
+    ids = torch.from_numpy(synth.synthetic_token_ids(2)).cuda()
+    ehs = encoder.codes_ln(ids)
+    x = synth.synthetic_noise(2, device="cuda")
+    t = torch.tensor([620.0, 333.0], device="cuda")
+    outs = {}
+    for pre in (True, False):
+        d.PRESPLIT = pre
+        for name, mask in (("masked", torch.arange(512, device="cuda")[None] <= torch.tensor([[375], [100]], device="cuda")), ("full", None)):
+            outs[pre, name], _ = d(x, t, encoder_hidden_states=ehs, mask=mask, context_see_xt=True)
+    assert int(d.overflow.item()) == 0
+    for name in ("masked", "full"):
+        assert torch.equal(outs[True, name], outs[False, name]), name
+
+
 def test_dit_truncated_context_equals_masked(dit, encoder):
     """sampler fast path (context truncated to k+1 tokens, no mask) == per-sample kvis path"""
     ids = torch.from_numpy(synth.synthetic_token_ids(2)).cuda()

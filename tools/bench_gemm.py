@@ -36,8 +36,13 @@ def main():
         flop = 2.0 * M * N * K
         t_lib = bench(lambda: F.linear(a, w, b))
         t_s = bench(lambda: ops.linear_f16x2(a, packed, b, N))
+        a_s = ops.split_f16x2(a)
+        same = torch.equal(ops.linear_f16x2_split(a_s, packed, b, N), ops.linear_f16x2(a, packed, b, N))
+        t_p = bench(lambda: ops.linear_f16x2_split(a_s, packed, b, N))
+        t_po = bench(lambda: ops.linear_f16x2_split(a_s, packed, b, N, gelu=True, out_split=True))
         print(f"M={M} N={N} K={K}: fp32 library {t_lib * 1e3:.3f} ms ({flop / t_lib / 1e12:.0f} TF) | f16x2 split {t_s * 1e3:.3f} ms "
-              f"({flop / t_s / 1e12:.0f} TF-equiv, {3 * flop / t_s / 1e12:.0f} TF f16 MFMA = {3 * flop / t_s / 2.5e15:.2f} of peak) | x{t_lib / t_s:.2f}", flush=True)
+              f"({flop / t_s / 1e12:.0f} TF-equiv, {3 * flop / t_s / 1e12:.0f} TF f16 MFMA = {3 * flop / t_s / 2.5e15:.2f} of peak) | x{t_lib / t_s:.2f}"
+              f" | pre-split A {t_p * 1e3:.3f} ms ({3 * flop / t_p / 2.5e15:.2f} of peak, bit-equal {same}), +GELU+split out {t_po * 1e3:.3f} ms", flush=True)
 
 
 if __name__ == "__main__":
