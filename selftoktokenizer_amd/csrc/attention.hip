@@ -498,7 +498,8 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
                 const int r = a + 4 * bb;
                 const int d = 4 * (a + 8 * bb + 4 * half);
                 if (qs.o_hi) {       // split activation for the proj Linear (gemm_split.hip); |o| <= max |v| < 65504 here
-                    const HiLo ab = split_pair_scaled(o0[r] * inv, o0[r + 8] * inv), cd = split_pair_scaled(o1[r] * inv, o1[r + 8] * inv);
+                    const HiLo ab = split_pair_scaled(opaque_f32(o0[r] * inv), opaque_f32(o0[r + 8] * inv));
+                    const HiLo cd = split_pair_scaled(opaque_f32(o1[r] * inv), opaque_f32(o1[r + 8] * inv));
                     *reinterpret_cast<uint2*>(qs.o_hi + off + d) = make_uint2(ab.hi, cd.hi);
                     *reinterpret_cast<uint2*>(qs.o_lo + off + d) = make_uint2(ab.lo, cd.lo);
                 } else {

@@ -41,4 +41,14 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// The fp32 value `v`, made opaque to the optimiser.  hipcc folds fptrunc(fmul/fadd) into one v_fma_mixlo_f16, i.e. it rounds
+// the EXACT product or sum to fp16 once instead of rounding the fp32 result -- a different fp16 value whenever the fp32 result
+// sits on an fp16 rounding tie.  Every producer of a "split activation" passes its fp32 result through here first, so that the
+// planes are a function of the fp32 value alone (bit-identical to splitting the stored fp32 tensor).
+__device__ __forceinline__ float opaque_f32(float v)
+{
+    asm("" : "+v"(v));
+    return v;
+}
+
 }  // namespace selftok

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void residual_ln_mod_kernel(
         if (n_hi) {      // "split activation" for the f16x2 Linear that consumes n (gemm_split.hip): hi = fp16(n), lo = fp16((n - hi) 2^11)
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
             typedef float f4 __attribute__((ext_vector_type(4)));
-            const f4 ov = {o.x, o.y, o.z, o.w};
+            const f4 ov = {opaque_f32(o.x), opaque_f32(o.y), opaque_f32(o.z), opaque_f32(o.w)};   // see common.h
             const h4 hh = __builtin_convertvector(ov, h4);
             const h4 ll = __builtin_convertvector((ov - __builtin_convertvector(hh, f4)) * 2048.0f, h4);
             *reinterpret_cast<h4*>(n_hi + (size_t)gid * H + (i * G + gl) * 4) = hh;

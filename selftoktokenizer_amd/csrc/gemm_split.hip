@@ -337,7 +337,14 @@ constexpr int PA_STAGES = 3, PW_STAGES = 4;
 constexpr int PW_BASE = PA_STAGES * PA_BYTES;    // 98304
 constexpr int P_LDS_BYTES = PW_BASE + PW_STAGES * W_BYTES;   // 163840
 
-template <int ACT, int OSPLIT>
+// one LDS-DMA piece: 64 lanes x 16 B from (uniform base + per-lane 32-bit byte offset) to LDS [lds, lds + 1 KiB) in lane order.
+// Inline asm because hipcc will not select the SGPR-base form for the builtin (it rebuilds a 64-bit VGPR address per piece).
+__device__ __forceinline__ void lds_dma16(const void* base, unsigned voff, unsigned lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory");   // M0 is reserved: hipcc never keeps a value in it across statements
+}
+
+template <int ACT, int OSPLIT, int PP = 1, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo, long lda,
                                                                   const _Float16* __restrict__ Wp, const float* __restrict__ bias,
                                                                   float* __restrict__ out, _Float16* __restrict__ ohi, _Float16* __restrict__ olo, long ldo,
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[P_LDS_BYTES];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: lives in an SGPR
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
@@ -364,30 +371,32 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
     const int m0 = mb * BM, n0 = nb * BN;
     const int KT = K / BK, KL = KT - 1;
 
-    // ---- DMA maps: wave w moves rows 16w..16w+15 and 128+16w.. of both planes (4 instructions) and 2 KiB of the weight tile ----
+    // ---- DMA maps: wave w moves rows 16w..16w+15 and 128+16w.. of both planes (4 instructions) and 2 KiB of the weight tile.
+    // Every source address is (uniform 64-bit base in SGPRs) + (per-lane 32-bit offset that never changes) and every LDS
+    // destination is scalar, so that issuing a piece costs scalar adds only: VALU issue slots are what the partner wave's
+    // matrix stream leaves least of (MI355X_MICROARCH.md, "Two waves per SIMD") ----
     const int d_g = (lane & 3) ^ ((lane >> 4) & 3);                 // source k-group of LDS slot (lane & 3) in row (lane >> 2)
-    int r0 = m0 + wave * 16 + (lane >> 2), r1 = r0 + 128;
-    r0 = r0 < M ? r0 : M - 1;                                       // ragged last row block: re-read the last row
-    r1 = r1 < M ? r1 : M - 1;
-    const _Float16* a_src[4] = {Ahi + (size_t)r0 * lda + d_g * 8, Ahi + (size_t)r1 * lda + d_g * 8,
-                                Alo + (size_t)r0 * lda + d_g * 8, Alo + (size_t)r1 * lda + d_g * 8};
-    const _Float16* w_src = Wp + (size_t)nb * KT * (W_BYTES / 2) + (size_t)wave * 512 + lane * 8;
+    const int rmax = M - 1 - m0;                                    // ragged last row block: re-read the last row
+    int r0 = wave * 16 + (lane >> 2), r1 = r0 + 128;
+    r0 = r0 < rmax ? r0 : rmax;
+    r1 = r1 < rmax ? r1 : rmax;
+    const unsigned a_off[2] = {(unsigned)(r0 * (int)lda + d_g * 8) * 2u, (unsigned)(r1 * (int)lda + d_g * 8) * 2u};   // bytes, < 512 lda
+    const unsigned char* const a_base[2] = {(const unsigned char*)(Ahi + (size_t)m0 * lda), (const unsigned char*)(Alo + (size_t)m0 * lda)};
+    const unsigned char* const w_base = (const unsigned char*)(Wp + (size_t)nb * KT * (W_BYTES / 2) + (size_t)wave * 512);
+    const unsigned w_off = lane * 16;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     auto dma_a = [&](int kt, int stage) {
         kt = kt < KL ? kt : KL;                                     // past the end: stage the last tile again (nobody reads it)
-        unsigned char* dst = smem + stage * PA_BYTES + wave * 1024;
+        const unsigned dst = lds0 + stage * PA_BYTES + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + (size_t)kt * BK),
-                                             (__attribute__((address_space(3))) void*)(dst + (j & 1) * 8192 + (j >> 1) * PA_P), 16, 0, 0);
+        for (int j = 0; j < 4; ++j) lds_dma16(a_base[j >> 1] + (size_t)kt * (BK * 2), a_off[j & 1], dst + (j & 1) * 8192 + (j >> 1) * PA_P);
     };
     auto dma_w = [&](int kt, int stage) {
         kt = kt < KL ? kt : KL;
-        const _Float16* src = w_src + (size_t)kt * (W_BYTES / 2);
-        unsigned char* dst = smem + PW_BASE + stage * W_BYTES + wave * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 8 * 512),
-                                         (__attribute__((address_space(3))) void*)(dst + 8 * 1024), 16, 0, 0);
+        const unsigned char* src = w_base + (size_t)kt * W_BYTES;
+        const unsigned dst = lds0 + PW_BASE + stage * W_BYTES + wave * 1024;
+        lds_dma16(src, w_off, dst);
+        lds_dma16(src + 8 * 1024, w_off, dst + 8 * 1024);
     };
 
     f32x16v hi[2][2], lo[2][2];
@@ -416,9 +425,11 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
     auto mfma_row = [&](int i, f16x8 (&af)[2][2], f16x8 (&wf)[2][2]) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wf[j][0], hi[i][j], 0, 0, 0);
-                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], wf[j][1], lo[i][j], 0, 0, 0);
-                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], wf[j][0], lo[i][j], 0, 0, 0);
+                // operands swapped (weights as the A operand): the block comes out transposed, lane = output ROW, registers = 16
+                // output columns in groups of 4 consecutive ones -> 16-byte (fp32) / 8-byte (fp16 plane) epilogue stores
+                hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][0], af[i][0], hi[i][j], 0, 0, 0);
+                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][1], af[i][0], lo[i][j], 0, 0, 0);
+                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][0], af[i][1], lo[i][j], 0, 0, 0);
             }
     };
 
@@ -453,44 +464,120 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                // tile 0 (4 + 2 oldest) landed; W1, A1, W2 in flight
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    read_frags(af0, wf0, 0, 0, 0);
 
     int ac = 0, wc = 0;                                             // kt % 3, kt % 4
-    for (int kt = 0; kt < KT; ++kt) {
-        const int a1 = ac == 2 ? 0 : ac + 1, a2 = a1 == 2 ? 0 : a1 + 1;
-        iteration(kt, ac, a1, a2, wc, (wc + 1) & 3, (wc + 3) & 3);
-        ac = a1;
-        wc = (wc + 1) & 3;
+    if (PP == 0) {
+        read_frags(af0, wf0, 0, 0, 0);
+        for (int kt = 0; kt < KT; ++kt) {
+            const int a1 = ac == 2 ? 0 : ac + 1, a2 = a1 == 2 ? 0 : a1 + 1;
+            iteration(kt, ac, a1, a2, wc, (wc + 1) & 3, (wc + 3) & 3);
+            ac = a1;
+            wc = (wc + 1) & 3;
+        }
+    } else {
+        // "Ping-pong": the two waves of a SIMD (waves w and w + 4 of the work-group) run half an iteration apart.  While one of
+        // them issues its 24 MFMAs of tile kt back to back (compute segment: nothing else in its stream, the matrix pipe never
+        // waits for an operand), the other does ALL its memory work for its next tile (load segment: 16 fragment reads, 6 DMA
+        // pieces, the counted wait) in the shadow of those MFMAs; at the barrier they swap roles.  A wave therefore never mixes
+        // MFMAs with waits, and the SIMD's matrix pipe is fed by whichever wave is in its compute segment.
+        //   segment:   0      1      2      3     ...
+        //   waves 0-3  L(0)   C(0)   L(1)   C(1)
+        //   waves 4-7   -     L(0)   C(0)   L(1)       (one extra barrier up front, one less at the end)
+        // Tile kt is read in segments 2kt and 2kt+1; its activation stage is refilled with tile kt+3 by DMAs issued in the load
+        // segments L(kt+1) (segments 2kt+2 / 2kt+3), its weight stage (ring of 4) with tile kt+4 likewise.  Each wave waits for its
+        // own pieces of tile kt+1 at the end of L(kt) -- vmcnt(8) as above -- and the barrier that follows makes them visible.
+        const int grp = wave >> 2;
+        if (grp) __builtin_amdgcn_s_barrier();
+        // static priority for the later-dispatched half: it loses every issue arbitration otherwise; per-segment priority flips
+        // measured slower (profiles/r2_gemm_presplit_ablation.txt)
+        if (!(ABL & 64) && grp) __builtin_amdgcn_s_setprio(1);
+        for (int kt = 0; kt < KT; ++kt) {
+            const int a1 = ac == 2 ? 0 : ac + 1, a2 = a1 == 2 ? 0 : a1 + 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 16)) {
+                read_frags(af0, wf0, ac, wc, 0);
+                read_frags(af1, wf1, ac, wc, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 1)) dma_a(kt + 2, a2);
+            if (!(ABL & 4)) dma_w(kt + 3, (wc + 3) & 3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ABL & 5) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            if (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 8)) {                                       // per accumulator the same summation order as mfma_row
+                mfma_row(0, af0, wf0);
+                mfma_row(1, af0, wf0);
+                mfma_row(0, af1, wf1);
+                mfma_row(1, af1, wf1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 32) && !(grp && kt == KL)) __builtin_amdgcn_s_barrier();
+            ac = a1;
+            wc = (wc + 1) & 3;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // nothing of mine may still be writing LDS when the wave ends
 
-    // ---- epilogue (as above); OSPLIT: the output is written as the two fp16 planes the next Linear consumes ----
+    // ---- epilogue: D^T[n = (r&3) + 8 (r>>2) + 4 lh][m = l31] of each 32x32 block: a lane owns one output row and, per register
+    // group g = r >> 2, four consecutive columns.  Storing those 8- or 16-byte pieces of 32 different rows per instruction
+    // measured +10..20 % on the whole kernel (write transactions, not bytes), so the wave's 64 x 64 outputs are first transposed
+    // through its own LDS slice (the rings are dead by now) and leave as 16 B per lane, 128 (fp16 planes) or 256 (fp32) contiguous
+    // bytes per row.  OSPLIT: the output is written as the two fp16 planes the next Linear consumes ----
+    constexpr int STG_ROW = OSPLIT ? 144 : 272, STG_PLANE = 64 * STG_ROW;   // 64 rows x (128 | 256 B + pad); 18 | 17 KiB per wave
+    unsigned char* stg = smem + wave * (OSPLIT ? 2 * STG_PLANE : STG_PLANE);
+    __syncthreads();                                                // every wave has drained its DMAs (vmcnt(0) above): LDS is free
     float chk = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
-        const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rbase = m0 + wm * 64 + i * 32 + 4 * lh;
+        for (int g = 0; g < 4; ++g) {
+            const int cl = j * 32 + 8 * g + 4 * lh, col = n0 + wn * 64 + cl;
+            const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                float v = hi[i][j][r] + lo[i][j][r] * LO_INV + bv;
-                if (ACT == 1) v = gelu_tanh_f(v);
-                if (row < M) {
-                    if (OSPLIT) {
-                        const _Float16 h = (_Float16)v;
-                        const _Float16 l = (_Float16)((v - (float)h) * LO_SCALE);
-                        ohi[(size_t)row * ldo + col] = h;
-                        olo[(size_t)row * ldo + col] = l;
-                        chk = __builtin_fmaf((float)h, 0.f, chk);     // |v| beyond fp16: h = inf -> flagged here, at the producer
-                    } else {
-                        out[(size_t)row * ldo + col] = v;
-                        chk = __builtin_fmaf(v, 0.f, chk);
+            for (int i = 0; i < 2; ++i) {
+                const int rl = i * 32 + l31, row = m0 + wm * 64 + rl;
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    v[c] = hi[i][j][4 * g + c] + lo[i][j][4 * g + c] * LO_INV + (c == 0 ? bv.x : c == 1 ? bv.y : c == 2 ? bv.z : bv.w);
+                    if (ACT == 1) v[c] = gelu_tanh_f(v[c]);
+                }
+                if (OSPLIT) {
+                    f16x4 h, l;
+                    split4(make_float4(opaque_f32(v[0]), opaque_f32(v[1]), opaque_f32(v[2]), opaque_f32(v[3])), h, l);   // common.h: why opaque
+                    *reinterpret_cast<f16x4*>(stg + rl * STG_ROW + cl * 2) = h;
+                    *reinterpret_cast<f16x4*>(stg + STG_PLANE + rl * STG_ROW + cl * 2) = l;
+                    if (row < M) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) chk = __builtin_fmaf((float)h[c], 0.f, chk);   // |v| beyond fp16: h = inf -> flagged at the producer
+                    }
+                } else {
+                    *reinterpret_cast<float4*>(stg + rl * STG_ROW + cl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (row < M) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) chk = __builtin_fmaf(v[c], 0.f, chk);
                     }
                 }
             }
+        }
+    }
+    if (OSPLIT) {                                                   // the slice is private to the wave: its LDS ops complete in order
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int rl = pass * 8 + (lane >> 3), seg = lane & 7, row = m0 + wm * 64 + rl;
+                const f16x8 val = *reinterpret_cast<const f16x8*>(stg + p * STG_PLANE + rl * STG_ROW + seg * 16);
+                if (row < M) *reinterpret_cast<f16x8*>((p ? olo : ohi) + (size_t)row * ldo + n0 + wn * 64 + seg * 8) = val;
+            }
+    } else {
+#pragma unroll
+        for (int pass = 0; pass < 16; ++pass) {
+            const int rl = pass * 4 + (lane >> 4), seg = lane & 15, row = m0 + wm * 64 + rl;
+            const float4 val = *reinterpret_cast<const float4*>(stg + rl * STG_ROW + seg * 16);
+            if (row < M) *reinterpret_cast<float4*>(out + (size_t)row * ldo + n0 + wn * 64 + seg * 4) = val;
         }
     }
     if (overflow && chk != 0.f) atomicOr(overflow, 1);
@@ -574,15 +661,25 @@ int selftok_linear_f16x2_split(const void* a_hi, const void* a_lo, long lda, con
     if (M < 0 || N <= 0 || K <= 0 || N % BN || K % BK) { set_last_error("linear_f16x2_split: need N % 128 == 0 and K % 32 == 0"); return SELFTOK_EINVAL; }
     if (M == 0) return SELFTOK_OK;
     const bool osplit = out_hi != nullptr || out_lo != nullptr;
-    if (!a_hi || !a_lo || !packed || lda < K || (lda & 7) || ldo < N || ((size_t)a_hi & 15) || ((size_t)a_lo & 15)
+    if (!a_hi || !a_lo || !packed || lda < K || (lda & 7) || ldo < N || (ldo & 3) || ((size_t)a_hi & 15) || ((size_t)a_lo & 15)
+        || ((size_t)out & 15) || ((size_t)out_hi & 15) || ((size_t)out_lo & 15) || (osplit && (ldo & 7)) || (bias && ((size_t)bias & 15))
         || (osplit ? (!out_hi || !out_lo || out) : !out)) {
-        set_last_error("linear_f16x2_split: bad pointers/strides (planes 16-byte aligned, lda % 8 == 0, lda >= K, ldo >= N; either out or both out planes)");
+        set_last_error("linear_f16x2_split: bad pointers/strides (planes, out and bias 16-byte aligned, lda % 8 == 0, lda >= K, ldo % 4 == 0, ldo >= N; either out or both out planes)");
         return SELFTOK_EINVAL;
     }
     const int mblocks = (M + BM - 1) / BM, nblocks = N / BN;
     const dim3 grid((unsigned)(mblocks * nblocks));
     const _Float16 *ah = (const _Float16*)a_hi, *al = (const _Float16*)a_lo;
     _Float16 *oh = (_Float16*)out_hi, *ol = (_Float16*)out_lo;
+#ifdef SELFTOK_GEMM_ABLATE
+    {
+        const char* e = getenv("SELFTOK_GEMM_ABL");
+        const int abl = e ? atoi(e) : 0;
+#define PRE_ABL(pp, v) if (abl == (pp ? v : 1000 + v)) { hipLaunchKernelGGL((linear_f16x2_pre_kernel<0, 0, pp, v>), grid, dim3(512), 0, stream, ah, al, lda, (const _Float16*)packed, bias, out, oh, ol, ldo, M, N, K, overflow, mblocks, nblocks); return check_launch("linear_f16x2_pre_kernel(ablated)"); }
+        PRE_ABL(0, 0) PRE_ABL(1, 1) PRE_ABL(1, 4) PRE_ABL(1, 5) PRE_ABL(1, 8) PRE_ABL(1, 16) PRE_ABL(1, 21) PRE_ABL(1, 24) PRE_ABL(1, 32) PRE_ABL(1, 64) PRE_ABL(1, 13) PRE_ABL(1, 37)
+#undef PRE_ABL
+    }
+#endif
 #define PRE_LAUNCH(ACT, OS) hipLaunchKernelGGL((linear_f16x2_pre_kernel<ACT, OS>), grid, dim3(512), 0, stream, ah, al, lda, (const _Float16*)packed, bias, out, oh, ol, ldo, M, N, K, overflow, mblocks, nblocks)
     if (flags & SELFTOK_LINEAR_GELU) { if (osplit) PRE_LAUNCH(1, 1); else PRE_LAUNCH(1, 0); }
     else { if (osplit) PRE_LAUNCH(0, 1); else PRE_LAUNCH(0, 0); }
