@@ -351,6 +351,8 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
                                                                   int M, int N, int K, int* __restrict__ overflow, int mblocks, int nblocks)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[P_LDS_BYTES];
+    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, rt0 = 0;
+    if (ABL & 2048) { tk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: lives in an SGPR
     const int wm = wave >> 1, wn = wave & 1;
@@ -487,12 +489,19 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
         // segments L(kt+1) (segments 2kt+2 / 2kt+3), its weight stage (ring of 4) with tile kt+4 likewise.  Each wave waits for its
         // own pieces of tile kt+1 at the end of L(kt) -- vmcnt(8) as above -- and the barrier that follows makes them visible.
         const int grp = wave >> 2;
+        if (ABL & 2048) tk1 = __builtin_readcyclecounter();
         if (grp) __builtin_amdgcn_s_barrier();
         // static priority for the later-dispatched half: it loses every issue arbitration otherwise; per-segment priority flips
         // measured slower (profiles/r2_gemm_presplit_ablation.txt)
         if (!(ABL & 64) && grp) __builtin_amdgcn_s_setprio(1);
+        // ABL & 2048 (tools/microbench only): s_memtime stamps at the segment boundaries, summed per wave and written behind the bias
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        unsigned acc_reads = 0, acc_vm = 0, acc_bar1 = 0, acc_mfma = 0, acc_bar2 = 0;
+#define STAMP(t) do { if (ABL & 2048) { __builtin_amdgcn_sched_barrier(0); t = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
         for (int kt = 0; kt < KT; ++kt) {
             const int a1 = ac == 2 ? 0 : ac + 1, a2 = a1 == 2 ? 0 : a1 + 1;
+            STAMP(t0);
+            if ((ABL & 2048) && kt > 0) acc_bar2 += (unsigned)(t0 - t4);
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 16)) {
                 read_frags(af0, wf0, ac, wc, 0);
@@ -502,9 +511,15 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
             if (!(ABL & 1)) dma_a(kt + 2, a2);
             if (!(ABL & 4)) dma_w(kt + 3, (wc + 3) & 3);
             __builtin_amdgcn_sched_barrier(0);
+            if (ABL & 2048) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                STAMP(t1);                                          // all issued, fragment reads landed
+            }
             if (ABL & 5) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            STAMP(t2);                                              // my pieces of the next tile landed
             if (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+            STAMP(t3);
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 8)) {                                       // per accumulator the same summation order as mfma_row
                 mfma_row(0, af0, wf0);
@@ -513,9 +528,19 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
                 mfma_row(1, af1, wf1);
             }
             __builtin_amdgcn_sched_barrier(0);
+            STAMP(t4);                                              // last MFMA issued
+            if (ABL & 2048) { acc_reads += (unsigned)(t1 - t0); acc_vm += (unsigned)(t2 - t1); acc_bar1 += (unsigned)(t3 - t2); acc_mfma += (unsigned)(t4 - t3); }
             if (!(ABL & 32) && !(grp && kt == KL)) __builtin_amdgcn_s_barrier();
             ac = a1;
             wc = (wc + 1) & 3;
+        }
+#undef STAMP
+        if (ABL & 2048) tk2 = __builtin_readcyclecounter();
+        if ((ABL & 2048) && blockIdx.x == gridDim.x / 2 && lane == 0) {
+            float* dbg = const_cast<float*>(bias) + N + wave * 8;
+            dbg[0] = (float)acc_reads / KT; dbg[1] = (float)acc_vm / KT; dbg[2] = (float)acc_bar1 / KT;
+            dbg[3] = (float)acc_mfma / KT; dbg[4] = (float)acc_bar2 / (KT - 1);
+            dbg[5] = (float)(tk1 - tk0); dbg[6] = (float)(tk2 - tk1);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // nothing of mine may still be writing LDS when the wave ends
@@ -581,6 +606,17 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
         }
     }
     if (overflow && chk != 0.f) atomicOr(overflow, 1);
+    if ((ABL & 2048) && blockIdx.x == gridDim.x / 2 && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const_cast<float*>(bias)[N + wave * 8 + 7] = (float)(__builtin_readcyclecounter() - tk2);
+    }
+    if ((ABL & 2048) && overflow && tid == 0) {      // per work-group timeline record: [realtime start, end (100 MHz), cycles, HW_ID, XCC_ID]
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int* rec = overflow + 8 + (size_t)blockIdx.x * 8;
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime(), tk3 = __builtin_readcyclecounter();
+        rec[0] = (int)(unsigned)rt0; rec[1] = (int)(unsigned)rt1; rec[2] = (int)(unsigned)(tk3 - tk0);
+        rec[3] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 4); rec[4] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
 }
 
 // fp32 [rows, cols] (row stride ld) -> the two fp16 planes (stand-alone producer: tests, and inputs that no fused producer writes)
@@ -676,7 +712,7 @@ int selftok_linear_f16x2_split(const void* a_hi, const void* a_lo, long lda, con
         const char* e = getenv("SELFTOK_GEMM_ABL");
         const int abl = e ? atoi(e) : 0;
 #define PRE_ABL(pp, v) if (abl == (pp ? v : 1000 + v)) { hipLaunchKernelGGL((linear_f16x2_pre_kernel<0, 0, pp, v>), grid, dim3(512), 0, stream, ah, al, lda, (const _Float16*)packed, bias, out, oh, ol, ldo, M, N, K, overflow, mblocks, nblocks); return check_launch("linear_f16x2_pre_kernel(ablated)"); }
-        PRE_ABL(0, 0) PRE_ABL(1, 1) PRE_ABL(1, 4) PRE_ABL(1, 5) PRE_ABL(1, 8) PRE_ABL(1, 16) PRE_ABL(1, 21) PRE_ABL(1, 24) PRE_ABL(1, 32) PRE_ABL(1, 64) PRE_ABL(1, 13) PRE_ABL(1, 37)
+        PRE_ABL(0, 0) PRE_ABL(1, 1) PRE_ABL(1, 4) PRE_ABL(1, 5) PRE_ABL(1, 8) PRE_ABL(1, 16) PRE_ABL(1, 21) PRE_ABL(1, 24) PRE_ABL(1, 32) PRE_ABL(1, 64) PRE_ABL(1, 13) PRE_ABL(1, 37) PRE_ABL(1, 2048)
 #undef PRE_ABL
     }
 #endif
