@@ -697,10 +697,10 @@ int selftok_linear_f16x2_split(const void* a_hi, const void* a_lo, long lda, con
     if (M < 0 || N <= 0 || K <= 0 || N % BN || K % BK) { set_last_error("linear_f16x2_split: need N % 128 == 0 and K % 32 == 0"); return SELFTOK_EINVAL; }
     if (M == 0) return SELFTOK_OK;
     const bool osplit = out_hi != nullptr || out_lo != nullptr;
-    if (!a_hi || !a_lo || !packed || lda < K || (lda & 7) || ldo < N || (ldo & 3) || ((size_t)a_hi & 15) || ((size_t)a_lo & 15)
+    if (!a_hi || !a_lo || !packed || lda < K || (lda & 7) || lda > (1L << 22) || ldo < N || (ldo & 3) || ((size_t)a_hi & 15) || ((size_t)a_lo & 15)
         || ((size_t)out & 15) || ((size_t)out_hi & 15) || ((size_t)out_lo & 15) || (osplit && (ldo & 7)) || (bias && ((size_t)bias & 15))
         || (osplit ? (!out_hi || !out_lo || out) : !out)) {
-        set_last_error("linear_f16x2_split: bad pointers/strides (planes, out and bias 16-byte aligned, lda % 8 == 0, lda >= K, ldo % 4 == 0, ldo >= N; either out or both out planes)");
+        set_last_error("linear_f16x2_split: bad pointers/strides (planes, out and bias 16-byte aligned, lda % 8 == 0, K <= lda <= 2^22, ldo % 4 == 0, ldo >= N; either out or both out planes)");
         return SELFTOK_EINVAL;
     }
     const int mblocks = (M + BM - 1) / BM, nblocks = N / BN;
