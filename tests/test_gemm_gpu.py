@@ -134,3 +134,27 @@ def test_presplit_overflow_flag():
     xs = ops.split_f16x2(big * 3.0e3)                      # inputs in range, outputs of the Linear beyond the fp16 range
     ops.linear_f16x2_split(xs, ops.linear_f16x2_pack(w * 50.0), None, 128, overflow=flag, out_split=True)
     assert int(flag.item()) & 1
+
+
+def test_gelu_epilogue_accuracy():
+    """the epilogue's GELU (x * sigmoid(2u) on v_exp_f32 / v_rcp_f32) against the fp64 tanh-GELU over the whole fp32-relevant range,
+    next to torch's own fp32 GELU: identity weights make the Linear a pass-through, so the output is GELU(x) itself."""
+    K = N = 128
+    x = torch.cat([torch.linspace(-12, 12, 256 * K - 16, device="cuda"), torch.tensor([0.0, -0.0, 1e-20, -1e-20, 1e-6, -1e-6, 30.0, -30.0, 88.0, -88.0,
+                                                                                       1e4, -1e4, 6e4, -6e4, 3.0, -3.0], device="cuda")]).reshape(256, K)
+    xs = ops.split_f16x2(x)
+    x_eff = ops.split_to_f32(xs)                          # what the kernel multiplies (22 significand bits)
+    packed = ops.linear_f16x2_pack(torch.eye(N, device="cuda"))
+    out = ops.linear_f16x2_split(xs, packed, None, N, gelu=True)
+    ref = F.gelu(x_eff.double(), approximate="tanh")
+    lib = F.gelu(x_eff, approximate="tanh")
+    err, err_lib = (out.double() - ref).abs(), (lib.double() - ref).abs()
+    # GELU is ill-conditioned for negative x (a 1-ulp error of u moves the result by several ulps: torch fp32 shows 4.4e-7 relative at
+    # x = -2.4, this kernel 6.5e-7): 8 fp32 ulps of the value, plus the argument rounding of the exponential in the deep negative tail
+    tol = 1.0e-6 * ref.abs() + 1e-9 * x_eff.abs().double().clamp(min=1.0)
+    print(f"GELU epilogue: max |err| {float(err.max()):.3e} (torch fp32 GELU {float(err_lib.max()):.3e}); max err/tol {float((err / tol).max()):.2f} "
+          f"(torch {float((err_lib / tol).max()):.2f})")
+    worst = int((err / tol).argmax())
+    assert bool((err <= tol).all()), (float(x_eff.flatten()[worst]), float(out.flatten()[worst]), float(ref.flatten()[worst]), float(lib.flatten()[worst]))
+    assert float(err[x_eff.abs() <= 12].max()) <= float(err_lib[x_eff.abs() <= 12].max()) * 1.5 + 1e-9
+    assert torch.isfinite(out).all()
