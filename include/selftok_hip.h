@@ -159,6 +159,14 @@ int selftok_linear_f16x2_f32(const float* A, long lda, const void* packed, const
 int selftok_split_f16x2_f32(const float* x, long ld, void* hi, void* lo, long ldo, long rows, int cols, int* overflow, hipStream_t stream);
 int selftok_linear_f16x2_split(const void* a_hi, const void* a_lo, long lda, const void* packed, const float* bias,
                                float* out, void* out_hi, void* out_lo, long ldo, int M, int N, int K, int flags, int* overflow, hipStream_t stream);
+/* The same Linear with the residual update of DismantledBlock.post_attention / block_mixing fused into its epilogue
+ * (x + gate_msa * attn.proj(...), x + gate_mlp * mlp(...): sd3/mmdit.py:485-496):
+ *   out[r, c] = resid[r, c] + gate(r, c) * (A W^T + bias)[r, c],   gate(r, c) at gate + (r / T) gate_stride_b + (r % T) gate_stride_t + c
+ * (gate NULL: out = resid + y).  Multiply and add are separate fp32 operations, i.e. the bits selftok_residual_ln_mod_f32 would
+ * produce from the stored y; `out` may alias `resid`.  fp32 output only. */
+int selftok_linear_f16x2_split_residual(const void* a_hi, const void* a_lo, long lda, const void* packed, const float* bias,
+                                        const float* resid, long ldr, const float* gate, long gate_stride_b, long gate_stride_t, int T,
+                                        float* out, long ldo, int M, int N, int K, int* overflow, hipStream_t stream);
 
 /* ---- two-segment attention with implicit prefix-visibility mask ------------------------------
  * Replaces attention(q,k,v,heads,mask)=SDPA with a materialised bool mask (sd3/other_impls.py:37-45,

@@ -349,11 +349,16 @@ __device__ __forceinline__ void lds_dma16(const void* base, unsigned voff, unsig
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory");   // M0 is reserved: hipcc never keeps a value in it across statements
 }
 
-template <int ACT, int OSPLIT, int PP = 1, int ABL = 0>
+// fused residual epilogue (RES): out = resid + gate * (A W^T + bias), gate element (row, col) at gate + (row / T) gsb + (row % T) gst + col
+// (per-sample table: gst = 0; per-token table: gsb = 0; gate NULL: out = resid + y).  The multiply and the add are separate
+// fp32 operations, exactly as residual_ln_mod_kernel performs them on the stored y: same bits, one tensor round trip less.
+struct ResArgs { const float* resid; long ldr; const float* gate; long gsb, gst; int T; };
+
+template <int ACT, int OSPLIT, int PP = 1, int ABL = 0, int RES = 0>
 __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo, long lda,
                                                                   const _Float16* __restrict__ Wp, const float* __restrict__ bias,
                                                                   float* __restrict__ out, _Float16* __restrict__ ohi, _Float16* __restrict__ olo, long ldo,
-                                                                  int M, int N, int K, int* __restrict__ overflow, int mblocks, int nblocks)
+                                                                  int M, int N, int K, int* __restrict__ overflow, int mblocks, int nblocks, ResArgs res)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[P_LDS_BYTES];
     unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, rt0 = 0;
@@ -606,8 +611,21 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
 #pragma unroll
         for (int pass = 0; pass < 16; ++pass) {
             const int rl = pass * 4 + (lane >> 4), seg = lane & 15, row = m0 + wm * 64 + rl;
-            const float4 val = *reinterpret_cast<const float4*>(stg + rl * STG_ROW + seg * 16);
-            if (row < M) *reinterpret_cast<float4*>(out + (size_t)row * ldo + n0 + wn * 64 + seg * 4) = val;
+            float4 val = *reinterpret_cast<const float4*>(stg + rl * STG_ROW + seg * 16);
+            if (row < M) {
+                const int col = n0 + wn * 64 + seg * 4;
+                if (RES) {
+                    const float4 r = *reinterpret_cast<const float4*>(res.resid + (size_t)row * res.ldr + col);
+                    if (res.gate) {
+                        const int b = row / res.T, t = row - b * res.T;
+                        const float4 g = *reinterpret_cast<const float4*>(res.gate + b * res.gsb + t * res.gst + col);
+                        val.x = r.x + g.x * val.x; val.y = r.y + g.y * val.y; val.z = r.z + g.z * val.z; val.w = r.w + g.w * val.w;
+                    } else {
+                        val.x += r.x; val.y += r.y; val.z += r.z; val.w += r.w;
+                    }
+                }
+                *reinterpret_cast<float4*>(out + (size_t)row * ldo + col) = val;
+            }
         }
     }
     if (overflow && chk != 0.f) atomicOr(overflow, 1);
@@ -716,16 +734,35 @@ int selftok_linear_f16x2_split(const void* a_hi, const void* a_lo, long lda, con
     {
         const char* e = getenv("SELFTOK_GEMM_ABL");
         const int abl = e ? atoi(e) : 0;
-#define PRE_ABL(pp, v) if (abl == (pp ? v : 1000 + v)) { hipLaunchKernelGGL((linear_f16x2_pre_kernel<0, 0, pp, v>), grid, dim3(512), 0, stream, ah, al, lda, (const _Float16*)packed, bias, out, oh, ol, ldo, M, N, K, overflow, mblocks, nblocks); return check_launch("linear_f16x2_pre_kernel(ablated)"); }
+#define PRE_ABL(pp, v) if (abl == (pp ? v : 1000 + v)) { hipLaunchKernelGGL((linear_f16x2_pre_kernel<0, 0, pp, v>), grid, dim3(512), 0, stream, ah, al, lda, (const _Float16*)packed, bias, out, oh, ol, ldo, M, N, K, overflow, mblocks, nblocks, ResArgs{}); return check_launch("linear_f16x2_pre_kernel(ablated)"); }
         PRE_ABL(0, 0) PRE_ABL(1, 1) PRE_ABL(1, 4) PRE_ABL(1, 5) PRE_ABL(1, 8) PRE_ABL(1, 16) PRE_ABL(1, 21) PRE_ABL(1, 24) PRE_ABL(1, 32) PRE_ABL(1, 64) PRE_ABL(1, 13) PRE_ABL(1, 37) PRE_ABL(1, 2048)
 #undef PRE_ABL
     }
 #endif
-#define PRE_LAUNCH(ACT, OS) hipLaunchKernelGGL((linear_f16x2_pre_kernel<ACT, OS>), grid, dim3(512), 0, stream, ah, al, lda, (const _Float16*)packed, bias, out, oh, ol, ldo, M, N, K, overflow, mblocks, nblocks)
+#define PRE_LAUNCH(ACT, OS) hipLaunchKernelGGL((linear_f16x2_pre_kernel<ACT, OS>), grid, dim3(512), 0, stream, ah, al, lda, (const _Float16*)packed, bias, out, oh, ol, ldo, M, N, K, overflow, mblocks, nblocks, ResArgs{})
     if (flags & SELFTOK_LINEAR_GELU) { if (osplit) PRE_LAUNCH(1, 1); else PRE_LAUNCH(1, 0); }
     else { if (osplit) PRE_LAUNCH(0, 1); else PRE_LAUNCH(0, 0); }
 #undef PRE_LAUNCH
     return check_launch("linear_f16x2_pre_kernel");
+}
+
+int selftok_linear_f16x2_split_residual(const void* a_hi, const void* a_lo, long lda, const void* packed, const float* bias,
+                                        const float* resid, long ldr, const float* gate, long gate_stride_b, long gate_stride_t, int T,
+                                        float* out, long ldo, int M, int N, int K, int* overflow, hipStream_t stream)
+{
+    if (M < 0 || N <= 0 || K <= 0 || N % BN || K % BK) { set_last_error("linear_f16x2_split_residual: need N % 128 == 0 and K % 32 == 0"); return SELFTOK_EINVAL; }
+    if (M == 0) return SELFTOK_OK;
+    if (!a_hi || !a_lo || !packed || !resid || !out || lda < K || (lda & 7) || lda > (1L << 22) || ldo < N || (ldo & 3) || ldr < N || (ldr & 3) || T <= 0
+        || ((size_t)a_hi & 15) || ((size_t)a_lo & 15) || ((size_t)out & 15) || ((size_t)resid & 15) || (bias && ((size_t)bias & 15))
+        || (gate && (((size_t)gate & 15) || (gate_stride_b & 3) || (gate_stride_t & 3)))) {
+        set_last_error("linear_f16x2_split_residual: bad pointers/strides (16-byte aligned, strides multiples of 4, T > 0)");
+        return SELFTOK_EINVAL;
+    }
+    const int mblocks = (M + BM - 1) / BM, nblocks = N / BN;
+    hipLaunchKernelGGL((linear_f16x2_pre_kernel<0, 0, 1, 0, 1>), dim3((unsigned)(mblocks * nblocks)), dim3(512), 0, stream,
+                       (const _Float16*)a_hi, (const _Float16*)a_lo, lda, (const _Float16*)packed, bias, out, (_Float16*)nullptr, (_Float16*)nullptr, ldo,
+                       M, N, K, overflow, mblocks, nblocks, ResArgs{resid, ldr, gate, gate_stride_b, gate_stride_t, T});
+    return check_launch("linear_f16x2_pre_kernel(residual)");
 }
 
 }  // extern "C"

@@ -106,6 +106,20 @@ class MMDiTGPU:
         """residual_ln_mod whose normalised output feeds Linear `consumer`: split form if that Linear takes it"""
         return ops.residual_ln_mod(x, split=self._pre(consumer), overflow=self.overflow, **kw)
 
+    def _res_ln(self, consumer, x, lin_name, lin_in, *, gate, gate_per_sample, split=None, **ln_kw):
+        """x' = x + gate * Linear(lin_in);  n = LN(x') * (1 + scale) + shift  ->  (x', n).
+        With a split input the residual update rides in the Linear's epilogue (one [B,T,H] fp32 round trip less) and the LN kernel
+        only normalises; otherwise residual_ln_mod does both from the stored Linear output.  Same bits either way."""
+        split = self._pre(consumer) if split is None else split
+        if lin_in.dtype == torch.float16:
+            w, b = self.w[lin_name + ".weight"], self.w[lin_name + ".bias"]
+            x = ops.linear_f16x2_split_residual(lin_in, self._packed[lin_name], b, w.shape[0], x, gate=gate, gate_per_sample=gate_per_sample,
+                                                overflow=self.overflow)
+            _, n = ops.residual_ln_mod(x, split=split, overflow=self.overflow, **ln_kw)
+            return x, n
+        return ops.residual_ln_mod(x, y=self.lin(lin_name, lin_in), gate=gate, gate_per_sample=gate_per_sample, split=split,
+                                   overflow=self.overflow, **ln_kw)
+
     def _pos_bias(self, h: int, w: int) -> torch.Tensor:
         key = (h, w)
         if key not in self._pos_cache:
@@ -184,28 +198,29 @@ class MMDiTGPU:
             # ---- context stream post-attention (sd3/mmdit.py:485-496, 'pos_emb') ----
             if has_ctx and not last:
                 t = tab[i]
-                ctx, cn2 = self._ln(pc + ".mlp.fc1", ctx, y=self.lin(pc + ".attn.proj", oc), gate=t[:, 2 * H:3 * H],
-                                    shift=t[:, 3 * H:4 * H], scale=t[:, 4 * H:5 * H])
+                ctx, cn2 = self._res_ln(pc + ".mlp.fc1", ctx, pc + ".attn.proj", oc, gate=t[:, 2 * H:3 * H], gate_per_sample=False,
+                                        shift=t[:, 3 * H:4 * H], scale=t[:, 4 * H:5 * H])
                 h = self.lin(pc + ".mlp.fc1", cn2, gelu=True, out_split=cn2.dtype == torch.float16 and self._pre(pc + ".mlp.fc2"))
-                m = self.lin(pc + ".mlp.fc2", h)
                 nq = blk(i + 1, "context", "attn.qkv")
                 if i + 1 < DIT_DEPTH - 1:
                     tn = tab[i + 1]
-                    ctx, cn = self._ln(nq, ctx, y=m, gate=t[:, 5 * H:6 * H], shift=tn[:, 0:H], scale=tn[:, H:2 * H])
+                    ctx, cn = self._res_ln(nq, ctx, pc + ".mlp.fc2", h, gate=t[:, 5 * H:6 * H], gate_per_sample=False,
+                                           shift=tn[:, 0:H], scale=tn[:, H:2 * H])
                 else:      # next block is the pre_only one: modulated per sample by c (sd3/mmdit.py:476-483)
-                    ctx, cn = self._ln(nq, ctx, y=m, gate=t[:, 5 * H:6 * H], gate_per_sample=False,
-                                       shift=mods_c_last[:, 0:H], scale=mods_c_last[:, H:2 * H], per_sample=True)
+                    ctx, cn = self._res_ln(nq, ctx, pc + ".mlp.fc2", h, gate=t[:, 5 * H:6 * H], gate_per_sample=False,
+                                           shift=mods_c_last[:, 0:H], scale=mods_c_last[:, H:2 * H], per_sample=True)
             # ---- image stream post-attention ('t_emb') ----
             mx = mods_x[i]
-            x, xn2 = self._ln(px + ".mlp.fc1", x, y=self.lin(px + ".attn.proj", ox), gate=mx[:, 2 * H:3 * H],
-                              shift=mx[:, 3 * H:4 * H], scale=mx[:, 4 * H:5 * H], per_sample=True)
+            x, xn2 = self._res_ln(px + ".mlp.fc1", x, px + ".attn.proj", ox, gate=mx[:, 2 * H:3 * H], gate_per_sample=True,
+                                  shift=mx[:, 3 * H:4 * H], scale=mx[:, 4 * H:5 * H], per_sample=True)
             h = self.lin(px + ".mlp.fc1", xn2, gelu=True, out_split=xn2.dtype == torch.float16 and self._pre(px + ".mlp.fc2"))
-            m = self.lin(px + ".mlp.fc2", h)
             if not last:
                 mn = mods_x[i + 1]
-                x, xn = self._ln(blk(i + 1, "x", "attn.qkv"), x, y=m, gate=mx[:, 5 * H:6 * H], shift=mn[:, 0:H], scale=mn[:, H:2 * H], per_sample=True)
-            else:          # FinalLayer: LN + modulate(shift, scale = adaLN(c).chunk(2)) + Linear (sd3/mmdit.py:641-645)
-                x, xn = ops.residual_ln_mod(x, y=m, gate=mx[:, 5 * H:6 * H], shift=mods_f[:, 0:H], scale=mods_f[:, H:2 * H], per_sample=True)
+                x, xn = self._res_ln(blk(i + 1, "x", "attn.qkv"), x, px + ".mlp.fc2", h, gate=mx[:, 5 * H:6 * H], gate_per_sample=True,
+                                     shift=mn[:, 0:H], scale=mn[:, H:2 * H], per_sample=True)
+            else:          # FinalLayer: LN + modulate(shift, scale = adaLN(c).chunk(2)) + Linear (sd3/mmdit.py:641-645); its Linear takes fp32
+                x, xn = self._res_ln(None, x, px + ".mlp.fc2", h, gate=mx[:, 5 * H:6 * H], gate_per_sample=True, split=False,
+                                     shift=mods_f[:, 0:H], scale=mods_f[:, H:2 * H], per_sample=True)
         return self.lin("model.final_layer.linear", xn)
 
     # ---- reference-shaped entry points ---------------------------------------------------------------

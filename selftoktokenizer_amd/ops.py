@@ -274,6 +274,28 @@ def linear_f16x2_split(xs: torch.Tensor, packed: torch.Tensor, bias, N: int, gel
     return out.reshape(*lead, N)
 
 
+def linear_f16x2_split_residual(xs: torch.Tensor, packed: torch.Tensor, bias, N: int, resid: torch.Tensor, gate=None,
+                                gate_per_sample: bool = False, overflow: torch.Tensor = None) -> torch.Tensor:
+    """resid + gate * (xs @ W.T + bias): linear_f16x2_split with the block's residual update fused into the epilogue.
+    resid [B,T,N] fp32 contiguous; gate a 2-D view [T,N] (per token) or [B,N] (gate_per_sample) with unit inner stride, or None.
+    Bit-identical to residual_ln_mod(resid, y=linear_f16x2_split(...), gate=gate)[0]."""
+    _need_cuda(xs, packed, resid)
+    K = xs.shape[-1]
+    assert xs.dtype == torch.float16 and xs.shape[0] == 2 and xs.is_contiguous() and packed.numel() * 2 == 4 * N * K
+    assert resid.dim() == 3 and resid.is_contiguous() and resid.dtype == torch.float32 and resid.shape[-1] == N
+    B, T, _ = resid.shape
+    M = B * T
+    assert xs[0].numel() // K == M
+    gsb = gst = 0
+    if gate is not None:
+        assert gate.dim() == 2 and gate.stride(1) == 1 and gate.shape == ((B, N) if gate_per_sample else (T, N))
+        gsb, gst = (gate.stride(0), 0) if gate_per_sample else (0, gate.stride(0))
+    out = torch.empty_like(resid)
+    _lib.check(_lib.load().selftok_linear_f16x2_split_residual(_p(xs[0]), _p(xs[1]), K, _p(packed), _p(bias), _p(resid), N, _p(gate), gsb, gst, T,
+                                                           _p(out), N, M, N, K, _p(overflow), _stream()), "selftok_linear_f16x2_split_residual")
+    return out
+
+
 def silu(x):
     _need_cuda(x)
     x = x.contiguous()

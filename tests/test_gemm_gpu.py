@@ -158,3 +158,23 @@ def test_gelu_epilogue_accuracy():
     assert bool((err <= tol).all()), (float(x_eff.flatten()[worst]), float(out.flatten()[worst]), float(ref.flatten()[worst]), float(lib.flatten()[worst]))
     assert float(err[x_eff.abs() <= 12].max()) <= float(err_lib[x_eff.abs() <= 12].max()) * 1.5 + 1e-9
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("B,T,N,K", [(2, 300, 1536, 1536), (3, 77, 256, 96), (1, 515, 1536, 6144)])   # N: a hidden size residual_ln_mod supports
+def test_residual_epilogue_bit_identical(B, T, N, K):
+    """out = resid + gate * Linear(x) in the Linear's epilogue == residual_ln_mod on the stored Linear output (per-token gate,
+    per-sample gate, no gate; ragged row blocks)."""
+    a, w, b = _data(B * T, N, K, seed=B + T + N + K)
+    packed = ops.linear_f16x2_pack(w)
+    xs = ops.split_f16x2(a.reshape(B, T, K))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    resid = torch.randn(B, T, N, device="cuda", generator=g)
+    tab_t = torch.randn(T, 3 * N, device="cuda", generator=g)
+    tab_b = torch.randn(B, 3 * N, device="cuda", generator=g)
+    y = ops.linear_f16x2_split(xs, packed, b, N)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for gate, ps in ((tab_t[:, N:2 * N], False), (tab_b[:, 2 * N:], True), (None, False)):
+        ref, _ = ops.residual_ln_mod(resid, y=y, gate=gate, gate_per_sample=ps, want_n=False)
+        out = ops.linear_f16x2_split_residual(xs, packed, b, N, resid, gate=gate, gate_per_sample=ps, overflow=flag)
+        assert torch.equal(out, ref)
+    assert int(flag.item()) == 0
