@@ -104,10 +104,10 @@ int selftok_residual_ln_mod_f32(const float* x, const float* y, const float* gat
                                 float* x_out, float* n_out, int B, int T, int H,
                                 long mod_stride_b, long mod_stride_t, long gate_stride_b, long gate_stride_t,
                                 float eps, hipStream_t stream);
-/* Same, with n written as a "split activation" (two fp16 planes [B*T, H], see selftok_linear_f16x2_split) for the f16x2 Linear
- * that consumes it; overflow (device int, may be NULL) bit 0 is OR-ed if |n| >= 65504. */
+/* Same, with n written as a "split activation" [B*T, H] (see selftok_linear_f16x2_split) for the f16x2 Linear that consumes it;
+ * overflow (device int, may be NULL) bit 0 is OR-ed if |n| >= 65504. */
 int selftok_residual_ln_mod_split(const float* x, const float* y, const float* gate, const float* shift, const float* scale,
-                                  float* x_out, void* n_hi, void* n_lo, int* overflow, int B, int T, int H,
+                                  float* x_out, void* n_blk, int* overflow, int B, int T, int H,
                                   long mod_stride_b, long mod_stride_t, long gate_stride_b, long gate_stride_t,
                                   float eps, hipStream_t stream);
 
@@ -149,22 +149,26 @@ size_t selftok_linear_f16x2_packed_bytes(int N, int K);
 int selftok_linear_f16x2_pack_weight(const float* W, void* packed, int N, int K, int* overflow, hipStream_t stream);
 int selftok_linear_f16x2_f32(const float* A, long lda, const void* packed, const float* bias, float* out, long ldo,
                              int M, int N, int K, int flags, int* overflow, hipStream_t stream);
-/* "Split activations": the same fp32 tensor stored as the two row-major fp16 planes of the split (hi = fp16(x),
- * lo = fp16((x - hi) 2^11); 4 bytes per element like fp32).  A kernel that PRODUCES a Linear's input writes this form
- * directly (selftok_residual_ln_mod_f32 with xn_hi/xn_lo, selftok_attn_f32 with o_hi/o_lo, the GELU epilogue below), and
- * selftok_linear_f16x2_split then stages its activation tiles by LDS-DMA like its weight tiles; results are bit-identical
- * to selftok_linear_f16x2_f32 on the un-split tensor.  selftok_split_f16x2_f32 is the stand-alone producer.
- * Planes 16-byte aligned, strides lda/ldo in elements (lda % 8 == 0).  Output: either fp32 `out` (out_hi = out_lo = NULL)
- * or split planes (out = NULL).  overflow bit 0 as above (raised by whichever kernel rounds a value beyond the fp16 range). */
-int selftok_split_f16x2_f32(const float* x, long ld, void* hi, void* lo, long ldo, long rows, int cols, int* overflow, hipStream_t stream);
-int selftok_linear_f16x2_split(const void* a_hi, const void* a_lo, long lda, const void* packed, const float* bias,
-                               float* out, void* out_hi, void* out_lo, long ldo, int M, int N, int K, int flags, int* overflow, hipStream_t stream);
+/* "Split activation": a [rows, K] fp32 tensor (K % 32 == 0) stored as the two fp16 planes of the split, hi = fp16(x),
+ * lo = fp16((x - hi) 2^11) -- 4 bytes per element like fp32 -- in 1-KiB chunks of 16 rows x 32 k per plane:
+ *     halfs index of element (row, k) of plane p (0 hi, 1 lo) = (((row/16) (K/32) + k/32) 2 + p) 512 + (row%16) 32 + k%32
+ * (selftok_split_f16x2_bytes = ceil(rows/16) 16 K 4; rows of the last chunk beyond `rows` are never read for a result).
+ * One chunk is one LDS-DMA piece of the consuming Linear.  A kernel that PRODUCES a Linear's input writes this form directly
+ * (selftok_residual_ln_mod_split, selftok_attn_f32 with o_blk, the epilogue of selftok_linear_f16x2_split with out_blk), and
+ * selftok_linear_f16x2_split stages its activation tiles by LDS-DMA like its weight tiles; results are bit-identical to
+ * selftok_linear_f16x2_f32 on the fp32 tensor.  selftok_split_f16x2_f32 is the stand-alone producer.  Pointers 16-byte
+ * aligned.  Output: either fp32 `out` (row stride ldo, out_blk = NULL) or a split activation [M, N] (out = NULL).
+ * overflow bit 0 as above (raised by whichever kernel rounds a value beyond the fp16 range). */
+size_t selftok_split_f16x2_bytes(long rows, int cols);
+int selftok_split_f16x2_f32(const float* x, long ld, void* blk, long rows, int cols, int* overflow, hipStream_t stream);
+int selftok_linear_f16x2_split(const void* a_blk, const void* packed, const float* bias, float* out, void* out_blk, long ldo,
+                               int M, int N, int K, int flags, int* overflow, hipStream_t stream);
 /* The same Linear with the residual update of DismantledBlock.post_attention / block_mixing fused into its epilogue
  * (x + gate_msa * attn.proj(...), x + gate_mlp * mlp(...): sd3/mmdit.py:485-496):
  *   out[r, c] = resid[r, c] + gate(r, c) * (A W^T + bias)[r, c],   gate(r, c) at gate + (r / T) gate_stride_b + (r % T) gate_stride_t + c
  * (gate NULL: out = resid + y).  Multiply and add are separate fp32 operations, i.e. the bits selftok_residual_ln_mod_f32 would
  * produce from the stored y; `out` may alias `resid`.  fp32 output only. */
-int selftok_linear_f16x2_split_residual(const void* a_hi, const void* a_lo, long lda, const void* packed, const float* bias,
+int selftok_linear_f16x2_split_residual(const void* a_blk, const void* packed, const float* bias,
                                         const float* resid, long ldr, const float* gate, long gate_stride_b, long gate_stride_t, int T,
                                         float* out, long ldo, int M, int N, int K, int* overflow, hipStream_t stream);
 
@@ -191,8 +195,8 @@ typedef struct selftok_attn_desc {
     int mode;            /* 0: fp32-input MFMA (exact fp32 products); SELFTOK_ATTN_F16X2: both contractions as f16x2-split
                             products on the f16 matrix cores (head_dim 64 only; see selftok_linear_f16x2_f32) */
     int* overflow;       /* f16x2 mode: device int, bit 2 is OR-ed if |q|, |k| or |v| >= 65504 (result invalid); may be NULL */
-    void* o_hi[2];       /* f16x2 mode, per segment: if non-NULL the output rows are written as a "split activation" (fp16 planes  */
-    void* o_lo[2];       /* o_hi / o_lo, same o_rs / o_bs strides in elements) for selftok_linear_f16x2_split; seg.o may be NULL */
+    void* o_blk[2];      /* f16x2 mode, per segment: if non-NULL the segment's output [B * len, H * head_dim] (row = b len + r) is written
+                            as a "split activation" for selftok_linear_f16x2_split; seg.o may then be NULL */
 } selftok_attn_desc;
 int selftok_attn_f32(const selftok_attn_desc* desc, hipStream_t stream);
 

@@ -37,13 +37,14 @@ SIGNATURES = {
     "selftok_rmsnorm_f32": (_i, [_vp, _vp, _vp, _l, _i, _f, _vp]),
     "selftok_rotary_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "selftok_attn_f32": (_i, [_vp, _vp]),
-    "selftok_residual_ln_mod_split": (_i, [_vp] * 9 + [_i, _i, _i, _l, _l, _l, _l, _f, _vp]),
+    "selftok_residual_ln_mod_split": (_i, [_vp] * 8 + [_i, _i, _i, _l, _l, _l, _l, _f, _vp]),
     "selftok_linear_f16x2_packed_bytes": (_sz, [_i, _i]),
     "selftok_linear_f16x2_pack_weight": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "selftok_linear_f16x2_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp, _vp]),
-    "selftok_split_f16x2_f32": (_i, [_vp, _l, _vp, _vp, _l, _l, _i, _vp, _vp]),
-    "selftok_linear_f16x2_split": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp, _vp]),
-    "selftok_linear_f16x2_split_residual": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _l, _l, _i, _vp, _l, _i, _i, _i, _vp, _vp]),
+    "selftok_split_f16x2_bytes": (_sz, [_l, _i]),
+    "selftok_split_f16x2_f32": (_i, [_vp, _l, _vp, _l, _i, _vp, _vp]),
+    "selftok_linear_f16x2_split": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp, _vp]),
+    "selftok_linear_f16x2_split_residual": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _l, _l, _i, _vp, _l, _i, _i, _i, _vp, _vp]),
     "selftok_groupnorm_silu_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "selftok_latent_process_in": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     "selftok_latent_process_out": (_i, [_vp, _vp, _l, _f, _f, _vp]),
@@ -60,7 +61,7 @@ class AttnSeg(C.Structure):
 class AttnDesc(C.Structure):
     _fields_ = [("seg", AttnSeg * 2), ("B", _i), ("H", _i), ("head_dim", _i), ("kvis", _vp),
                 ("seg0_sees_seg1", _i), ("scale", _f), ("mode", _i), ("overflow", _vp),
-                ("o_hi", _vp * 2), ("o_lo", _vp * 2)]
+                ("o_blk", _vp * 2)]
 
 _lib = None
 

@@ -33,8 +33,7 @@ struct AttnSeg {
     const float* k;
     const float* v;
     float* o;
-    _Float16* o_hi;   // f16x2 kernel: split-activation output planes (or NULL)
-    _Float16* o_lo;
+    _Float16* o_blk;  // f16x2 kernel: split-activation output (or NULL): the segment's [B * len, H * 64] matrix
     int len;          // rows in this segment
     long q_rs, k_rs, v_rs, o_rs;   // row strides (floats)
     long q_bs, k_bs, v_bs, o_bs;   // batch strides (floats)
@@ -497,11 +496,12 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
                 // registers a + 4 bb (+8): d' = a + 8 bb + 4 half (+16)  ->  d = 4 (a + 8 bb + 4 half) + {0, 1} + 2 db
                 const int r = a + 4 * bb;
                 const int d = 4 * (a + 8 * bb + 4 * half);
-                if (qs.o_hi) {       // split activation for the proj Linear (gemm_split.hip); |o| <= max |v| < 65504 here
+                if (qs.o_blk) {      // split activation for the proj Linear (gemm_split.hip); |o| <= max |v| < 65504 here
                     const HiLo ab = split_pair_scaled(opaque_f32(o0[r] * inv), opaque_f32(o0[r + 8] * inv));
                     const HiLo cd = split_pair_scaled(opaque_f32(o1[r] * inv), opaque_f32(o1[r + 8] * inv));
-                    *reinterpret_cast<uint2*>(qs.o_hi + off + d) = make_uint2(ab.hi, cd.hi);
-                    *reinterpret_cast<uint2*>(qs.o_lo + off + d) = make_uint2(ab.lo, cd.lo);
+                    const long row_g = (long)b * qs.len + my_row;
+                    *reinterpret_cast<uint2*>(qs.o_blk + split_blk_index(row_g, h * 64 + d, 0, P.H * 2)) = make_uint2(ab.hi, cd.hi);
+                    *reinterpret_cast<uint2*>(qs.o_blk + split_blk_index(row_g, h * 64 + d, 1, P.H * 2)) = make_uint2(ab.lo, cd.lo);
                 } else {
                     *reinterpret_cast<float4*>(qs.o + off + d) = make_float4(o0[r] * inv, o0[r + 8] * inv, o1[r] * inv, o1[r + 8] * inv);
                 }
@@ -576,11 +576,11 @@ int selftok_attn_f32(const selftok_attn_desc* d, hipStream_t stream)
         AttnParams P;
         for (int s = 0; s < 2; ++s) {
             const selftok_attn_seg& a = d->seg[s];
-            const bool osplit = d->mode == SELFTOK_ATTN_F16X2 && d->o_hi[s] != nullptr;
-            if ((d->o_hi[s] == nullptr) != (d->o_lo[s] == nullptr) || (d->o_hi[s] && d->mode != SELFTOK_ATTN_F16X2)) { set_last_error("attn: split outputs need both planes and the f16x2 mode"); return SELFTOK_EINVAL; }
+            const bool osplit = d->mode == SELFTOK_ATTN_F16X2 && d->o_blk[s] != nullptr;
+            if (d->o_blk[s] && (d->mode != SELFTOK_ATTN_F16X2 || ((size_t)d->o_blk[s] & 15))) { set_last_error("attn: split outputs need the f16x2 mode and 16-byte alignment"); return SELFTOK_EINVAL; }
             if (a.len < 0 || (a.len > 0 && (!a.k || !a.v)) || (a.q && !a.o && !osplit)) { set_last_error("attn: bad segment"); return SELFTOK_EINVAL; }
             if (((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.q_bs | a.k_bs | a.v_bs | a.o_bs) & 3) != 0) { set_last_error("attn: strides must be multiples of 4 floats"); return SELFTOK_EINVAL; }
-            P.seg[s] = AttnSeg{a.len > 0 ? a.q : nullptr, a.k, a.v, a.o, (_Float16*)d->o_hi[s], (_Float16*)d->o_lo[s], a.len, a.q_rs, a.k_rs, a.v_rs, a.o_rs, a.q_bs, a.k_bs, a.v_bs, a.o_bs};
+            P.seg[s] = AttnSeg{a.len > 0 ? a.q : nullptr, a.k, a.v, a.o, (_Float16*)d->o_blk[s], a.len, a.q_rs, a.k_rs, a.v_rs, a.o_rs, a.q_bs, a.k_bs, a.v_bs, a.o_bs};
         }
         P.B = d->B; P.H = d->H; P.kvis = d->kvis; P.seg0_sees_seg1 = d->seg0_sees_seg1; P.scale = d->scale;
         int t0 = P.seg[0].q ? (P.seg[0].len + QROWS - 1) / QROWS : 0;

@@ -41,6 +41,14 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// "Split activation" layout (include/selftok_hip.h): a [rows, K] fp32 tensor as fp16 hi / lo planes, stored in 1-KiB chunks of
+// 16 rows x 32 k per plane, [rows/16][K/32][plane][16][32] -- one chunk is exactly one LDS-DMA piece of the consuming GEMM (8 full
+// cache lines; with row-major planes a piece was 16 half lines, each fetched twice).  Index in halfs of element (row, k), plane p:
+__device__ __forceinline__ size_t split_blk_index(long row, int k, int plane, int KT)
+{
+    return ((((size_t)(row >> 4) * KT + (k >> 5)) * 2 + plane) << 9) + ((row & 15) << 5) + (k & 31);
+}
+
 // The fp32 value `v`, made opaque to the optimiser.  hipcc folds fptrunc(fmul/fadd) into one v_fma_mixlo_f16, i.e. it rounds
 // the EXACT product or sum to fp16 once instead of rounding the fp32 result -- a different fp16 value whenever the fp32 result
 // sits on an fp16 rounding tie.  Every producer of a "split activation" passes its fp32 result through here first, so that the

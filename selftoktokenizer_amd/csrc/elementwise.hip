@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void residual_ln_mod_kernel(
     const float* __restrict__ shift, const float* __restrict__ scale,
     float* __restrict__ x_out, float* __restrict__ n_out,
     int rows, int T, long mod_stride_b, long mod_stride_t, long gate_stride_b, long gate_stride_t, float eps,
-    _Float16* __restrict__ n_hi = nullptr, _Float16* __restrict__ n_lo = nullptr, int* __restrict__ overflow = nullptr)
+    _Float16* __restrict__ n_blk = nullptr, int* __restrict__ overflow = nullptr)
 {
     constexpr int H = G * VPL * 4;
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / G;   // row
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void residual_ln_mod_kernel(
             for (int i = 0; i < VPL; ++i) st4(xo + (i * G + gl) * 4, v[i]);
         }
     }
-    if (!n_out && !n_hi) return;
+    if (!n_out && !n_blk) return;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -99,18 +99,18 @@ __global__ __launch_bounds__(256) void residual_ln_mod_kernel(
             o.z = o.z * (1.0f + c4.z) + s4.z; o.w = o.w * (1.0f + c4.w) + s4.w;
         }
         if (nr) st4(nr + (i * G + gl) * 4, o);
-        if (n_hi) {      // "split activation" for the f16x2 Linear that consumes n (gemm_split.hip): hi = fp16(n), lo = fp16((n - hi) 2^11)
+        if (n_blk) {     // "split activation" for the f16x2 Linear that consumes n (gemm_split.hip): hi = fp16(n), lo = fp16((n - hi) 2^11)
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
             typedef float f4 __attribute__((ext_vector_type(4)));
             const f4 ov = {opaque_f32(o.x), opaque_f32(o.y), opaque_f32(o.z), opaque_f32(o.w)};   // see common.h
             const h4 hh = __builtin_convertvector(ov, h4);
             const h4 ll = __builtin_convertvector((ov - __builtin_convertvector(hh, f4)) * 2048.0f, h4);
-            *reinterpret_cast<h4*>(n_hi + (size_t)gid * H + (i * G + gl) * 4) = hh;
-            *reinterpret_cast<h4*>(n_lo + (size_t)gid * H + (i * G + gl) * 4) = ll;
+            *reinterpret_cast<h4*>(n_blk + split_blk_index(gid, (i * G + gl) * 4, 0, H / 32)) = hh;
+            *reinterpret_cast<h4*>(n_blk + split_blk_index(gid, (i * G + gl) * 4, 1, H / 32)) = ll;
             mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
         }
     }
-    if (n_hi && overflow && !(mx < 65504.0f)) atomicOr(overflow, 1);
+    if (n_blk && overflow && !(mx < 65504.0f)) atomicOr(overflow, 1);
 }
 
 // in-place  h = gelu_tanh(h + bias)   (timm / sd3 Mlp act: modules.py:109,293 ; sd3/other_impls.py:82-90)
@@ -280,12 +280,12 @@ static inline int grid_for(long n, int block = 256, int cap = 256 * 16)
 extern "C" {
 
 static int residual_ln_mod_launch(const float* x, const float* y, const float* gate, const float* shift, const float* scale,
-                                  float* x_out, float* n_out, _Float16* n_hi, _Float16* n_lo, int* overflow, int B, int T, int H,
+                                  float* x_out, float* n_out, _Float16* n_blk, int* overflow, int B, int T, int H,
                                   long mod_stride_b, long mod_stride_t, long gate_stride_b, long gate_stride_t,
                                   float eps, hipStream_t stream)
 {
-    if (!x || B < 0 || T < 0 || (shift == nullptr) != (scale == nullptr) || (n_hi == nullptr) != (n_lo == nullptr)
-        || (!n_out && !n_hi && !(y && x_out))) {
+    if (!x || B < 0 || T < 0 || (shift == nullptr) != (scale == nullptr) || (n_blk && (H % 32 || ((size_t)n_blk & 15)))
+        || (!n_out && !n_blk && !(y && x_out))) {
         set_last_error("residual_ln_mod: bad argument");
         return SELFTOK_EINVAL;
     }
@@ -294,7 +294,7 @@ static int residual_ln_mod_launch(const float* x, const float* y, const float* g
 #define LAUNCH(G, VPL)                                                                                                  \
     hipLaunchKernelGGL((residual_ln_mod_kernel<G, VPL>), dim3((rows + (256 / G) - 1) / (256 / G)), dim3(256), 0, stream, \
                        x, y, gate, shift, scale, x_out, n_out, rows, T, mod_stride_b, mod_stride_t, gate_stride_b,      \
-                       gate_stride_t, eps, n_hi, n_lo, overflow)
+                       gate_stride_t, eps, n_blk, overflow)
     switch (H) {
         case 64: LAUNCH(16, 1); break;
         case 512: LAUNCH(64, 2); break;
@@ -312,17 +312,17 @@ int selftok_residual_ln_mod_f32(const float* x, const float* y, const float* gat
                                 long mod_stride_b, long mod_stride_t, long gate_stride_b, long gate_stride_t,
                                 float eps, hipStream_t stream)
 {
-    return residual_ln_mod_launch(x, y, gate, shift, scale, x_out, n_out, nullptr, nullptr, nullptr, B, T, H,
+    return residual_ln_mod_launch(x, y, gate, shift, scale, x_out, n_out, nullptr, nullptr, B, T, H,
                                   mod_stride_b, mod_stride_t, gate_stride_b, gate_stride_t, eps, stream);
 }
 
 int selftok_residual_ln_mod_split(const float* x, const float* y, const float* gate, const float* shift, const float* scale,
-                                  float* x_out, void* n_hi, void* n_lo, int* overflow, int B, int T, int H,
+                                  float* x_out, void* n_blk, int* overflow, int B, int T, int H,
                                   long mod_stride_b, long mod_stride_t, long gate_stride_b, long gate_stride_t,
                                   float eps, hipStream_t stream)
 {
-    if (!n_hi || !n_lo) { set_last_error("residual_ln_mod_split: null output plane"); return SELFTOK_EINVAL; }
-    return residual_ln_mod_launch(x, y, gate, shift, scale, x_out, nullptr, (_Float16*)n_hi, (_Float16*)n_lo, overflow, B, T, H,
+    if (!n_blk) { set_last_error("residual_ln_mod_split: null output"); return SELFTOK_EINVAL; }
+    return residual_ln_mod_launch(x, y, gate, shift, scale, x_out, nullptr, (_Float16*)n_blk, overflow, B, T, H,
                                   mod_stride_b, mod_stride_t, gate_stride_b, gate_stride_t, eps, stream);
 }
 

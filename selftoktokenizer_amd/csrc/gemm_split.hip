@@ -355,9 +355,9 @@ __device__ __forceinline__ void lds_dma16(const void* base, unsigned voff, unsig
 struct ResArgs { const float* resid; long ldr; const float* gate; long gsb, gst; int T; };
 
 template <int ACT, int OSPLIT, int PP = 1, int ABL = 0, int RES = 0>
-__global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo, long lda,
+__global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16* __restrict__ Ablk,
                                                                   const _Float16* __restrict__ Wp, const float* __restrict__ bias,
-                                                                  float* __restrict__ out, _Float16* __restrict__ ohi, _Float16* __restrict__ olo, long ldo,
+                                                                  float* __restrict__ out, _Float16* __restrict__ oblk, long ldo,
                                                                   int M, int N, int K, int* __restrict__ overflow, int mblocks, int nblocks, ResArgs res)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[P_LDS_BYTES];
@@ -388,12 +388,13 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
     // destination is scalar, so that issuing a piece costs scalar adds only: VALU issue slots are what the partner wave's
     // matrix stream leaves least of (MI355X_MICROARCH.md, "Two waves per SIMD") ----
     const int d_g = (lane & 3) ^ ((lane >> 4) & 3);                 // source k-group of LDS slot (lane & 3) in row (lane >> 2)
-    const int rmax = M - 1 - m0;                                    // ragged last row block: re-read the last row
-    int r0 = wave * 16 + (lane >> 2), r1 = r0 + 128;
-    r0 = r0 < rmax ? r0 : rmax;
-    r1 = r1 < rmax ? r1 : rmax;
-    const unsigned a_off[2] = {(unsigned)(r0 * (int)lda + d_g * 8) * 2u, (unsigned)(r1 * (int)lda + d_g * 8) * 2u};   // bytes, < 512 lda
-    const unsigned char* const a_base[2] = {(const unsigned char*)(Ahi + (size_t)m0 * lda), (const unsigned char*)(Alo + (size_t)m0 * lda)};
+    const unsigned a_off = (unsigned)((lane >> 2) * 64 + d_g * 16);     // bytes inside a 1-KiB chunk [16 rows][32 halfs]
+    const int rb_last = (M - 1) >> 4;                               // ragged M: chunks past the end re-read the last one (rows discarded)
+    int rb0 = m0 / 16 + wave, rb1 = rb0 + 8;
+    rb0 = rb0 < rb_last ? rb0 : rb_last;
+    rb1 = rb1 < rb_last ? rb1 : rb_last;
+    // chunk (row block rb, k-tile kt, plane p) starts at ((rb KT + kt) 2 + p) KiB
+    const unsigned char* const a_base[2] = {(const unsigned char*)Ablk + (size_t)rb0 * KT * 2048, (const unsigned char*)Ablk + (size_t)rb1 * KT * 2048};
     const unsigned char* const w_base = (const unsigned char*)(Wp + (size_t)nb * KT * (W_BYTES / 2) + (size_t)wave * 512);
     const unsigned w_off = lane * 16;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
         kt = kt < KL ? kt : KL;                                     // past the end: stage the last tile again (nobody reads it)
         const unsigned dst = lds0 + stage * PA_BYTES + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds_dma16(a_base[j >> 1] + (size_t)kt * (BK * 2), a_off[j & 1], dst + (j & 1) * 8192 + (j >> 1) * PA_P);
+        for (int j = 0; j < 4; ++j) lds_dma16(a_base[j & 1] + (size_t)kt * 2048 + (j >> 1) * 1024, a_off, dst + (j & 1) * 8192 + (j >> 1) * PA_P);
     };
     auto dma_w = [&](int kt, int stage) {
         kt = kt < KL ? kt : KL;
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
             for (int pass = 0; pass < 8; ++pass) {
                 const int rl = pass * 8 + (lane >> 3), seg = lane & 7, row = m0 + wm * 64 + rl;
                 const f16x8 val = *reinterpret_cast<const f16x8*>(stg + p * STG_PLANE + rl * STG_ROW + seg * 16);
-                if (row < M) *reinterpret_cast<f16x8*>((p ? olo : ohi) + (size_t)row * ldo + n0 + wn * 64 + seg * 8) = val;
+                if (row < M) *reinterpret_cast<f16x8*>(oblk + split_blk_index(row, n0 + wn * 64 + seg * 8, p, N / 32)) = val;
             }
     } else {
 #pragma unroll
@@ -642,9 +643,9 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
     }
 }
 
-// fp32 [rows, cols] (row stride ld) -> the two fp16 planes (stand-alone producer: tests, and inputs that no fused producer writes)
-__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, long ld, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                                         long ldo, long rows, int cols, int* __restrict__ overflow)
+// fp32 [rows, cols] (row stride ld) -> split activation (stand-alone producer: tests, and inputs that no fused producer writes)
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, long ld, _Float16* __restrict__ blk,
+                                                         long rows, int cols, int* __restrict__ overflow)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c4 = cols / 4;
@@ -655,8 +656,8 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     f16x4 h, l;
     float mx = 0.f;
     split4(v, h, l, mx);
-    *reinterpret_cast<f16x4*>(hi + r * ldo + c) = h;
-    *reinterpret_cast<f16x4*>(lo + r * ldo + c) = l;
+    *reinterpret_cast<f16x4*>(blk + split_blk_index(r, c, 0, cols / 32)) = h;
+    *reinterpret_cast<f16x4*>(blk + split_blk_index(r, c, 1, cols / 32)) = l;
     if (!(mx < F16_MAX) && overflow) atomicOr(overflow, 1);
 }
 
@@ -704,63 +705,68 @@ int selftok_linear_f16x2_f32(const float* A, long lda, const void* packed, const
     return check_launch("linear_f16x2_kernel");
 }
 
-int selftok_split_f16x2_f32(const float* x, long ld, void* hi, void* lo, long ldo, long rows, int cols, int* overflow, hipStream_t stream)
+size_t selftok_split_f16x2_bytes(long rows, int cols)
 {
-    if (rows < 0 || cols <= 0 || (cols & 3) || (ld & 3) || (ldo & 3) || ld < cols || ldo < cols) { set_last_error("split_f16x2: cols, ld, ldo must be multiples of 4, ld/ldo >= cols"); return SELFTOK_EINVAL; }
+    if (rows < 0 || cols <= 0 || cols % 32) return 0;
+    return (size_t)((rows + 15) / 16) * 16 * cols * 4;      // two fp16 planes, rows padded to the 16-row chunk
+}
+
+int selftok_split_f16x2_f32(const float* x, long ld, void* blk, long rows, int cols, int* overflow, hipStream_t stream)
+{
+    if (rows < 0 || cols <= 0 || (cols & 31) || (ld & 3) || ld < cols) { set_last_error("split_f16x2: cols % 32 == 0, ld % 4 == 0, ld >= cols"); return SELFTOK_EINVAL; }
     if (rows == 0) return SELFTOK_OK;
-    if (!x || !hi || !lo) { set_last_error("split_f16x2: null pointer"); return SELFTOK_EINVAL; }
+    if (!x || !blk || ((size_t)blk & 15) || ((size_t)x & 15)) { set_last_error("split_f16x2: null / unaligned pointer"); return SELFTOK_EINVAL; }
     const long n = rows * (cols / 4);
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ld, (_Float16*)hi, (_Float16*)lo, ldo, rows, cols, overflow);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ld, (_Float16*)blk, rows, cols, overflow);
     return check_launch("split_rows_kernel");
 }
 
-int selftok_linear_f16x2_split(const void* a_hi, const void* a_lo, long lda, const void* packed, const float* bias,
-                               float* out, void* out_hi, void* out_lo, long ldo, int M, int N, int K, int flags, int* overflow, hipStream_t stream)
+int selftok_linear_f16x2_split(const void* a_blk, const void* packed, const float* bias, float* out, void* out_blk, long ldo,
+                               int M, int N, int K, int flags, int* overflow, hipStream_t stream)
 {
     if (M < 0 || N <= 0 || K <= 0 || N % BN || K % BK) { set_last_error("linear_f16x2_split: need N % 128 == 0 and K % 32 == 0"); return SELFTOK_EINVAL; }
     if (M == 0) return SELFTOK_OK;
-    const bool osplit = out_hi != nullptr || out_lo != nullptr;
-    if (!a_hi || !a_lo || !packed || lda < K || (lda & 7) || lda > (1L << 22) || ldo < N || (ldo & 3) || ((size_t)a_hi & 15) || ((size_t)a_lo & 15)
-        || ((size_t)out & 15) || ((size_t)out_hi & 15) || ((size_t)out_lo & 15) || (osplit && (ldo & 7)) || (bias && ((size_t)bias & 15))
-        || (osplit ? (!out_hi || !out_lo || out) : !out)) {
-        set_last_error("linear_f16x2_split: bad pointers/strides (planes, out and bias 16-byte aligned, lda % 8 == 0, K <= lda <= 2^22, ldo % 4 == 0, ldo >= N; either out or both out planes)");
+    const bool osplit = out_blk != nullptr;
+    if (!a_blk || !packed || ((size_t)a_blk & 15) || ((size_t)out & 15) || ((size_t)out_blk & 15) || (bias && ((size_t)bias & 15))
+        || (osplit ? out != nullptr : (!out || ldo < N || (ldo & 3)))) {
+        set_last_error("linear_f16x2_split: bad pointers/strides (a_blk, out, out_blk and bias 16-byte aligned; either out with ldo % 4 == 0, ldo >= N, or out_blk)");
         return SELFTOK_EINVAL;
     }
     const int mblocks = (M + BM - 1) / BM, nblocks = N / BN;
     const dim3 grid((unsigned)(mblocks * nblocks));
-    const _Float16 *ah = (const _Float16*)a_hi, *al = (const _Float16*)a_lo;
-    _Float16 *oh = (_Float16*)out_hi, *ol = (_Float16*)out_lo;
+    const _Float16* ab = (const _Float16*)a_blk;
+    _Float16* ob = (_Float16*)out_blk;
 #ifdef SELFTOK_GEMM_ABLATE
     {
         const char* e = getenv("SELFTOK_GEMM_ABL");
         const int abl = e ? atoi(e) : 0;
-#define PRE_ABL(pp, v) if (abl == (pp ? v : 1000 + v)) { hipLaunchKernelGGL((linear_f16x2_pre_kernel<0, 0, pp, v>), grid, dim3(512), 0, stream, ah, al, lda, (const _Float16*)packed, bias, out, oh, ol, ldo, M, N, K, overflow, mblocks, nblocks, ResArgs{}); return check_launch("linear_f16x2_pre_kernel(ablated)"); }
+#define PRE_ABL(pp, v) if (abl == (pp ? v : 1000 + v)) { hipLaunchKernelGGL((linear_f16x2_pre_kernel<0, 0, pp, v>), grid, dim3(512), 0, stream, ab, (const _Float16*)packed, bias, out, ob, ldo, M, N, K, overflow, mblocks, nblocks, ResArgs{}); return check_launch("linear_f16x2_pre_kernel(ablated)"); }
         PRE_ABL(0, 0) PRE_ABL(1, 1) PRE_ABL(1, 4) PRE_ABL(1, 5) PRE_ABL(1, 8) PRE_ABL(1, 16) PRE_ABL(1, 21) PRE_ABL(1, 24) PRE_ABL(1, 32) PRE_ABL(1, 64) PRE_ABL(1, 13) PRE_ABL(1, 37) PRE_ABL(1, 2048)
 #undef PRE_ABL
     }
 #endif
-#define PRE_LAUNCH(ACT, OS) hipLaunchKernelGGL((linear_f16x2_pre_kernel<ACT, OS>), grid, dim3(512), 0, stream, ah, al, lda, (const _Float16*)packed, bias, out, oh, ol, ldo, M, N, K, overflow, mblocks, nblocks, ResArgs{})
+#define PRE_LAUNCH(ACT, OS) hipLaunchKernelGGL((linear_f16x2_pre_kernel<ACT, OS>), grid, dim3(512), 0, stream, ab, (const _Float16*)packed, bias, out, ob, ldo, M, N, K, overflow, mblocks, nblocks, ResArgs{})
     if (flags & SELFTOK_LINEAR_GELU) { if (osplit) PRE_LAUNCH(1, 1); else PRE_LAUNCH(1, 0); }
     else { if (osplit) PRE_LAUNCH(0, 1); else PRE_LAUNCH(0, 0); }
 #undef PRE_LAUNCH
     return check_launch("linear_f16x2_pre_kernel");
 }
 
-int selftok_linear_f16x2_split_residual(const void* a_hi, const void* a_lo, long lda, const void* packed, const float* bias,
+int selftok_linear_f16x2_split_residual(const void* a_blk, const void* packed, const float* bias,
                                         const float* resid, long ldr, const float* gate, long gate_stride_b, long gate_stride_t, int T,
                                         float* out, long ldo, int M, int N, int K, int* overflow, hipStream_t stream)
 {
     if (M < 0 || N <= 0 || K <= 0 || N % BN || K % BK) { set_last_error("linear_f16x2_split_residual: need N % 128 == 0 and K % 32 == 0"); return SELFTOK_EINVAL; }
     if (M == 0) return SELFTOK_OK;
-    if (!a_hi || !a_lo || !packed || !resid || !out || lda < K || (lda & 7) || lda > (1L << 22) || ldo < N || (ldo & 3) || ldr < N || (ldr & 3) || T <= 0
-        || ((size_t)a_hi & 15) || ((size_t)a_lo & 15) || ((size_t)out & 15) || ((size_t)resid & 15) || (bias && ((size_t)bias & 15))
+    if (!a_blk || !packed || !resid || !out || ldo < N || (ldo & 3) || ldr < N || (ldr & 3) || T <= 0
+        || ((size_t)a_blk & 15) || ((size_t)out & 15) || ((size_t)resid & 15) || (bias && ((size_t)bias & 15))
         || (gate && (((size_t)gate & 15) || (gate_stride_b & 3) || (gate_stride_t & 3)))) {
         set_last_error("linear_f16x2_split_residual: bad pointers/strides (16-byte aligned, strides multiples of 4, T > 0)");
         return SELFTOK_EINVAL;
     }
     const int mblocks = (M + BM - 1) / BM, nblocks = N / BN;
     hipLaunchKernelGGL((linear_f16x2_pre_kernel<0, 0, 1, 0, 1>), dim3((unsigned)(mblocks * nblocks)), dim3(512), 0, stream,
-                       (const _Float16*)a_hi, (const _Float16*)a_lo, lda, (const _Float16*)packed, bias, out, (_Float16*)nullptr, (_Float16*)nullptr, ldo,
+                       (const _Float16*)a_blk, (const _Float16*)packed, bias, out, (_Float16*)nullptr, ldo,
                        M, N, K, overflow, mblocks, nblocks, ResArgs{resid, ldr, gate, gate_stride_b, gate_stride_t, T});
     return check_launch("linear_f16x2_pre_kernel(residual)");
 }

@@ -86,8 +86,8 @@ class MMDiTGPU:
         return mode
 
     def lin(self, name, x, gelu: bool = False, out_split: bool = False):
-        """x fp32 [..., K], or a split activation (fp16 [2, ..., K], ops.split_f16x2) when `self._pre(name)`; out_split: return
-        the split form for the next Linear (only with a split input)."""
+        """x fp32 [..., K], or a split activation (ops.SplitAct) when `self._pre(name)`; out_split: return the split form for the
+        next Linear (only with a split input)."""
         w, b = self.w[name + ".weight"], self.w[name + ".bias"]
         if x.dtype == torch.float16:
             return ops.linear_f16x2_split(x, self._packed[name], b, w.shape[0], gelu=gelu, overflow=self.overflow, out_split=out_split)
@@ -172,7 +172,7 @@ class MMDiTGPU:
 
         def attn_out(rows, consumer, zero=False):   # attention output buffer: split planes if the proj Linear takes them
             if self._pre(consumer) and amode:
-                return (torch.zeros if zero else torch.empty)(2, B, rows, H, device=x.device, dtype=torch.float16)
+                return ops.SplitAct((B, rows, H), x.device, zero=zero)
             return (torch.zeros if zero else torch.empty)(B, rows, H, device=x.device)
 
         _, xn = self._ln(blk(0, "x", "attn.qkv"), x, shift=mods_x[0][:, 0:H], scale=mods_x[0][:, H:2 * H], per_sample=True)

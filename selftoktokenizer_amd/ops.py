@@ -143,8 +143,8 @@ def residual_ln_mod(x, *, y=None, gate=None, shift=None, scale=None, per_sample=
                     want_x=True, want_n=True, eps=1e-6, split=False, overflow=None):
     """x' = x + gate*y ; n = LN(x')*(1+scale)+shift.   x,y [B,T,H].  shift/scale/gate are 2-D views
     [T,H] (per token, default) or [B,H] (per_sample=True) -- typically column slices of a [*,6H] table.
-    Returns (x', n) (either may be None).  split=True: n comes back as a split activation (fp16 [2,B,T,H], see split_f16x2)
-    for linear_f16x2_split; `overflow` bit 0 is raised if |n| >= 65504."""
+    Returns (x', n) (either may be None).  split=True: n comes back as a SplitAct [B,T,H] for linear_f16x2_split; `overflow` bit 0
+    is raised if |n| >= 65504."""
     _need_cuda(x)
     B, T, H = x.shape
     assert x.is_contiguous() and x.dtype == torch.float32
@@ -163,8 +163,8 @@ def residual_ln_mod(x, *, y=None, gate=None, shift=None, scale=None, per_sample=
         assert y.is_contiguous() and y.shape == x.shape
     x_out = torch.empty_like(x) if (y is not None and want_x) else None
     if split and want_n:
-        n_s = torch.empty(2, B, T, H, dtype=torch.float16, device=x.device)
-        _lib.check(_lib.load().selftok_residual_ln_mod_split(_p(x), _p(y), _p(gate), _p(shift), _p(scale), _p(x_out), _p(n_s[0]), _p(n_s[1]),
+        n_s = SplitAct((B, T, H), x.device)
+        _lib.check(_lib.load().selftok_residual_ln_mod_split(_p(x), _p(y), _p(gate), _p(shift), _p(scale), _p(x_out), _p(n_s.data),
                                                              _p(overflow), B, T, H, msb, mst, gsb, gst, eps, _stream()), "selftok_residual_ln_mod_split")
         return (x_out if y is not None else x), n_s
     n_out = torch.empty_like(x) if want_n else None
@@ -232,66 +232,92 @@ def linear_f16x2(x: torch.Tensor, packed: torch.Tensor, bias, N: int, gelu: bool
     return out.reshape(*x.shape[:-1], N)
 
 
-def split_f16x2(x: torch.Tensor, overflow: torch.Tensor = None) -> torch.Tensor:
-    """fp32 [..., K] -> "split activation" fp16 [2, ..., K]: plane 0 = fp16(x), plane 1 = fp16((x - plane0) * 2^11).  The form the
-    fused producers (residual_ln_mod / attention / linear_f16x2_split with split outputs) write directly; this stand-alone kernel
-    is for inputs no fused producer makes.  `overflow` bit 0 is raised for |x| >= 65504."""
+class SplitAct:
+    """A "split activation" (include/selftok_hip.h): the fp32 tensor of logical `shape` [..., K] held as fp16 hi / lo planes in
+    1-KiB chunks of 16 rows x 32 k, `data` = fp16 [ceil(rows/16), K/32, 2, 16, 32].  What the fused producers (residual_ln_mod,
+    attention, the f16x2 Linear's epilogue) write and linear_f16x2_split consumes; `dtype` is torch.float16 so that callers can
+    tell it from an fp32 tensor the way they tell dtypes apart."""
+    dtype = torch.float16
+
+    def __init__(self, shape, device, zero: bool = False):
+        self.shape = tuple(int(v) for v in shape)
+        K = self.shape[-1]
+        assert K % 32 == 0, "split activations need K % 32 == 0"
+        self.rows = 1
+        for v in self.shape[:-1]:
+            self.rows *= v
+        self.data = (torch.zeros if zero else torch.empty)((self.rows + 15) // 16, K // 32, 2, 16, 32, dtype=torch.float16, device=device)
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def planes(self) -> torch.Tensor:
+        """un-blocked copy fp16 [2, *shape] (hi, lo): tests / debugging"""
+        K = self.shape[-1]
+        p = self.data.permute(2, 0, 3, 1, 4).reshape(2, -1, K)[:, :self.rows]
+        return p.reshape(2, *self.shape)
+
+
+def split_f16x2(x: torch.Tensor, overflow: torch.Tensor = None) -> SplitAct:
+    """fp32 [..., K] -> SplitAct: hi = fp16(x), lo = fp16((x - hi) * 2^11).  The stand-alone producer, for inputs no fused producer
+    makes.  `overflow` bit 0 is raised for |x| >= 65504."""
     _need_cuda(x)
     K = x.shape[-1]
     x2 = x.reshape(-1, K)
-    if x2.stride(1) != 1 or (x2.shape[0] > 1 and (x2.stride(0) % 4 or x2.stride(0) < K)):
+    if x2.stride(1) != 1 or (x2.shape[0] > 1 and (x2.stride(0) % 4 or x2.stride(0) < K)) or x2.data_ptr() % 16:
         x2 = x2.contiguous()
-    rows = x2.shape[0]
-    out = torch.empty(2, rows, K, dtype=torch.float16, device=x.device)
-    _lib.check(_lib.load().selftok_split_f16x2_f32(_p(x2), x2.stride(0) if rows > 1 else K, _p(out[0]), _p(out[1]), K, rows, K,
+    out = SplitAct(x.shape, x.device)
+    _lib.check(_lib.load().selftok_split_f16x2_f32(_p(x2), x2.stride(0) if out.rows > 1 else K, _p(out.data), out.rows, K,
                                                    _p(overflow), _stream()), "selftok_split_f16x2_f32")
-    return out.reshape(2, *x.shape)
+    return out
 
 
-def split_to_f32(xs: torch.Tensor) -> torch.Tensor:
+def split_to_f32(xs: SplitAct) -> torch.Tensor:
     """the fp32 value a split activation stands for (tests / debugging)"""
-    return xs[0].float() + xs[1].float() * (1.0 / 2048.0)
+    p = xs.planes()
+    return p[0].float() + p[1].float() * (1.0 / 2048.0)
 
 
-def linear_f16x2_split(xs: torch.Tensor, packed: torch.Tensor, bias, N: int, gelu: bool = False, overflow: torch.Tensor = None,
-                       out_split: bool = False) -> torch.Tensor:
-    """linear_f16x2 on a split activation xs [2, ..., K] fp16 (contiguous): both operands reach LDS by LDS-DMA.  Returns fp32
-    [..., N], or with out_split the split form [2, ..., N] for the next Linear.  Same results as linear_f16x2 on the fp32 tensor."""
-    _need_cuda(xs, packed)
+def linear_f16x2_split(xs: SplitAct, packed: torch.Tensor, bias, N: int, gelu: bool = False, overflow: torch.Tensor = None,
+                       out_split: bool = False):
+    """linear_f16x2 on a split activation: both operands reach LDS by LDS-DMA.  Returns fp32 [..., N], or with out_split a SplitAct
+    [..., N] for the next Linear.  Same results as linear_f16x2 on the fp32 tensor."""
+    _need_cuda(xs.data, packed)
     K = xs.shape[-1]
-    assert xs.dtype == torch.float16 and xs.shape[0] == 2 and xs.is_contiguous() and packed.numel() * 2 == 4 * N * K
-    M = xs[0].numel() // K
-    lead = xs.shape[1:-1]
+    assert packed.numel() * 2 == 4 * N * K, "packed weight does not match (N, K)"
+    M, lead = xs.rows, xs.shape[:-1]
     lib = _lib.load()
+    flags = LINEAR_GELU if gelu else 0
     if out_split:
-        out = torch.empty(2, M, N, dtype=torch.float16, device=xs.device)
-        _lib.check(lib.selftok_linear_f16x2_split(_p(xs[0]), _p(xs[1]), K, _p(packed), _p(bias), None, _p(out[0]), _p(out[1]), N, M, N, K,
-                                                  LINEAR_GELU if gelu else 0, _p(overflow), _stream()), "selftok_linear_f16x2_split")
-        return out.reshape(2, *lead, N)
+        out = SplitAct((*lead, N), xs.device)
+        _lib.check(lib.selftok_linear_f16x2_split(_p(xs.data), _p(packed), _p(bias), None, _p(out.data), N, M, N, K, flags, _p(overflow), _stream()),
+                   "selftok_linear_f16x2_split")
+        return out
     out = torch.empty(M, N, dtype=torch.float32, device=xs.device)
-    _lib.check(lib.selftok_linear_f16x2_split(_p(xs[0]), _p(xs[1]), K, _p(packed), _p(bias), _p(out), None, None, N, M, N, K,
-                                              LINEAR_GELU if gelu else 0, _p(overflow), _stream()), "selftok_linear_f16x2_split")
+    _lib.check(lib.selftok_linear_f16x2_split(_p(xs.data), _p(packed), _p(bias), _p(out), None, N, M, N, K, flags, _p(overflow), _stream()),
+               "selftok_linear_f16x2_split")
     return out.reshape(*lead, N)
 
 
-def linear_f16x2_split_residual(xs: torch.Tensor, packed: torch.Tensor, bias, N: int, resid: torch.Tensor, gate=None,
+def linear_f16x2_split_residual(xs: SplitAct, packed: torch.Tensor, bias, N: int, resid: torch.Tensor, gate=None,
                                 gate_per_sample: bool = False, overflow: torch.Tensor = None) -> torch.Tensor:
     """resid + gate * (xs @ W.T + bias): linear_f16x2_split with the block's residual update fused into the epilogue.
     resid [B,T,N] fp32 contiguous; gate a 2-D view [T,N] (per token) or [B,N] (gate_per_sample) with unit inner stride, or None.
     Bit-identical to residual_ln_mod(resid, y=linear_f16x2_split(...), gate=gate)[0]."""
-    _need_cuda(xs, packed, resid)
+    _need_cuda(xs.data, packed, resid)
     K = xs.shape[-1]
-    assert xs.dtype == torch.float16 and xs.shape[0] == 2 and xs.is_contiguous() and packed.numel() * 2 == 4 * N * K
+    assert packed.numel() * 2 == 4 * N * K
     assert resid.dim() == 3 and resid.is_contiguous() and resid.dtype == torch.float32 and resid.shape[-1] == N
     B, T, _ = resid.shape
     M = B * T
-    assert xs[0].numel() // K == M
+    assert xs.rows == M
     gsb = gst = 0
     if gate is not None:
         assert gate.dim() == 2 and gate.stride(1) == 1 and gate.shape == ((B, N) if gate_per_sample else (T, N))
         gsb, gst = (gate.stride(0), 0) if gate_per_sample else (0, gate.stride(0))
     out = torch.empty_like(resid)
-    _lib.check(_lib.load().selftok_linear_f16x2_split_residual(_p(xs[0]), _p(xs[1]), K, _p(packed), _p(bias), _p(resid), N, _p(gate), gsb, gst, T,
+    _lib.check(_lib.load().selftok_linear_f16x2_split_residual(_p(xs.data), _p(packed), _p(bias), _p(resid), N, _p(gate), gsb, gst, T,
                                                            _p(out), N, M, N, K, _p(overflow), _stream()), "selftok_linear_f16x2_split_residual")
     return out
 
@@ -373,9 +399,8 @@ def _seg(q, k, v, o):
     s = _lib.AttnSeg()
     if k is None:
         return s
-    if o is not None and o.dtype == torch.float16:      # split-activation output [2,B,L,H*Dh]: planes go into the descriptor
-        assert o.dim() == 4 and o.shape[0] == 2 and o.stride(3) == 1
-        s.o_rs, s.o_bs = o.stride(2), o.stride(1)
+    if isinstance(o, SplitAct):      # split-activation output [B,L,H*Dh]: its pointer goes into the descriptor (attention())
+        assert o.shape == (k.shape[0], q.shape[1], q.shape[2])
         o = None
     for name, t in (("q", q), ("k", k), ("v", v), ("o", o)):
         if t is None:
@@ -401,9 +426,9 @@ def attention(seg0, seg1, heads, head_dim, kvis=None, seg0_sees_seg1=True, scale
     _need_cuda(ref[1])
     d.seg[0] = _seg(*seg0) if seg0 is not None else _lib.AttnSeg()
     d.seg[1] = _seg(*seg1) if seg1 is not None else _lib.AttnSeg()
-    for i, sg in enumerate((seg0, seg1)):               # `o` given as a split activation (fp16 [2,B,L,H*Dh]); f16x2 mode only
-        if sg is not None and sg[3] is not None and sg[3].dtype == torch.float16:
-            d.o_hi[i], d.o_lo[i] = sg[3][0].data_ptr(), sg[3][1].data_ptr()
+    for i, sg in enumerate((seg0, seg1)):               # `o` given as a SplitAct [B,L,H*Dh]; f16x2 mode only
+        if sg is not None and isinstance(sg[3], SplitAct):
+            d.o_blk[i] = sg[3].data.data_ptr()
     d.B, d.H, d.head_dim = ref[1].shape[0], heads, head_dim
     if kvis is not None:
         assert kvis.dtype == torch.int32 and kvis.is_cuda and kvis.numel() == d.B

@@ -107,7 +107,7 @@ def test_presplit_activations_bit_identical(M, N, K):
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
     packed = ops.linear_f16x2_pack(w, flag)
     xs = ops.split_f16x2(a, flag)
-    assert xs.shape == (2, M, K) and xs.dtype == torch.float16
+    assert xs.shape == (M, K) and xs.dtype == torch.float16 and xs.data.shape == ((M + 15) // 16, K // 32, 2, 16, 32)
     assert float((ops.split_to_f32(xs) - a).abs().max()) <= float(a.abs().max()) * 2.0 ** -21
     ref = ops.linear_f16x2(a, packed, b, N)
     out = ops.linear_f16x2_split(xs, packed, b, N, overflow=flag)
@@ -117,7 +117,7 @@ def test_presplit_activations_bit_identical(M, N, K):
     assert torch.equal(out_g, ref_g)
     # split outputs: exactly the split of the fp32 output
     os_ = ops.linear_f16x2_split(xs, packed, b, N, gelu=True, overflow=flag, out_split=True)
-    assert torch.equal(os_, ops.split_f16x2(ref_g))
+    assert os_.shape == (M, N) and torch.equal(os_.planes(), ops.split_f16x2(ref_g).planes())
     assert int(flag.item()) == 0
 
 

@@ -95,7 +95,7 @@ def test_c_abi_exports_every_declared_symbol():
     L = _lib.load()
     assert L.selftok_version() >= 100
     assert L.selftok_vq_workspace_bytes(512, 32768) >= 512 * 8
-    assert ctypes.sizeof(_lib.AttnSeg) == 4 * 8 + 8 + 8 * 8 and ctypes.sizeof(_lib.AttnDesc) == 2 * ctypes.sizeof(_lib.AttnSeg) + 48 + 32      # + mode, overflow, split-output planes (round 2)
+    assert ctypes.sizeof(_lib.AttnSeg) == 4 * 8 + 8 + 8 * 8 and ctypes.sizeof(_lib.AttnDesc) == 2 * ctypes.sizeof(_lib.AttnSeg) + 48 + 16      # + mode, overflow, split-activation outputs (round 2)
 
 
 def test_no_cpu_fallback():

@@ -49,8 +49,8 @@ def test_residual_ln_mod(H, mode):
     else:
         xo_s, n_s = ops.residual_ln_mod(xc, y=yc, gate=tc[:, 2 * H:3 * H], shift=tc[:, 0:H], scale=tc[:, H:2 * H],
                                         per_sample=(mode == "sample"), split=True, overflow=flag)
-    assert n_s.dtype == torch.float16 and n_s.shape == (2, B, T, H)
-    assert torch.equal(xo_s, xo) and torch.equal(n_s, ops.split_f16x2(n)) and int(flag.item()) == 0
+    assert n_s.dtype == torch.float16 and n_s.shape == (B, T, H)
+    assert torch.equal(xo_s, xo) and torch.equal(n_s.planes(), ops.split_f16x2(n).planes()) and int(flag.item()) == 0
 
 
 def test_bias_gelu_silu_addrows():
@@ -149,11 +149,11 @@ def test_joint_attention_vs_masked_sdpa(see, kv, mode):
         torch.testing.assert_close(o_c[b, :live].cpu(), ref[b, :live], rtol=2e-5, atol=2e-5)
         assert torch.count_nonzero(o_c[b, live:]) == 0     # dead context rows are not written
     if mode == ops.ATTN_F16X2:      # outputs written as split activations (for the proj Linear): exactly the split of the fp32 outputs
-        s_c = torch.zeros(2, B, Kc, D, device="cuda", dtype=torch.float16)
-        s_x = torch.zeros(2, B, nx, D, device="cuda", dtype=torch.float16)
+        s_c = ops.SplitAct((B, Kc, D), "cuda", zero=True)
+        s_x = ops.SplitAct((B, nx, D), "cuda", zero=True)
         ops.attention((cc[..., :D], cc[..., D:2 * D], cc[..., 2 * D:], s_c), (xc[..., :D], xc[..., D:2 * D], xc[..., 2 * D:], s_x),
                       H, 64, kvis=None if kvis is None else kvis.int().cuda(), seg0_sees_seg1=see, mode=mode)
-        assert torch.equal(s_x, ops.split_f16x2(o_x)) and torch.equal(s_c, ops.split_f16x2(o_c))
+        assert torch.equal(s_x.planes(), ops.split_f16x2(o_x).planes()) and torch.equal(s_c.planes(), ops.split_f16x2(o_c).planes())
 
 
 @pytest.mark.parametrize("mode", ATTN_MODES)
