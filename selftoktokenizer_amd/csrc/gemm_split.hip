@@ -14,15 +14,23 @@
 // tests/test_gemm_gpu.py): rms error 0.37x of hipBLASLt's fp32 GEMM at K=1536 and K=6144, i.e. this is MORE accurate
 // than the fp32 library GEMM it replaces, at 3 matrix instructions of the 16x-rate pipe per fp32 one.
 //
-// Activations are split on the fly (fp32 in HBM, split in registers while staging to LDS); weights are split once at
-// load time into the kernel's own tile order (selftok_linear_f16x2_pack_weight), so a weight tile reaches LDS by
-// direct LDS-DMA (global_load_lds, 16 B per lane, no VGPR round trip) as one linear 16 KiB copy.
+// Weights are split once at load time into the kernel's own tile order (selftok_linear_f16x2_pack_weight), so a weight
+// tile reaches LDS by direct LDS-DMA (global_load_lds, 16 B per lane, no VGPR round trip) as one linear 16 KiB copy.
+// Two kernels, bit-identical results:
+//   linear_f16x2_kernel      fp32 activations, split in registers while staging to LDS (the general entry point);
+//   linear_f16x2_pre_kernel  activations already split by the kernel that produced them ("split activation", common.h):
+//                            both operands by LDS-DMA, ping-pong schedule, LDS-transposed epilogue with optional GELU,
+//                            split-activation output and fused residual update -- what the decode step runs.
+// The chip is power-limited under this instruction mix (1.37 GHz effective shader clock, matrix pipe busy 89 % of the
+// k-loop; tools/stamp_gemm_pre.py): the second kernel runs at 0.9-1.05x the rate of the vendor's plain fp16 GEMM with
+// the same number of MFMAs, while carrying operands of fp32 precision.
 //
 // Range: fp16 overflows at 65504.  An |activation| >= 65504 turns the output non-finite, which raises *overflow (device int,
 // caller-owned, sticky) and the caller redoes the work with the fp32 library GEMM; weights are checked at pack time.  Values below the fp16 normal
 // range are carried by the scaled low part (tests cover 1e-7..1e-3).
 //
-// Tiling: workgroup = 8 waves = 256 (M) x 128 (N) outputs, K step 32, two LDS stages (2 x 48.25 KiB); each wave owns
+// Tiling (first kernel; the second differs in staging only, see its comment): workgroup = 8 waves = 256 (M) x 128 (N)
+// outputs, K step 32, two activation + five weight LDS stages; each wave owns
 // 64 x 64 = 2 x 2 MFMA blocks with hi+lo accumulators (128 VGPRs), 12 MFMAs per 8 ds_read_b128 per 16-deep k-step.
 // LDS images are MFMA-fragment ordered [plane][k-group of 8][row][8 halfs]: every fragment read is 512 contiguous
 // bytes per half wave (conflict-free); the activation image pads each k-group by 32 B so that the ds_write_b64 of the
