@@ -15,7 +15,8 @@ for f in sorted(glob.glob(out + "/*/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "linear_f16x2" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        print(f"{k}: mean {sum(v)/len(v):.4g} over {len(v)} launches")
+            kern = "pre_kernel" if "pre_kernel" in r["Kernel_Name"] else "kernel"
+            acc[(kern, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (kern, k), v in sorted(acc.items()):
+        print(f"linear_f16x2_{kern} {k}: mean {sum(v)/len(v):.4g} over {len(v)} launches")
 PY
