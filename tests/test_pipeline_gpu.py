@@ -218,13 +218,34 @@ def test_k1024_vs_reference_and_renderer_config():
     assert tuple(tok.shape) == (2, 1024)
     rec, lat = p.decoding(tok.cpu().numpy(), noise=synth.synthetic_noise(2), max_steps=2, return_latent=True)
     assert tuple(rec.shape) == (2, 3, 256, 256) and bool(torch.isfinite(lat).all())
+    # the FULL-SIZE leg of configs[2] (B = 64 x 1024 tokens; two of the 50 sampler steps keep the test short): same per-image results
+    # as the B = 2 call up to GEMM-tiling noise, in both arithmetics
+    tok64 = p.encoding(synth.synthetic_images(64, device="cuda"))
+    assert tuple(tok64.shape) == (64, 1024) and float((tok64[:2] == tok).float().mean()) >= 0.99
+    ids64 = tok64.cpu().numpy()
+    ids64[:2] = tok.cpu().numpy()
+    for gemm in ("fp32", "f16x2"):
+        assert p.set_gemm(gemm) == gemm
+        _, lat64 = p.decoding(ids64, noise=synth.synthetic_noise(64), max_steps=2, return_latent=True)
+        assert tuple(lat64.shape) == (64, 16, 32, 32) and bool(torch.isfinite(lat64).all())
+        d = float((lat64[:2] - lat).abs().max())
+        print(f"configs[2] full size (B=64, K=1024) [{gemm}]: latents of images 0-1 vs the B=2 fp32 call, max abs diff {d:.3e}")
+        assert d < 2e-4
     del p, sd
     torch.cuda.empty_cache()
     sd = W.synthetic_state_dict(W.expected_shapes(512, renderer=True), device="cuda")
     r = SelftokPipeline(default_config(512, renderer=True), None, None, device="cuda", state_dict=sd, vae_state_dict=vsd)
     r.verbose = False
-    rec = r.decoding_with_renderer(synth.synthetic_token_ids(2))
+    rec, lat = r.decoding_with_renderer(synth.synthetic_token_ids(2), return_latent=True)
     assert tuple(rec.shape) == (2, 3, 256, 256) and float(rec.min()) >= 0 and float(rec.max()) <= 1
+    # the FULL-SIZE leg of configs[3]: B = 256 through the one-step renderer, both arithmetics
+    for gemm in ("fp32", "f16x2"):
+        assert r.set_gemm(gemm) == gemm
+        rec256, lat256 = r.decoding_with_renderer(synth.synthetic_token_ids(256), return_latent=True)
+        assert tuple(rec256.shape) == (256, 3, 256, 256) and float(rec256.min()) >= 0 and float(rec256.max()) <= 1
+        d = float((lat256[:2] - lat).abs().max())
+        print(f"configs[3] full size (B=256 renderer) [{gemm}]: latents of images 0-1 vs the B=2 fp32 call, max abs diff {d:.3e}")
+        assert d < 2e-4
 
 
 def test_ema_decoder_option(pipe):
