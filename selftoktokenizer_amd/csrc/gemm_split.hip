@@ -332,14 +332,15 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_kernel(const float* __res
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Same product with the activations ALREADY split by the kernel that produced them (residual_ln_mod, the attention epilogue,
-// or this kernel's own GELU epilogue): A arrives as two row-major fp16 planes (hi, lo; same 4 bytes per element as fp32), so the
-// activation tile reaches LDS by LDS-DMA exactly like the weight tile -- no register staging, no VALU split, no ds_write, no
+// or this kernel's own GELU epilogue): A arrives as a "split activation" (common.h: fp16 hi / lo planes in 1-KiB chunks of 16 rows x
+// 32 k, the same 4 bytes per element as fp32; one chunk = one DMA piece = 8 full cache lines), so the activation tile reaches LDS by
+// LDS-DMA exactly like the weight tile -- no register staging, no VALU split, no ds_write, no
 // counted waits on registers.  The split is the same function of the fp32 value as `split4`, so the results are bit-identical
 // to linear_f16x2_kernel on the un-split tensor.
 //
 // LDS image of an activation tile: [plane][row 0..255][4 slots of 16 B], slot = k-group ^ ((row >> 2) & 3).  A DMA instruction
 // writes 1 KiB = 16 rows x 4 slots in lane order (that is all the hardware offers: M0 base + lane * 16), so the swizzle is applied
-// on the SOURCE side: lane (row, slot) fetches k-group slot ^ ((row >> 2) & 3) of its row -- still the same 64 B segment of that row.
+// on the SOURCE side: lane (row, slot) fetches k-group slot ^ ((row >> 2) & 3) of its row -- still inside the same contiguous chunk.
 // A fragment read (32 rows x one k-group per half wave) then touches each of the 64 banks once per 16 lanes.
 // Rings: 3 activation stages (32 KiB) + 4 weight stages (16 KiB) = the CU's whole 160 KiB; the DMAs of activation tile kt+2 and
 // weight tile kt+3 are issued at the top of iteration kt into the stages iteration kt-1 released at its barrier.
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
             }
     };
 
+    // The single-phase schedule (PP == 0; kept for tools/ablate_gemm_pre.py, the product runs the ping-pong loop below).
     // VM ops retire in issue order; per iteration a wave issues 4 activation DMAs (tile kt+2), then 2 weight DMAs (tile kt+3).
     // At the barrier that ends phase A of iteration kt, tile kt+1 must have landed: its activation DMAs were issued in iteration
     // kt-1 and may be followed by that iteration's 2 weight DMAs and this iteration's 6 -> vmcnt(8).
