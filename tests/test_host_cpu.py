@@ -288,3 +288,22 @@ def test_save_image_uses_the_tensor_dtype_arithmetic(tmp_path):
     preprocess.save_image(x, str(tmp_path / "f.png"))
     want32 = x.clone().mul_(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
     assert np.array_equal(np.array(Image.open(str(tmp_path / "f.png"))), want32)
+
+
+def test_header_is_plain_c_and_matches_the_ctypes_mirror(tmp_path):
+    """include/selftok_hip.h must compile as C (it is what a cgo / JNI / ctypes binding reads) and the descriptor struct the
+    Python side mirrors must have the same size and field offsets as the C one."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not installed")
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "selftok_hip.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(selftok_attn_seg), sizeof(selftok_attn_desc),\n'
+                   ' offsetof(selftok_attn_desc, kvis), offsetof(selftok_attn_desc, mode), offsetof(selftok_attn_desc, overflow), offsetof(selftok_attn_desc, o_blk));return 0;}\n')
+    exe = tmp_path / "abi"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    D = _lib.AttnDesc
+    assert got == [ctypes.sizeof(_lib.AttnSeg), ctypes.sizeof(D), D.kvis.offset, D.mode.offset, D.overflow.offset, D.o_blk.offset]
