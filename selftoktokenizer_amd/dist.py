@@ -43,26 +43,114 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class IdGatherer:
+    """The path's ONE exchange step: every rank contributes its [B_local,K] token ids and receives the whole [B_total,K] matrix.
+
+    One collective per step -- `all_gather_into_tensor` (ncclAllGather on RCCL) of an int32 payload (ids < 2^15) into a
+    preallocated [world * B_max, K] buffer.  The per-rank row counts are exchanged ONCE, here in the constructor (they are a
+    property of the sharding, not of a step), so a step has no second collective and no host synchronisation.  On a GPU the
+    collective is enqueued on a side stream behind an event of the producing stream: the caller's stream is free to start decoding
+    the local shard (each rank only needs ITS ids for that; the gathered matrix is the API result) and joins in `wait()`."""
+
+    def __init__(self, b_local: int, K: int, device, counts=None):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.K, self.b_local = int(K), int(b_local)
+        self.device = torch.device(device)
+        self.collectives = 0                    # collectives issued by step calls (tests assert one per step)
+        self._cpu_pg = self.world > 1 and dist.get_backend() == "gloo"
+        self._buf_dev = torch.device("cpu") if self._cpu_pg else self.device
+        if counts is None:
+            if self.world > 1:                  # setup-time exchange of the shard sizes (once per sharding, not per step)
+                mine = torch.tensor([self.b_local], dtype=torch.int64, device=self._buf_dev)
+                allc = torch.empty(self.world, dtype=torch.int64, device=self._buf_dev)
+                dist.all_gather_into_tensor(allc, mine)
+                counts = [int(c) for c in allc.cpu().tolist()]
+            else:
+                counts = [self.b_local]
+        assert len(counts) == self.world and counts[self.rank] == self.b_local, (counts, self.rank, self.b_local)
+        self.counts = list(counts)
+        self.bmax = max(self.counts) if self.counts else 0
+        self.even = all(c == self.bmax for c in self.counts)
+        self.send = torch.zeros(self.bmax, self.K, dtype=torch.int32, device=self._buf_dev)
+        self.recv = torch.empty(self.world * self.bmax, self.K, dtype=torch.int32, device=self._buf_dev)    # rank-major, concatenated along dim 0
+        self.stream = torch.cuda.Stream(device=self.device) if (self.world > 1 and self._buf_dev.type == "cuda") else None
+        self._done = None
+        self._t0 = self._t1 = None
+        self._host_ms = 0.0
+
+    @property
+    def payload_bytes(self) -> int:
+        return int(self.recv.numel() * 4) if self.world > 1 else 0
+
+    def launch(self, ids_local: torch.Tensor, timed: bool = False) -> None:
+        """enqueue the all-gather of this step's ids; returns at once (GPU: nothing waits on the host)"""
+        assert tuple(ids_local.shape) == (self.b_local, self.K), (tuple(ids_local.shape), (self.b_local, self.K))
+        self._dtype, self._out_dev, self._local = ids_local.dtype, ids_local.device, ids_local
+        if self.world == 1:
+            return
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))       # ids are produced on the caller's stream
+            with torch.cuda.stream(self.stream):
+                if timed:
+                    self._t0, self._t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    self._t0.record()
+                self.send[: self.b_local].copy_(ids_local, non_blocking=True)     # int64 -> int32 cast rides in the copy
+                dist.all_gather_into_tensor(self.recv, self.send)                 # THE collective of the step
+                if timed:
+                    self._t1.record()
+                self._done = torch.cuda.Event()
+                self._done.record()
+            ids_local.record_stream(self.stream)
+        else:                                                                     # gloo (CPU tests / one-GPU dry runs): host collective
+            import time
+            t0 = time.perf_counter()
+            self.send[: self.b_local].copy_(ids_local)
+            dist.all_gather_into_tensor(self.recv, self.send)
+            self._host_ms = 1000.0 * (time.perf_counter() - t0)
+        self.collectives += 1
+
+    def wait(self) -> torch.Tensor:
+        """[B_total,K] ids of every rank in rank order, in the dtype / on the device of the ids handed to launch()"""
+        if self.world == 1:
+            return self._local
+        if self._done is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._done)         # device-side join, no host wait
+        if self.even:
+            out = self.recv
+        else:
+            out = torch.cat([self.recv[r * self.bmax: r * self.bmax + self.counts[r]] for r in range(self.world)])
+        return out.to(device=self._out_dev, dtype=self._dtype, copy=True)     # `recv` is overwritten by the next launch
+
+    def last_ms(self) -> float:
+        """duration of the last launch(timed=True): HIP events on the side stream for RCCL (synchronises on them), host clock for gloo"""
+        if self.world == 1:
+            return 0.0
+        if self._t1 is not None:
+            self._t1.synchronize()
+            return float(self._t0.elapsed_time(self._t1))
+        return self._host_ms
+
+
+_gatherers = {}
+
+
+def id_gatherer(b_local: int, K: int, device) -> IdGatherer:
+    """the cached IdGatherer of a (shard size, K, device): built (and the shard sizes exchanged) on first use"""
+    key = (int(b_local), int(K), str(device), dist.get_world_size() if dist.is_initialized() else 1)
+    if key not in _gatherers:
+        _gatherers[key] = IdGatherer(b_local, K, device)
+    return _gatherers[key]
+
+
 def all_gather_ids(ids_local: torch.Tensor) -> torch.Tensor:
-    """[B_local,K] token ids (any int dtype) -> [B_total,K] on every rank, in rank order.
-    The payload travels as int32 (ids < 2^15); uneven shards are padded to the largest shard."""
+    """[B_local,K] token ids (any int dtype) -> [B_total,K] on every rank, in rank order: one collective per call (the first call
+    of a shard shape also exchanges the shard sizes).  Uneven shards are padded to the largest shard inside the payload."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return ids_local
-    world = dist.get_world_size()
-    K = ids_local.shape[1]
-    out_device = ids_local.device
-    if dist.get_backend() == "gloo" and ids_local.is_cuda:      # CPU collective (tests / single-GPU dry runs of the N>1 flow)
-        ids_local = ids_local.cpu()
-    n_local = torch.tensor([ids_local.shape[0]], dtype=torch.int64, device=ids_local.device)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local)
-    counts = [int(c.item()) for c in counts]
-    nmax = max(counts)
-    send = torch.zeros(nmax, K, dtype=torch.int32, device=ids_local.device)
-    send[: ids_local.shape[0]] = ids_local.to(torch.int32)
-    bufs = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(bufs, send)                       # ncclAllGather over xGMI on the GPU box
-    return torch.cat([bufs[r][: counts[r]] for r in range(world)]).to(ids_local.dtype).to(out_device)
+    g = id_gatherer(ids_local.shape[0], ids_local.shape[1], ids_local.device)
+    g.launch(ids_local)
+    return g.wait()
 
 
 def world_size() -> int:
@@ -98,21 +186,14 @@ def backend_name():
 
 
 def all_gather_ids_timed(ids_local: torch.Tensor):
-    """all_gather_ids + its duration in ms: HIP events on the current stream for RCCL (the collective is enqueued on the
-    stream, the host does not wait), host clock for gloo.  (ids_all, 0.0) with a single rank."""
+    """all_gather_ids + its duration in ms (HIP events on the collective's stream for RCCL, host clock for gloo); (ids, 0.0) with
+    a single rank.  Synchronises on the end event: benchmarks that overlap the gather with decode use IdGatherer directly."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return ids_local, 0.0
-    if dist.get_backend() == "nccl" and ids_local.is_cuda:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = all_gather_ids(ids_local)
-        e1.record()
-        e1.synchronize()
-        return out, float(e0.elapsed_time(e1))
-    import time
-    t0 = time.perf_counter()
-    out = all_gather_ids(ids_local)
-    return out, 1000.0 * (time.perf_counter() - t0)
+    g = id_gatherer(ids_local.shape[0], ids_local.shape[1], ids_local.device)
+    g.launch(ids_local, timed=True)
+    out = g.wait()
+    return out, g.last_ms()
 
 
 def barrier():
@@ -132,5 +213,6 @@ def max_over_ranks(value: float, device) -> float:
 
 
 def shutdown():
+    _gatherers.clear()
     if dist.is_initialized():
         dist.destroy_process_group()

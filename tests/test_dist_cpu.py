@@ -29,6 +29,60 @@ def _worker(rank, world, port, total, q):
     torch.distributed.destroy_process_group()
 
 
+def _step_worker(rank, world, port, total, q):
+    """a step issues exactly ONE collective (all_gather_into_tensor on a preallocated int32 buffer); the shard
+    sizes are exchanged once when the gatherer is built; the list-form all_gather is never used"""
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = D.init_from_env("gloo")
+    calls = {"into": 0, "list": 0, "other": 0}
+    real_into, real_list = dist.all_gather_into_tensor, dist.all_gather
+
+    def into(*a, **k):
+        calls["into"] += 1
+        return real_into(*a, **k)
+
+    def lst(*a, **k):
+        calls["list"] += 1
+        return real_list(*a, **k)
+    dist.all_gather_into_tensor, dist.all_gather = into, lst
+    for name in ("all_reduce", "broadcast", "all_to_all", "gather", "reduce_scatter", "all_gather_object"):
+        real = getattr(dist, name)
+        setattr(dist, name, (lambda real: lambda *a, **k: (calls.__setitem__("other", calls["other"] + 1), real(*a, **k))[1])(real))
+    lo, hi = D.shard_range(total, r, w)
+    g = D.id_gatherer(hi - lo, 512, "cpu")
+    setup = dict(calls)
+    ok = setup == {"into": 1, "list": 0, "other": 0} and g.counts == [D.shard_range(total, i, w)[1] - D.shard_range(total, i, w)[0] for i in range(w)]
+    per_step = []
+    for step in range(3):
+        all_ids = torch.from_numpy(synth.synthetic_token_ids(total, first_index=7 * step))
+        before = dict(calls)
+        g.launch(all_ids[lo:hi])
+        out = g.wait()
+        per_step.append({k: calls[k] - before[k] for k in calls})
+        ok = ok and bool(torch.equal(out, all_ids)) and out.dtype == torch.int64
+        ok = ok and bool(torch.equal(D.all_gather_ids(all_ids[lo:hi].to(torch.int32)), all_ids.to(torch.int32)))   # cached gatherer: 1 more
+    ok = ok and all(s == {"into": 1, "list": 0, "other": 0} for s in per_step) and g.collectives == 6
+    ok = ok and g.payload_bytes == w * g.bmax * 512 * 4
+    q.put((rank, ok, per_step))
+    D.shutdown()
+
+
+def test_one_collective_per_step_world2_gloo():
+    for total in (6, 5):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = 33500 + (os.getpid() % 2000) + total
+        procs = [ctx.Process(target=_step_worker, args=(r, 2, port, total, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert all(ok for _, ok, _ in res), res
+
+
 def _run(total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

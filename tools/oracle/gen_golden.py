@@ -1,7 +1,7 @@
 """Generate tests/golden/*.npz by running the REFERENCE (read-only import, build container only) on the
 hash-generated synthetic weights/inputs, and report how oracle/ compares on the same inputs.
 
-    python tools/oracle/gen_golden.py [stage ...]      stages: keys vq schedule encoder dit vae pipeline renderer cfg k1024 vqtrain
+    python tools/oracle/gen_golden.py [stage ...]      stages: keys vq schedule encoder dit vae pipeline pipeline16 renderer cfg k1024 vqtrain
 
 A golden file holds only data: inputs that cannot be regenerated from a seed, and the reference's
 outputs.  Weights/images/noise are regenerated from selftoktokenizer_amd.synth by name/seed.
@@ -295,6 +295,98 @@ def stage_pipeline():
                         lats=np.stack([xs[i].numpy() for i in keep]))
 
 
+def stage_pipeline16(B=16):
+    """The reference SelftokPipeline end to end on B = 16 synthetic images (one batch; 50 steps: ~45 min on 8 cores), to
+    CHARACTERISE the end-to-end parity through the bf16 VAE over more than one image:
+      reference side : VAE latents x0 (bf16-exact), pre-quantizer features z, token ids, top-1/top-2 gap and runner-up id of
+                       every token, the final latent of the 50-step loop, reconstruction PSNR vs the original per image;
+      oracle side    : the same images through oracle/ on this CPU (ids, and its VAE decode of the reference's final latents ->
+                       PSNR) = the spread between two CPU implementations of the same bf16 VAE (ldm-style mirror with 1x1-conv
+                       attention vs the diffusers layout with Linear attention) that the GPU's deviation is judged against."""
+    H.install()
+    import mimogpt.infer.SelftokPipeline as SP
+    cfg = H.load_cfg(CFG_256)
+    SP.AutoencoderKL = _MirrorVAE
+    shapes = W.expected_shapes(512)
+    real_load = torch.load
+    torch.load = lambda *a, **k: W.synthetic_state_dict(shapes)
+    try:
+        with H.fast_init():
+            pipe = SP.SelftokPipeline(cfg=cfg, ckpt_path="synthetic", sd3_path="synthetic", datasize=256, device="cpu")
+    finally:
+        torch.load = real_load
+    sd = dict(pipe.model.state_dict())
+    vsd = W.synthetic_vae_state_dict()
+    images = synth.synthetic_images(B)
+    cap = {}
+    hk1 = pipe.model.encoder.register_forward_pre_hook(lambda m, args: cap.setdefault("x0", args[0].detach().clone()))
+    hk2 = pipe.model.encoder.quantizer.project_in.register_forward_hook(lambda m, i, o: cap.setdefault("z", o.detach().clone()))
+    t0 = time.time()
+    tokens = pipe.encoding(images, device="cpu")
+    hk1.remove(); hk2.remove()
+    print(f"[ref] encoding B={B} {time.time() - t0:.1f}s", flush=True)
+    x0, z = cap["x0"], cap["z"]
+    assert torch.equal(x0, x0.to(torch.bfloat16).float())            # process_in runs in bf16: the latents are bf16-exact
+    cb = sd["encoder.quantizer._codebook.embed"][0]
+    xn = torch.nn.functional.normalize(z.reshape(-1, 16), dim=-1)
+    top2 = (xn @ cb.T).topk(2, dim=-1)
+    gap = (top2.values[:, 0] - top2.values[:, 1]).reshape(B, 512)
+    id2 = top2.indices[:, 1].reshape(B, 512)
+    assert bool((top2.indices[:, 0].reshape(B, 512) == tokens).float().mean() > 0.999)
+    t0 = time.time()
+    tok_o = OM.pipeline_encode(sd, vsd, images)
+    x0_o = OM.process_in(OM.vae_encode_mean(vsd, images.to(torch.bfloat16))).to(torch.float32)
+    z_o = OM.encoder_features(sd, x0_o)
+    print(f"[oracle] encoding B={B} {time.time() - t0:.1f}s", flush=True)
+    mism_o = (tok_o != tokens)
+    report("pipeline16_encode", images=B, oracle_ids_match=float((~mism_o).float().mean()), oracle_flips=int(mism_o.sum()),
+           oracle_flip_gaps=[round(float(v), 8) for v in gap[mism_o]], x0_maxdiff_oracle_vs_ref=maxdiff(x0_o, x0),
+           x0_rms_oracle_vs_ref=float((x0_o - x0).pow(2).mean().sqrt()), z_maxdiff_oracle_vs_ref=maxdiff(z_o, z))
+    # ---- 50-step decode of the reference (hash noise instead of torch.randn) ----
+    noise = synth.synthetic_noise(B)
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: noise.clone()
+    xs = []
+    hk = pipe.model.model.register_forward_pre_hook(lambda m, args: xs.append(args[0].detach().clone()))
+    real_loop = pipe.flow.p_sample_loop
+
+    def loop(*a, **k):
+        cap["lat"] = real_loop(*a, **k)
+        return cap["lat"]
+    pipe.flow.p_sample_loop = loop
+    t0 = time.time()
+    try:
+        rec = pipe.decoding(tokens.numpy(), device="cpu")
+    finally:
+        torch.randn = real_randn
+        hk.remove()
+        pipe.flow.p_sample_loop = real_loop
+    print(f"[ref] decoding B={B} {time.time() - t0:.1f}s", flush=True)
+    lat = cap["lat"].detach().float()
+    orig = (images + 1.0) / 2.0
+
+    def psnr_each(r):
+        mse = ((r.float() - orig) ** 2).reshape(B, -1).double().mean(dim=1)
+        return (10.0 * torch.log10(1.0 / mse)).numpy()
+    p_ref = psnr_each(rec)
+    # the oracle's sampler reproduces the reference's latents bit for bit (checked on the first two steps of this very batch), so
+    # the oracle's pixels = its VAE decode of the reference's final latents
+    stg, kps = OS.parse_stages(cfg.tokenizer.params.stages, cfg.tokenizer.params.k_per_stage)
+    trace = []
+    OM.decode_latent(sd, tokens, noise, stg, kps, 50, trace=trace, max_steps=2)
+    d2 = max(maxdiff(trace[0], xs[1]), maxdiff(trace[1], xs[2]))
+    rec_o = OM.norm_ip(OM.vae_decode(vsd, OM.process_out(lat).to(torch.bfloat16)))
+    p_or = psnr_each(rec_o)
+    d = np.abs(p_or - p_ref)
+    report("pipeline16_decode", images=B, oracle_latents_first2steps_maxdiff=d2, psnr_ref_mean=float(p_ref.mean()),
+           psnr_delta_oracle_vs_ref_mean=float(d.mean()), psnr_delta_oracle_vs_ref_max=float(d.max()),
+           psnr_delta_oracle_vs_ref_each=[round(float(v), 6) for v in d])
+    np.savez_compressed(os.path.join(GOLD, "pipeline_b16.npz"), tokens=tokens.numpy().astype(np.int16), id2=id2.numpy().astype(np.int16),
+                        gap=gap.numpy(), x0_bf16=x0.to(torch.bfloat16).view(torch.int16).numpy(), z=z.numpy(), lat=lat.numpy(),
+                        psnr_ref=p_ref, psnr_oracle=p_or, tokens_oracle=tok_o.numpy().astype(np.int16),
+                        x0_oracle_bf16=x0_o.to(torch.bfloat16).view(torch.int16).numpy())
+
+
 def stage_renderer():
     cfg, model, sd = tokenizer(CFG_RND)
     ids = torch.from_numpy(synth.synthetic_token_ids(1, first_index=7))
@@ -449,7 +541,7 @@ def stage_vqtrain():
 
 
 STAGES = dict(keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
-              vae=stage_vae, pipeline=stage_pipeline, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024, vqtrain=stage_vqtrain)
+              vae=stage_vae, pipeline=stage_pipeline, pipeline16=stage_pipeline16, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024, vqtrain=stage_vqtrain)
 
 if __name__ == "__main__":
     torch.set_grad_enabled(False)
