@@ -18,10 +18,15 @@ own torchrun launch is used as is.  Batch sharding (weak scaling, 64 images per 
 token ids per step (event-timed, reported), every rank decodes its slice of the GATHERED id matrix.
 
 Extra objects on the JSON line:
-  roofline          : the VQ nearest-code kernel (vq_mfma_kernel), timed live with HIP events on its launch stream.
+  roofline          : the VQ nearest-code kernel (vq_f16_kernel, the dominant launch of the VQ path), timed live with HIP events on
+                      its launch stream inside the timed steps: frac = EXECUTED f16-MFMA FLOPs / kernel time / the f16 matrix peak.
   roofline_kernels  : the other kernels a step is made of (attention, LN+modulate, fp32 GEMM, f16x2-split GEMM), event-timed
                       stand-alone at the shapes of the timed step.
   token_match       : token-id exact match of the timed batch against the CPU oracle (kernel boundary + end to end).
+  parity_16         : 16 images against the REFERENCE's own pipeline run (tests/golden/pipeline_b16.npz): id match, the reference
+                      top-1/top-2 gap of every flip, reconstruction-PSNR deltas (end to end and same-decoder), next to the
+                      CPU-oracle-vs-reference numbers on the same images.
+  latency_b1        : BASELINE configs[0]-style single image: encode + 50-step decode, eager vs hipGraph replay.
   gemm_modes        : the same step with the MMDiT Linears on the other GEMM arithmetic (fp32 library <-> f16x2 split).
   cpu_baseline      : oracle/ (our CPU restatement, verified equal to the reference) on this box's host cores, rank 0,
                       N=1 only, on a bounded sample (see "sample").
@@ -57,6 +62,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-token-check", action="store_true")
     ap.add_argument("--no-kernel-roofs", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 eager / hipGraph latency leg")
     ap.add_argument("--no-other-gemm", action="store_true", help="skip the second measurement on the other GEMM arithmetic")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="no GPU work: initialise the ranks, all-gather synthetic ids, print the JSON skeleton (CPU test of the N>1 entry)")
@@ -180,6 +186,155 @@ def event_time_ms(fn, n=10, warm=2):
     return e0.elapsed_time(e1) / n
 
 
+VQ_TRAFFIC_SOURCES = ("selftoktokenizer_amd/csrc/vq.hip", "selftoktokenizer_amd/csrc/common.h")
+
+
+def source_stamp(rel_paths=VQ_TRAFFIC_SOURCES) -> str:
+    """sha256 (16 hex) over the kernel sources a PMC measurement belongs to: a traffic figure is only quoted for the build it was taken on"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in rel_paths:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_vq_traffic(n_vq: int, coarse: bool, path=None):
+    """HBM-side bytes per VQ launch (main + finalize kernel) from the rocprofv3 PMC passes of THIS build
+    (tools/pmc_vq_traffic.sh -> profiles/vq_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, per-kernel correction factors
+    calibrated by tools/microbench/fetch_calib.hip in the same passes).  Returns (bytes or None, note): None when there is no
+    measurement for this (N, kernel) or when the file's source stamp is not the stamp of the sources in this tree."""
+    path = path or os.path.join(ROOT, "profiles", "vq_traffic.json")
+    key = f"N{n_vq}_f16" if coarse else f"N{n_vq}"
+    try:
+        d = json.load(open(path))
+    except Exception as e:                       # noqa: BLE001
+        return None, f"no traffic measurement ({type(e).__name__})"
+    now = source_stamp()
+    if d.get("source_stamp") != now:
+        return None, f"profiles/vq_traffic.json was measured on sources {d.get('source_stamp')}, this tree is {now}: stale, not quoted"
+    if key not in d:
+        return None, f"profiles/vq_traffic.json has no entry {key}"
+    return int(d[key]), f"rocprofv3 PMC, sources {now}: {d.get('method', '')}"
+
+
+def vq_roofline(n_vq, C, Dm, main_ms, fin_ms, launches, traffic, traffic_note, fp32_main_ms=None, fp32_fin_ms=None, ids_bytes=8):
+    """the `roofline` object of the JSON line, from measured kernel times.  Dominant kernel = vq_f16_kernel (the coarse pass: 3
+    v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 block of the score matrix): achieved = the f16-MFMA FLOPs it EXECUTES per launch
+    (3 x 2NCD) / its average launch duration, peak = the dense f16 matrix peak.  The fp32-equivalent rate of the reference's score
+    matrix is reported separately and never as `frac`."""
+    flops = 2.0 * n_vq * C * Dm                                   # the reference's fp32 score matrix (SURVEY 8d)
+    executed = 3.0 * flops                                        # f16 MFMA FLOPs the coarse kernel issues (hi*hi + hi*lo + lo*hi)
+    alg_bytes = 4.0 * n_vq * Dm + 4.0 * C * Dm + float(ids_bytes) * n_vq   # z + codebook (once) + ids
+    ach = executed / (main_ms * 1e-3) / 1e12
+    both = main_ms + fin_ms
+    roof = {"kernel": "vq_f16_kernel<RT> (f16 coarse pass of the cosine argmax; vq_finalize_f16_kernel re-scores the candidates in canonical fp32: "
+                      "ids and top-1 score bits equal the fp32 kernels')",
+            "bound": "mfma", "achieved": round(ach, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F16_MFMA_PEAK_TFLOPS, 4),
+            "traffic": traffic, "traffic_note": traffic_note,
+            "traffic_over_algorithmic_bytes": (round(traffic / alg_bytes, 2) if traffic else None),
+            "avg_launch_ms": round(main_ms, 4), "finalize_kernel_ms": round(fin_ms, 4), "both_launches_ms": round(both, 4), "launches": launches,
+            "executed_flops_per_launch": executed, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
+            "timing": "HIP events on the launch stream around each of the two launches of every VQ call inside the timed steps",
+            "fp32_equivalent": {"tflops": round(flops / (both * 1e-3) / 1e12, 2), "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
+                                "note": "2NCD of the reference's fp32 score matrix / (both launches); NOT a roofline fraction of this kernel (it runs on "
+                                        "the f16 matrix cores) -- kept for comparison with the fp32 kernel below"},
+            "hbm": {"achieved_GBs": round(alg_bytes / (both * 1e-3) / 1e9, 2), "frac_of_8TBs": round(alg_bytes / (both * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                    "note": "algorithmic bytes / both launches: ~7.7 kFLOP per byte at D = 16, the path is matrix bound by three orders of magnitude"},
+            "note": "frac = 3 * 2NCD / avg_launch_ms / 2500 TFLOP/s (N*C*D = %d x %d x %d); recompute from profiles/*kernel_stats.csv: the "
+                    "vq_f16_kernel row's average duration" % (n_vq, C, Dm)}
+    if fp32_main_ms:
+        a32 = flops / (fp32_main_ms * 1e-3) / 1e12
+        roof["fp32_mfma_kernel"] = {"kernel": "vq_mfma_kernel<RT> (round-1 kernel: exact fp32 products on v_mfma_f32_32x32x2_f32; same ids, bit for bit)",
+                                    "bound": "mfma(fp32)", "avg_launch_ms": round(fp32_main_ms, 4), "finalize_kernel_ms": round(fp32_fin_ms or 0.0, 4),
+                                    "achieved": round(a32, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(a32 / FP32_MFMA_PEAK_TFLOPS, 4)}
+    return roof
+
+
+GOLD16 = os.path.join(ROOT, "tests", "golden", "pipeline_b16.npz")
+
+
+def parity_16(pipe):
+    """16 images against the REFERENCE's own SelftokPipeline run on the same synthetic weights (tests/golden/pipeline_b16.npz, made by
+    tools/oracle/gen_golden.py pipeline16): token ids from pixels (through the bf16 VAE), the reference's top-1/top-2 gap of every
+    flipped token, and reconstruction PSNR -- end to end, and with the reference's final latents and ours through the SAME decoder
+    call -- next to what the CPU oracle (another implementation of the same bf16 VAE) gets on the same images."""
+    import numpy as np
+    import torch
+    from selftoktokenizer_amd import synth
+    g = np.load(GOLD16)
+    ref = g["tokens"].astype(np.int64)
+    B = ref.shape[0]
+    dev = pipe.device
+    imgs = synth.synthetic_images(B, device=dev)
+    x0 = pipe.encode_latents(imgs)
+    z = pipe.model.encoder.features(x0)
+    ids = pipe.model.encoder(x0, d=None)[1].cpu().numpy()
+    mism = ids != ref
+    x0_ref = torch.from_numpy(g["x0_bf16"]).view(torch.bfloat16).float()
+    dx = x0.cpu() - x0_ref
+    zn = torch.nn.functional.normalize(z.cpu().reshape(-1, 16), dim=-1)
+    zr = torch.nn.functional.normalize(torch.from_numpy(g["z"]).reshape(-1, 16), dim=-1)
+    dz = (zn - zr).norm(dim=-1).reshape(B, -1).numpy()              # |delta of the unit feature| per token: a score moves by at most this
+    mo = g["tokens_oracle"].astype(np.int64) != ref
+    out = {"images": B, "reference": "mimogpt.infer.SelftokPipeline on CPU (fp32 tokenizer, bf16 SDVAE mirror), tests/golden/pipeline_b16.npz",
+           "ids_match_vs_reference": round(float(1.0 - mism.mean()), 6), "flips": int(mism.sum()), "tokens": int(mism.size),
+           "flip_gaps_reference_top1_minus_top2": [round(float(v), 8) for v in np.sort(g["gap"][mism])],
+           "flips_to_the_reference_runner_up": int((ids[mism] == g["id2"].astype(np.int64)[mism]).sum()),
+           "unit_feature_delta_at_flips": [round(float(v), 8) for v in dz[mism][np.argsort(g["gap"][mism])]],
+           "unit_feature_delta_median_max": [round(float(np.median(dz)), 8), round(float(dz.max()), 8)],
+           "tokens_with_gap_below_2x_own_feature_delta": int((g["gap"] < 2.0 * dz).sum()),
+           "vae_latent_delta_vs_reference_max_rms": [round(float(dx.abs().max()), 5), round(float(dx.pow(2).mean().sqrt()), 6)],
+           "cpu_oracle_vs_reference": {"ids_match": round(float(1.0 - mo.mean()), 6), "flips": int(mo.sum()),
+                                       "flip_gaps": [round(float(v), 8) for v in np.sort(g["gap"][mo])]}}
+    if not pipe.model.model.renderer:
+        orig = (synth.synthetic_images(B) + 1.0) / 2.0
+
+        def psnr_each(px):
+            mse = ((px.float().cpu() - orig) ** 2).reshape(B, -1).double().mean(dim=1)
+            return (10.0 * torch.log10(1.0 / mse)).numpy()
+        rec, lat = pipe.decoding(ref, noise=synth.synthetic_noise(B), return_latent=True)        # the reference's ids and noise, 50 steps
+        lat_ref = torch.from_numpy(g["lat"]).to(dev)
+        d_e2e = np.abs(psnr_each(rec) - g["psnr_ref"])
+        both = pipe._to_pixels(torch.cat([lat_ref, lat]))                                        # one decoder call: only the latents differ
+        d_same = np.abs(psnr_each(both[:B]) - psnr_each(both[B:]))
+        d_or = np.abs(g["psnr_oracle"] - g["psnr_ref"])
+        out["psnr"] = {"unit": "dB, reconstruction PSNR vs the original image, |ours - reference| per image", "reference_mean_dB": round(float(g["psnr_ref"].mean()), 4),
+                       "end_to_end_delta_mean_max": [round(float(d_e2e.mean()), 6), round(float(d_e2e.max()), 6)],
+                       "same_decoder_delta_mean_max": [round(float(d_same.mean()), 7), round(float(d_same.max()), 7)],
+                       "cpu_oracle_vs_reference_delta_mean_max": [round(float(d_or.mean()), 6), round(float(d_or.max()), 6)],
+                       "final_latent_maxdiff_vs_reference": round(float((lat - lat_ref).abs().max()), 8),
+                       "note": "end to end = our latents through our bf16 VAE decoder (MIOpen) vs the reference's pixels; same decoder = the reference's "
+                               "final latents and ours through ONE call of our decoder (north star: 1e-3 dB); cpu oracle = oracle/'s CPU bf16 VAE on the "
+                               "reference's latents vs the reference's pixels: the spread between two implementations of the same bf16 network"}
+    return out
+
+
+def latency_b1(pipe, n=3):
+    """BASELINE configs[0]-style single image through the public API: encode + 50-step decode, launched eagerly (~21 k kernel launches) and
+    replayed from the hipGraph `decoding(use_graph=True)` captures once per shape"""
+    import numpy as np
+    import torch
+    from selftoktokenizer_amd import synth
+    img = synth.synthetic_images(1, device=pipe.device)
+
+    def once(graph):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tok = pipe.encoding(img)
+        t1 = time.perf_counter()
+        pipe.decoding(tok.cpu().numpy(), use_graph=graph)
+        torch.cuda.synchronize()
+        return 1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t0)
+    res = {}
+    for name, graph in (("eager", False), ("hipgraph", True)):
+        once(graph)                                    # warm-up (and the capture)
+        runs = [once(graph) for _ in range(n)]
+        res[name] = {"encode_ms": round(float(np.median([r[0] for r in runs])), 2), "encode_plus_decode_ms": round(float(np.median([r[1] for r in runs])), 2)}
+    res["note"] = "B = 1, 256x256, 512 tokens, 50 steps, gemm mode of the headline; encode_ms is host time to the returned (asynchronous) id tensor's launch end"
+    return res
+
+
 def kernel_roofs(pipe, B, K, k_table):
     """stand-alone, event-timed launches of the kernels a decode step is made of, at the shapes of the timed step
     (context rows = the mean live length over the 50 steps)."""
@@ -263,7 +418,9 @@ def token_match(pipe, images, tokens_gpu, sd_gpu, vsd_gpu, K, n_check=4):
         tables = OM.encoder_tables(sd, K)
         z_o = OM.encoder_features(sd, x0[:n_check].cpu(), tables)
         ids_same = OM.vq_ids(sd, z_o).numpy()
-        ids_e2e = OM.pipeline_encode(sd, vsd, images[:n_check].cpu(), tables).numpy()
+        x0_e2e = OM.process_in(OM.vae_encode_mean(vsd, images[:n_check].cpu().to(torch.bfloat16))).to(torch.float32)
+        z_e2e = OM.encoder_features(sd, x0_e2e, tables)                       # = OM.pipeline_encode, keeping the features for the gaps
+        ids_e2e = OM.vq_ids(sd, z_e2e).numpy()
 
         def gaps(ids_o, z_feat):
             mism = ids_o != ids_gpu[:n_check]
@@ -271,10 +428,10 @@ def token_match(pipe, images, tokens_gpu, sd_gpu, vsd_gpu, K, n_check=4):
                 return []
             xn = torch.nn.functional.normalize(z_feat.reshape(-1, 16), dim=-1)[torch.from_numpy(mism.reshape(-1))]
             top2 = (xn @ torch.from_numpy(cb).T).topk(2, dim=-1).values
-            return [round(float(g), 8) for g in (top2[:, 0] - top2[:, 1])]
+            return sorted(round(float(g), 8) for g in (top2[:, 0] - top2[:, 1]))
     return {"kernel_boundary": kb, "kernel_boundary_rows": int(ids_gpu.size),
             "e2e_same_latents": round(float((ids_same == ids_gpu[:n_check]).mean()), 6), "mismatch_gaps_same_latents": gaps(ids_same, z_o),
-            "e2e_vs_oracle": round(float((ids_e2e == ids_gpu[:n_check]).mean()), 6), "images_checked": n_check,
+            "e2e_vs_oracle": round(float((ids_e2e == ids_gpu[:n_check]).mean()), 6), "mismatch_gaps_e2e": gaps(ids_e2e, z_e2e), "images_checked": n_check,
             "note": "gap = oracle top-1 minus top-2 cosine score of each mismatching token (a flip needs an upstream difference larger than the gap); "
                     "e2e_vs_oracle additionally carries the bf16 VAE encoder (MIOpen vs CPU convolutions; the oracle itself matches the reference 99.8 % there)"}
 
@@ -334,17 +491,21 @@ def main(argv=None):
 
     ag = {"ms": [], "bytes": 0}
     last = {}
+    gather = D.id_gatherer(B, K, dev)          # shard sizes exchanged once, here; a step then issues exactly one collective
+    ag["bytes"] = gather.payload_bytes
 
     def step():
         tokens = pipe.encoding(images)                            # [B,K] int64 on device (public API)
-        ids_all, ms = D.all_gather_ids_timed(tokens)             # RCCL all-gather of the ids (no-op at N=1)
-        ag["ms"].append(ms)
-        ag["bytes"] = int(ids_all.shape[0] * ids_all.shape[1] * 4) if world > 1 else 0
-        mine = ids_all[rank * B:(rank + 1) * B].cpu().numpy()     # my slice of the GATHERED matrix, as the host array the API takes
+        gather.launch(tokens, timed=True)                         # ONE RCCL all-gather (int32 payload) on a side stream; no-op at N=1
+        mine = tokens.cpu().numpy()                               # a rank decodes its own shard: it needs only its own ids, as the host array the API takes
         last["tokens"] = tokens
         if renderer:
-            return pipe.decoding_with_renderer(mine)
-        return pipe.decoding(mine, max_steps=args.decode_steps)   # noise: torch.randn on the CPU generator, as the reference
+            out = pipe.decoding_with_renderer(mine)
+        else:
+            out = pipe.decoding(mine, max_steps=args.decode_steps)   # noise: torch.randn on the CPU generator, as the reference
+        last["ids_all"] = gather.wait()                           # the API result [world*B, K]: joined on the device, behind the decode
+        ag["ms"].append(gather.last_ms())
+        return out
 
     def timed(nsteps, nwarm):
         torch.manual_seed(1234 + rank)
@@ -370,7 +531,7 @@ def main(argv=None):
     if not args.no_other_gemm:
         alt = "f16x2" if gemm_main == "fp32" else "fp32"
         if pipe.set_gemm(alt) == alt:
-            n_alt = min(args.steps, 2)
+            n_alt = min(args.steps, 5)
             el_alt, _ = timed(n_alt, 1)
             other = {"gemm": alt, "value": round(world * B * n_alt / el_alt, 4), "unit": "images/s", "steps": n_alt, "warmup": 1,
                      "ms_per_step": round(1000.0 * el_alt / n_alt, 2)}
@@ -382,34 +543,12 @@ def main(argv=None):
     n_vq = B * K
     vq_main = float(np.mean([a.elapsed_time(b) for a, b, _ in vq_events])) if vq_events else float("nan")
     vq_fin = float(np.mean([b.elapsed_time(c) for _, b, c in vq_events])) if vq_events else float("nan")
-    vq_ms = vq_main + vq_fin
-    flops = 2.0 * n_vq * 32768 * 16
-    alg_bytes = 4.0 * n_vq * 16 + 4.0 * 32768 * 16 + 8.0 * n_vq          # z + codebook (once) + int64 ids
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "vq_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(f"N{n_vq}_f16" if ops.VQ_DEFAULT_COARSE else f"N{n_vq}")
-        except Exception:
-            traffic = None
     # the fp32-input MFMA kernel of round 1 on the same features, for reference (same ids, bit for bit)
     zf = pipe.model.encoder.features(pipe.encode_latents(images))
     _, lm, lf = ops.vq_encode_split_launch(zf, pipe.model.encoder.codebook_packed, coarse=False)
     fp32_main, fp32_fin = event_time_ms(lm, n=5), event_time_ms(lf, n=5)
-    roof = {"kernel": "vq_f16_kernel + vq_finalize_f16_kernel (f16 coarse pass, exact fp32 re-score: ids and score bits = the fp32 kernels')",
-            "bound": "mfma", "achieved": round(flops / (vq_ms * 1e-3) / 1e12, 2),
-            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / (vq_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": traffic, "avg_launch_ms": round(vq_ms, 4), "main_kernel_ms": round(vq_main, 4), "finalize_kernel_ms": round(vq_fin, 4),
-            "launches": len(vq_events), "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
-            "f16_mfma_frac_main_kernel": round(3 * flops / (vq_main * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 4),
-            "hbm_achieved_GBs": round(alg_bytes / (vq_ms * 1e-3) / 1e9, 2), "hbm_frac": round(alg_bytes / (vq_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-            "fp32_mfma_kernel_reference": {"kernel": "vq_mfma_kernel + vq_finalize_packed_kernel (round 1)", "avg_launch_ms": round(fp32_main + fp32_fin, 4),
-                                           "main_kernel_ms": round(fp32_main, 4), "achieved": round(flops / ((fp32_main + fp32_fin) * 1e-3) / 1e12, 2),
-                                           "frac": round(flops / ((fp32_main + fp32_fin) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
-            "note": "achieved = the 2*N*C*D FLOPs of the reference's fp32 score matrix (N*C*D = %d x 32768 x 16, ~7.9 kFLOP/B: matrix bound, not HBM "
-                    "bound, SURVEY.md 8d) / (both launches); peak = the fp32-input MFMA roof of that arithmetic.  frac > 1 is possible because the "
-                    "coarse pass runs as 3 f16 MFMAs per fp32 product on the 16x faster f16 cores and only the candidates inside the proven error "
-                    "window are re-scored in canonical fp32" % n_vq}
+    traffic, traffic_note = measured_vq_traffic(n_vq, ops.VQ_DEFAULT_COARSE)
+    roof = vq_roofline(n_vq, 32768, 16, vq_main, vq_fin, len(vq_events), traffic, traffic_note, fp32_main, fp32_fin)
     arith = {"fp32": "fp32 Q-Former/VQ/MMDiT (hipBLASLt fp32 GEMMs), bf16 SD3-VAE (reference dtypes)",
              "f16x2": "fp32 Q-Former/VQ/MMDiT with the MMDiT block Linears and joint attention as f16x2-split products on the f16 matrix cores "
                       "(fp32-equivalent: error vs fp64 below the fp32 kernels', tests/test_gemm_gpu.py, test_kernels_gpu.py), bf16 SD3-VAE"}
@@ -445,6 +584,10 @@ def main(argv=None):
         line["roofline_kernels"] = kernel_roofs(pipe, B, K, pipe.k_table)
     if not args.no_token_check:
         line["token_match"] = token_match(pipe, images, last["tokens"], sd, vsd, K)
+        if K == 512 and os.path.exists(GOLD16):
+            line["parity_16"] = parity_16(pipe)
+    if not args.no_latency and not renderer:
+        line["latency_b1"] = latency_b1(pipe)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, K)
         line["cpu_baseline_reference_survey"] = REFERENCE_SURVEY_BASELINE

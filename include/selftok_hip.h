@@ -132,8 +132,9 @@ int selftok_unpatchify_cfg_euler_f32(const float* y_cond, const float* y_uncond,
                                      int B, int C, int hp, int wp, float dt, float cfg_scale, hipStream_t stream);
 /* RMSNorm (modules.py:73-95; only with qk_norm='rms', unused by the shipped configs). */
 int selftok_rmsnorm_f32(const float* x, const float* w, float* out, long rows, int dim, float eps, hipStream_t stream);
-/* rotary embedding (mimogpt/utils/rotary_embedding_torch.py:37-53; no call site in the reference). */
-int selftok_rotary_f32(const float* t, const float* freqs, float* out, long rows, int seq, int dim, hipStream_t stream);
+/* rotary embedding: apply_rotary_emb(freqs, t, scale=) over the rotated slice (mimogpt/utils/rotary_embedding_torch.py:37-53; no call
+ * site in the reference).  t, out [rows, dim], freqs [seq, dim], row r uses freqs[r % seq]; interleaved pairs. */
+int selftok_rotary_f32(const float* t, const float* freqs, float* out, long rows, int seq, int dim, float scale, hipStream_t stream);
 
 /* ---- fp32-equivalent Linear on the f16 matrix cores ("f16x2 split") ---------------------------------
  * out[M,N] = act(A[M,K] W[N,K]^T + bias[N]),  fp32 in / fp32 out; replaces the fp32 nn.Linear GEMMs of the MMDiT

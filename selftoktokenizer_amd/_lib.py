@@ -35,7 +35,7 @@ SIGNATURES = {
     "selftok_patchify_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "selftok_unpatchify_cfg_euler_f32": (_i, [_vp] * 5 + [_i, _i, _i, _i, _f, _f, _vp]),
     "selftok_rmsnorm_f32": (_i, [_vp, _vp, _vp, _l, _i, _f, _vp]),
-    "selftok_rotary_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
+    "selftok_rotary_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _f, _vp]),
     "selftok_attn_f32": (_i, [_vp, _vp]),
     "selftok_residual_ln_mod_split": (_i, [_vp] * 8 + [_i, _i, _i, _l, _l, _l, _l, _f, _vp]),
     "selftok_linear_f16x2_packed_bytes": (_sz, [_i, _i]),

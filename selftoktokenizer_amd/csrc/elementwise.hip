@@ -247,10 +247,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     for (int c = gl; c < dim; c += 16) out[row * dim + c] = xr[c] * r * (w ? w[c] : 1.0f);
 }
 
-// rotary embedding (utils/rotary_embedding_torch.py:37-53): out = t*cos(f) + rotate_half(t)*sin(f),
+// rotary embedding (utils/rotary_embedding_torch.py:37-53): out = (t*cos(f))*scale + (rotate_half(t)*sin(f))*scale,
 // rotate_half on interleaved pairs (x1,x2) -> (-x2,x1).  Off the executed path (no call site in the reference).
 __global__ void rotary_kernel(const float* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ out,
-                              long rows, int seq, int dim)
+                              long rows, int seq, int dim, float scale)
 {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per pair
     long total = rows * (dim / 2);
@@ -261,8 +261,8 @@ __global__ void rotary_kernel(const float* __restrict__ t, const float* __restri
     const float* f = freqs + (size_t)pos * dim;
     float x1 = t[row * dim + 2 * pr], x2 = t[row * dim + 2 * pr + 1];
     float f1 = f[2 * pr], f2 = f[2 * pr + 1];
-    out[row * dim + 2 * pr] = x1 * cosf(f1) - x2 * sinf(f1);
-    out[row * dim + 2 * pr + 1] = x2 * cosf(f2) + x1 * sinf(f2);
+    out[row * dim + 2 * pr] = x1 * cosf(f1) * scale + (-x2) * sinf(f1) * scale;
+    out[row * dim + 2 * pr + 1] = x2 * cosf(f2) * scale + x1 * sinf(f2) * scale;
 }
 
 }  // namespace selftok
@@ -389,12 +389,12 @@ int selftok_rmsnorm_f32(const float* x, const float* w, float* out, long rows, i
     return check_launch("rmsnorm_kernel");
 }
 
-int selftok_rotary_f32(const float* t, const float* freqs, float* out, long rows, int seq, int dim, hipStream_t stream)
+int selftok_rotary_f32(const float* t, const float* freqs, float* out, long rows, int seq, int dim, float scale, hipStream_t stream)
 {
     if (!t || !freqs || !out || rows < 0 || seq <= 0 || dim <= 0 || (dim & 1)) { set_last_error("rotary: bad argument"); return SELFTOK_EINVAL; }
     long total = rows * (dim / 2);
     if (total == 0) return SELFTOK_OK;
-    hipLaunchKernelGGL(rotary_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, t, freqs, out, rows, seq, dim);
+    hipLaunchKernelGGL(rotary_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, t, freqs, out, rows, seq, dim, scale);
     return check_launch("rotary_kernel");
 }
 

@@ -247,6 +247,9 @@ constexpr float F16_SCORE_SCALE = F16_PRESCALE * F16_PRESCALE;
 // <= 1), the canonical chain's own 16 roundings <= 9.5e-7: < 2.4e-6 in the worst case.  The window is 3x that; measured maximum
 // over 1.7e7 scores: 3.0e-7 (tests/test_vq_gpu.py::test_vq_coarse_pass_error_bound_and_adversarial_near_ties).
 constexpr float F16_EPS = 7.62939453125e-06f;          // 2^-17
+// the bound above holds for |x|^2, |e|^2 <= 1; up to 1.01 it grows by 1 % (the window has a 3x margin).  Rows / code books beyond
+// it are flagged and take the exact scan (nothing enforced the unit-norm premise of the window).
+constexpr float F16_NORM2_MAX = 1.01f;
 
 // packed layout: tile t (32 codes) = 512 floats = [part 0..1][lane 0..63][4 floats]; lane l = (h = l>>5, i = l&31)
 // owns e[t*32+i][2m+h] for m = 4*part + j -- exactly the A fragments of the 8 chained 32x32x2 MFMAs, stored so that
@@ -275,6 +278,15 @@ __global__ void vq_pack_kernel(const float* __restrict__ cb, float* __restrict__
     p16[512 + ((k >> 3) * 32 + i) * 8 + (k & 7)] = (_Float16)(vs - (float)hi);
     if (suspicious(v)) atomicOr(reinterpret_cast<unsigned int*>(packed) + (size_t)C * D, 1u);
     if (!(fabsf(vs) < 60000.f)) atomicOr(reinterpret_cast<unsigned int*>(packed) + (size_t)C * D, 2u);     // outside the fp16 range
+    // F16_EPS is derived for unit-norm codes (sum |x_k e_k| <= |x| |e| <= 1): a code book that is not l2-normalised (the
+    // reference's always is, vector_quantize_pytorch.py:452,605) makes the coarse error scale with |e| and could leave the
+    // window -> flag it, every kernel of the coarse path then takes its exact scan (the fp32 kernels need no such bound)
+    if (k == 0) {
+        float n2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) n2 = __builtin_fmaf(cb[(size_t)c * D + j], cb[(size_t)c * D + j], n2);
+        if (!(n2 <= F16_NORM2_MAX)) atomicOr(reinterpret_cast<unsigned int*>(packed) + (size_t)C * D, 4u);
+    }
 }
 
 // running best of one lane for one x-row, MFMA flavour: the index is kept as (tile, register slot) so that the
@@ -392,7 +404,8 @@ __global__ __launch_bounds__(256) void vq_mfma_kernel(const float* __restrict__ 
             b[t][m] = __uint_as_float((__float_as_uint(xx[2 * m + 1]) & hmask) | (__float_as_uint(xx[2 * m]) & ~hmask));
     }
     // exact (NaN-aware) scan only if this wave holds a non-finite row or the pack step flagged the codebook
-    const bool slow = __any(xbad) || (reinterpret_cast<const uint32_t*>(packed)[(size_t)C * D] != 0u);
+    // metadata word: bit 0 = a code element is non-finite / absurd (bits 1, 2 concern the f16 coarse path only)
+    const bool slow = __any(xbad) || ((reinterpret_cast<const uint32_t*>(packed)[(size_t)C * D] & 1u) != 0u);
 
     const int ntiles_total = C >> 5;
     const int tile_first = blockIdx.y * tiles_per_split;
@@ -538,6 +551,12 @@ __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) xbad |= !(fabsf(xx[k]) < 400.f);      // NaN / inf / beyond fp16 after the 2^7 scaling
+        if (!normalize) {            // caller-normalised rows (SELFTOK_PRENORMED): the window needs |x| <= 1, check instead of trusting
+            float n2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; ++k) n2 = __builtin_fmaf(xx[k], xx[k], n2);
+            xbad |= !(n2 <= F16_NORM2_MAX);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             // bit-select between the two halves' elements (a `half ? a : b` on array elements becomes an indexed scratch access)

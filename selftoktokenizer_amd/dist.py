@@ -157,6 +157,10 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def rank() -> int:
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
 def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     """in-place SUM over ranks (RCCL all-reduce on the GPU box; the training-side VQ's bins / embed_sum); no-op with one rank"""
     if dist.is_initialized() and dist.get_world_size() > 1:
@@ -167,6 +171,26 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+def all_gather_rows(local: torch.Tensor, counts) -> torch.Tensor:
+    """[counts[rank], ...] rows of every rank -> [sum(counts), ...] in rank order; the shard sizes are known to every rank (no size
+    exchange).  One all_gather_into_tensor of shards padded to the largest (the reference: all_gather_variably_sized_v2,
+    vector_quantize_pytorch.py:262)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    counts = [int(c) for c in counts]
+    assert len(counts) == world and local.shape[0] == counts[rank], (counts, rank, tuple(local.shape))
+    cmax = max(counts)
+    cpu_pg = dist.get_backend() == "gloo" and local.is_cuda
+    src = local.cpu() if cpu_pg else local
+    send = torch.zeros((cmax,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    send[: counts[rank]] = src
+    recv = torch.empty((world * cmax,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(recv, send)
+    out = torch.cat([recv[r * cmax: r * cmax + counts[r]] for r in range(world)])
+    return out.to(local.device)
 
 
 def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:

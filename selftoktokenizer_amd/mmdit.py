@@ -89,7 +89,8 @@ class MMDiTGPU:
         """x fp32 [..., K], or a split activation (ops.SplitAct) when `self._pre(name)`; out_split: return the split form for the
         next Linear (only with a split input)."""
         w, b = self.w[name + ".weight"], self.w[name + ".bias"]
-        if x.dtype == torch.float16:
+        if isinstance(x, ops.SplitAct):
+            assert name in self._packed, f"split activation handed to Linear {name!r}, which has no f16x2-split weight (set_gemm('f16x2') packs the block Linears)"
             return ops.linear_f16x2_split(x, self._packed[name], b, w.shape[0], gelu=gelu, overflow=self.overflow, out_split=out_split)
         assert not out_split
         if self.gemm == "f16x2" and name in self._packed:
@@ -111,7 +112,8 @@ class MMDiTGPU:
         With a split input the residual update rides in the Linear's epilogue (one [B,T,H] fp32 round trip less) and the LN kernel
         only normalises; otherwise residual_ln_mod does both from the stored Linear output.  Same bits either way."""
         split = self._pre(consumer) if split is None else split
-        if lin_in.dtype == torch.float16:
+        if isinstance(lin_in, ops.SplitAct):
+            assert lin_name in self._packed, f"split activation handed to Linear {lin_name!r}, which has no f16x2-split weight"
             w, b = self.w[lin_name + ".weight"], self.w[lin_name + ".bias"]
             x = ops.linear_f16x2_split_residual(lin_in, self._packed[lin_name], b, w.shape[0], x, gate=gate, gate_per_sample=gate_per_sample,
                                                 overflow=self.overflow)
@@ -200,7 +202,7 @@ class MMDiTGPU:
                 t = tab[i]
                 ctx, cn2 = self._res_ln(pc + ".mlp.fc1", ctx, pc + ".attn.proj", oc, gate=t[:, 2 * H:3 * H], gate_per_sample=False,
                                         shift=t[:, 3 * H:4 * H], scale=t[:, 4 * H:5 * H])
-                h = self.lin(pc + ".mlp.fc1", cn2, gelu=True, out_split=cn2.dtype == torch.float16 and self._pre(pc + ".mlp.fc2"))
+                h = self.lin(pc + ".mlp.fc1", cn2, gelu=True, out_split=isinstance(cn2, ops.SplitAct) and self._pre(pc + ".mlp.fc2"))
                 nq = blk(i + 1, "context", "attn.qkv")
                 if i + 1 < DIT_DEPTH - 1:
                     tn = tab[i + 1]
@@ -213,7 +215,7 @@ class MMDiTGPU:
             mx = mods_x[i]
             x, xn2 = self._res_ln(px + ".mlp.fc1", x, px + ".attn.proj", ox, gate=mx[:, 2 * H:3 * H], gate_per_sample=True,
                                   shift=mx[:, 3 * H:4 * H], scale=mx[:, 4 * H:5 * H], per_sample=True)
-            h = self.lin(px + ".mlp.fc1", xn2, gelu=True, out_split=xn2.dtype == torch.float16 and self._pre(px + ".mlp.fc2"))
+            h = self.lin(px + ".mlp.fc1", xn2, gelu=True, out_split=isinstance(xn2, ops.SplitAct) and self._pre(px + ".mlp.fc2"))
             if not last:
                 mn = mods_x[i + 1]
                 x, xn = self._res_ln(blk(i + 1, "x", "attn.qkv"), x, px + ".mlp.fc2", h, gate=mx[:, 5 * H:6 * H], gate_per_sample=True,

@@ -22,12 +22,18 @@ def _stream():
 
 def _need_cuda(*ts):
     """every op launches on the CURRENT device's current stream: tensors on another GPU are refused (a kernel launched on
-    GPU 0's stream against GPU 1 pointers would fault or race) -- select the device first (SelftokPipeline does)."""
+    GPU 0's stream against GPU 1 pointers would fault or race) -- SelftokPipeline's entry points select their device themselves
+    (`with torch.cuda.device(...)`); direct callers of ops.* must do the same."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise _lib.SelftokHipError("selftok HIP ops need device tensors (there is no CPU fallback)")
-        if t is not None and t.device.index != torch.cuda.current_device():
-            raise _lib.SelftokHipError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+        if cur is None:
+            cur = torch.cuda.current_device()            # once per op, not once per tensor (host-bound small-batch decode loop)
+        if t.device.index != cur:
+            raise _lib.SelftokHipError(f"tensor on {t.device} but the current device is cuda:{cur}: "
                                        "call torch.cuda.set_device / use `with torch.cuda.device(...)` first")
 
 
@@ -222,8 +228,8 @@ def linear_f16x2(x: torch.Tensor, packed: torch.Tensor, bias, N: int, gelu: bool
     K = x.shape[-1]
     assert x.dtype == torch.float32 and packed.numel() * 2 == 4 * N * K, "packed weight does not match (N, K)"
     x2 = x.reshape(-1, K)
-    if x2.stride(1) != 1 or (x2.shape[0] > 1 and (x2.stride(0) % 4 or x2.stride(0) < K)):
-        x2 = x2.contiguous()
+    if x2.stride(1) != 1 or (x2.shape[0] > 1 and (x2.stride(0) % 4 or x2.stride(0) < K)) or x2.data_ptr() % 16:
+        x2 = x2.contiguous()                              # the kernel reads rows with 16-byte loads
     M = x2.shape[0]
     out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     lda = x2.stride(0) if M > 1 else K
@@ -379,15 +385,22 @@ def rmsnorm(x, w=None, eps=1e-6):
     return out
 
 
-def rotary(t, freqs):
-    """t [..., seq, dim], freqs [seq, dim]"""
+def rotary(t, freqs, start_index: int = 0, scale: float = 1.0):
+    """apply_rotary_emb(freqs, t, start_index, scale) (utils/rotary_embedding_torch.py:37-53): t [..., seq, dim], freqs [seq, rot_dim];
+    features start_index .. start_index + rot_dim are rotated, the rest passes through."""
     _need_cuda(t, freqs)
     t = t.contiguous().float()
     freqs = freqs.contiguous().float()
-    seq, dim = freqs.shape
-    out = torch.empty_like(t)
-    _lib.check(_lib.load().selftok_rotary_f32(_p(t), _p(freqs), _p(out), t.numel() // dim, seq, dim, _stream()), "selftok_rotary_f32")
-    return out
+    seq, rot = freqs.shape
+    dim = t.shape[-1]
+    if rot > dim - start_index:
+        raise ValueError(f"feature dimension {dim} is not of sufficient size to rotate in all the positions {rot}")
+    mid = t if (start_index == 0 and rot == dim) else t[..., start_index:start_index + rot].contiguous()
+    out = torch.empty_like(mid)
+    _lib.check(_lib.load().selftok_rotary_f32(_p(mid), _p(freqs), _p(out), mid.numel() // rot, seq, rot, float(scale), _stream()), "selftok_rotary_f32")
+    if mid is t:
+        return out
+    return torch.cat((t[..., :start_index], out, t[..., start_index + rot:]), dim=-1)
 
 
 # ----------------------------------------------------------------------------------------------

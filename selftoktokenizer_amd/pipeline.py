@@ -110,6 +110,18 @@ class _Flow(FlowSchedule):
         return x
 
 
+def _on_own_device(fn):
+    """run a public entry point with the pipeline's GPU as the current device: every HIP launch goes to the current device's
+    stream, and a process may hold several pipelines on different GPUs or change the current device between calls"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 class SelftokPipeline():
     def __init__(self, cfg, ckpt_path, sd3_path, datasize=256, start=1.0, cfg_scale=1, model_type='sd3',
                  dtype=torch.bfloat16, ema_decoder=False, device=None, state_dict: Optional[Dict[str, torch.Tensor]] = None,
@@ -127,8 +139,14 @@ class SelftokPipeline():
             raise ValueError(f"Unsupported MODEL_TYPE: {model_type}. Expected 'sd3'")
         self.cfg, self.datasize, self.model_type, self.dtype = cfg, datasize, model_type, dtype
         self.device = torch.device(device)
-        if self.device.type == "cuda" and self.device.index is not None:
-            torch.cuda.set_device(self.device)                                # our launches use the current device's stream
+        if self.device.type != "cuda":
+            raise _lib.SelftokHipError(f"SelftokPipeline needs a GPU device, got {self.device}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(self.device):                                  # our launches use the current device's stream
+            self._build(cfg, ckpt_path, sd3_path, start, cfg_scale, dtype, ema_decoder, state_dict, vae_state_dict, verbose, gemm)
+
+    def _build(self, cfg, ckpt_path, sd3_path, start, cfg_scale, dtype, ema_decoder, state_dict, vae_state_dict, verbose, gemm):
         p = cfg.tokenizer.params
         p.noise_schedule_config.is_eval = cfg.common.is_eval
         # configuration knobs the reference honours but this hot path does not implement: refuse, never ignore silently
@@ -158,7 +176,7 @@ class SelftokPipeline():
         self.ema_decoder = ema_decoder
         dit_sd = sd
         if ema_decoder:   # reference :193-194: EMA copy of the DiT under 'ema_state_dict' (keys without the 'model.' prefix)
-            dit_sd = {("model." + k if not k.startswith("model.") else k): v for k, v in sd["ema_state_dict"].items()}
+            dit_sd = {"model." + k: v for k, v in sd["ema_state_dict"].items()}       # strict contract checked above: bare MMDiT keys only
         encoder = QformerEncoderGPU(sd, self.device, K)
         dit = MMDiTGPU(dit_sd, self.device, K, renderer=renderer)
         dit.set_gemm(gemm or os.environ.get("SELFTOK_GEMM") or DEFAULT_GEMM)
@@ -181,12 +199,14 @@ class SelftokPipeline():
             print(msg)
 
     # ------------------------------------------------------------------------------------------------
+    @_on_own_device
     @torch.no_grad()
     def encode_latents(self, images: torch.Tensor) -> torch.Tensor:
         """VAE mean -> SD3LatentFormat.process_in -> fp32 (reference :214-218)"""
         moments = self.vae.encode_moments(images.to(dtype=self.dtype, device=self.device))
         return ops.latent_process_in(moments.contiguous(), moments.shape[1] // 2, SD3_SHIFT, SD3_SCALE)
 
+    @_on_own_device
     @torch.no_grad()
     def encoding(self, images, device=None):
         self._say("Begin encoding.")
@@ -195,6 +215,7 @@ class SelftokPipeline():
         self._say('End encoding.')
         return tokens
 
+    @_on_own_device
     @torch.no_grad()
     def _codes(self, idx) -> torch.Tensor:
         if isinstance(idx, np.ndarray):
@@ -209,12 +230,14 @@ class SelftokPipeline():
         B = token_idx.shape[0]
         return self.model.encoder.codes_ln(token_idx.reshape(B, -1))          # get_output_from_indices + final_layer_norm3
 
+    @_on_own_device
     @torch.no_grad()
     def _to_pixels(self, pred_x0: torch.Tensor) -> torch.Tensor:
         z = ops.latent_process_out(pred_x0, SD3_SHIFT, SD3_SCALE)             # process_out + .to(bf16) (:285-287)
         recons = self.vae.decode(z)[0].contiguous()
         return norm_ip(recons, -1, 1)
 
+    @_on_own_device
     def set_gemm(self, mode: str) -> str:
         """switch the MMDiT block Linears between 'fp32' and 'f16x2' (see MMDiTGPU.set_gemm); returns the mode in force"""
         return self.model.model.set_gemm(mode)
@@ -228,11 +251,11 @@ class SelftokPipeline():
         if dit.gemm == "f16x2" and int(dit.overflow.item()) != 0:
             print("[selftok] f16x2 GEMM: activation outside the fp16 range -> recomputing this call with fp32 GEMMs")
             dit.overflow.zero_()
-            dit.gemm = "fp32"
+            dit.set_gemm("fp32")
             try:
                 out = run()
             finally:
-                dit.gemm = "f16x2"
+                dit.set_gemm("f16x2")              # the split weights are kept: no re-pack
         return out
 
     @torch.no_grad()
@@ -263,6 +286,7 @@ class SelftokPipeline():
         g.replay()
         return s_out.clone()
 
+    @_on_own_device
     @torch.no_grad()
     def decoding(self, idx, device=None, noise: Optional[torch.Tensor] = None, return_latent: bool = False,
                  max_steps: Optional[int] = None, uncond_scale: float = 1.0, use_graph: bool = False,
@@ -287,6 +311,7 @@ class SelftokPipeline():
         self._say('End decoding.')
         return (recons, pred_x0) if return_latent else recons
 
+    @_on_own_device
     @torch.no_grad()
     def decoding_with_renderer(self, idx, device=None, return_latent: bool = False):
         """one MMDiT_Renderer pass instead of the 50-step loop (reference :296-322)"""

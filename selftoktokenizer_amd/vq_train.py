@@ -111,20 +111,28 @@ class CodebookEMA:
 
     def expire_codes_(self, z: torch.Tensor, generator: Optional[torch.Generator] = None) -> int:
         """expire_codes_ + replace (:488-523): dead codes are replaced by batch vectors sampled with the smart-reactivation weights.
-        Every rank must install the SAME vectors: rank 0 samples from its batch and broadcasts (the reference samples per rank and
-        gathers, sample_vectors_distributed :262-277)."""
+        Data parallel as the reference's sample_vectors_distributed (:249-265): rank r draws its share n // world (+1 for the first
+        n % world ranks) from ITS batch and the shares are all-gathered in rank order, so the replacements come from the global
+        batch and every rank installs the same vectors.  (The dead-code mask is a function of the all-reduced cluster sizes: the
+        same on every rank.)"""
         if self.threshold_rel == 0:
             return 0
         mask = self.expired_codes()
-        n = int(mask.sum().item())
+        n = int(mask.sum().item())               # one host read per training step, as the reference's `if not torch.any(...)` (:510)
         if n == 0:
             return 0
         samples = l2norm(z.float()).reshape(-1, z.shape[-1])                             # replace(): batch_samples = l2norm(...)
         b = samples.shape[0] // self.K
         p = (self.timestep_weight() / b)[None, :].expand(b, -1).reshape(-1)              # :491-496
-        pick = torch.multinomial(p, n, replacement=True, generator=generator)
-        new_codes = samples[pick]
-        D.broadcast_(new_codes, src=0)
+        world, rank = D.world_size(), D.rank()
+        shares = [n // world + (1 if r < n % world else 0) for r in range(world)]
+        mine = shares[rank]
+        if mine > 0:
+            pick = torch.multinomial(p, mine, replacement=True, generator=generator)
+            local = samples[pick]
+        else:
+            local = samples[:0]
+        new_codes = D.all_gather_rows(local.contiguous(), shares)
         self.change_code(mask.nonzero()[:, 0], new_codes)
         return n
 

@@ -324,7 +324,11 @@ def check_tokenizer_state_dict(sd: Dict[str, torch.Tensor], K: int, renderer: bo
     mism = [f"{k}: checkpoint {tuple(sd[k].shape)} vs model {tuple(v)}" for k, v in need.items() if k in sd and tuple(sd[k].shape) != tuple(v)]
     if mism:
         raise RuntimeError("size mismatch for " + "; ".join(mism[:8]) + (" ..." if len(mism) > 8 else ""))
-    missing = [k for k in need if k not in sd and not (ema and k.startswith("model."))]
+    # parameters of the reference model that the encode / decode path never reads (the class-label embedder of the MMDiT, two
+    # LayerNorms of the encoder that only the training forward uses): an inference-only / pruned checkpoint without them loads in
+    # the reference (strict=False) and must load here too
+    unused = ("model.y_embedder.", "encoder.final_layer_norm.", "encoder.final_layer_norm2.")
+    missing = [k for k in need if k not in sd and not (ema and k.startswith("model.")) and not k.startswith(unused)]
     if missing:
         raise RuntimeError(f"{len(missing)} tokenizer parameters are missing from the checkpoint (the reference would silently keep random "
                            f"initial values, strict=False): {missing[:6]}{' ...' if len(missing) > 6 else ''}")

@@ -221,6 +221,10 @@ def test_tokenizer_checkpoint_contract(tmp_path):
     part = {k: v for k, v in meta.items() if k != "encoder.query_tokens"}
     with pytest.raises(RuntimeError, match="missing"):
         W.check_tokenizer_state_dict(part, 512)
+    # a pruned / inference-only checkpoint without the parameters the encode/decode path never reads loads (strict=False in the reference)
+    pruned = {k: v for k, v in meta.items() if not k.startswith(("model.y_embedder.", "encoder.final_layer_norm.", "encoder.final_layer_norm2."))}
+    assert len(pruned) < len(meta)
+    W.check_tokenizer_state_dict(pruned, 512)
     # ema_decoder=True: the DiT comes from state_dict['ema_state_dict'] (keys without 'model.'), strict
     enc_only = {k: v for k, v in meta.items() if not k.startswith("model.")}
     with pytest.raises(KeyError):
@@ -307,3 +311,39 @@ def test_header_is_plain_c_and_matches_the_ctypes_mirror(tmp_path):
     got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     D = _lib.AttnDesc
     assert got == [ctypes.sizeof(_lib.AttnSeg), ctypes.sizeof(D), D.kvis.offset, D.mode.offset, D.overflow.offset, D.o_blk.offset]
+
+
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod_host", os.path.join(root, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_roofline_object_is_a_fraction_of_the_pipe_the_kernel_runs_on(tmp_path):
+    """frac = EXECUTED f16-MFMA FLOPs of the timed kernel / the f16 peak (0 < frac <= 1, recomputable from a
+    kernel-stats row), the fp32-equivalent rate is a separate field, the fp32 kernel gets its own fraction of the fp32 peak, and a
+    traffic figure is only quoted when it was measured on the sources of this tree."""
+    m = _bench_module()
+    # round-2 record (profiles/r2_bench_f16x2_presplit_kernel_stats.csv: 92.2 us main + 10.0 us finalize; fp32 kernel 262.4 us)
+    r = m.vq_roofline(32768, 32768, 16, 0.0922, 0.0100, 20, None, "none", 0.2624, 0.0100)
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and r["unit"] == "TFLOP/s"
+    assert abs(r["frac"] - 3 * 2 * 32768 * 32768 * 16 / 92.2e-6 / 2.5e15) < 1e-3 and 0 < r["frac"] <= 1
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-4
+    assert "frac" not in r["fp32_equivalent"] and r["fp32_equivalent"]["tflops"] > 157.3        # reported, never as a fraction
+    assert abs(r["fp32_mfma_kernel"]["frac"] - 0.8324) < 2e-3 and r["fp32_mfma_kernel"]["peak"] == 157.3
+    assert r["traffic"] is None and r["traffic_over_algorithmic_bytes"] is None
+    assert r["algorithmic_bytes"] == 4 * 32768 * 16 + 4 * 32768 * 16 + 8 * 32768
+    # traffic: stale stamp -> None; matching stamp -> the measured bytes
+    p = tmp_path / "vq_traffic.json"
+    p.write_text(json.dumps({"source_stamp": "0" * 16, "N32768_f16": 123}))
+    t, note = m.measured_vq_traffic(32768, True, str(p))
+    assert t is None and "stale" in note
+    p.write_text(json.dumps({"source_stamp": m.source_stamp(), "N32768_f16": 30000000, "method": "test"}))
+    t, note = m.measured_vq_traffic(32768, True, str(p))
+    assert t == 30000000
+    assert m.measured_vq_traffic(65536, True, str(p))[0] is None and m.measured_vq_traffic(32768, True, str(tmp_path / "nope.json"))[0] is None
+    r = m.vq_roofline(32768, 32768, 16, 0.0922, 0.0100, 20, t, note)
+    assert r["traffic"] == 30000000 and abs(r["traffic_over_algorithmic_bytes"] - 30000000 / 4456448) < 0.01

@@ -1,6 +1,8 @@
 """-m gpu: every fused HIP kernel (through the C ABI) against a plain torch fp32 reference of the same op."""
 import math
+import os
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -98,14 +100,21 @@ def test_unpatchify_cfg_euler():
 
 
 def test_rmsnorm_rotary():
+    """SURVEY 8a rows a31 / a32 against vectors produced by the REFERENCE's own RMSNorm class and apply_rotary_emb
+    (tests/golden/rmsnorm_rotary.npz, tools/oracle/gen_golden.py rmsnorm_rotary); inputs regenerate from synth by seed."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rmsnorm_rotary.npz"))
     x, w = U(14, (7, 24, 64), -2, 2), U(15, (64,), 0.9, 1.1)
-    ref = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * w
-    torch.testing.assert_close(ops.rmsnorm(x.cuda(), w.cuda()).cpu(), ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ops.rmsnorm(x.cuda(), w.cuda()).cpu(), torch.from_numpy(g["rms_affine"]), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ops.rmsnorm(x.cuda(), None).cpu(), torch.from_numpy(g["rms_plain"]), rtol=1e-5, atol=1e-6)
+    x2 = U(18, (5, 3, 256), -4, 4)
+    torch.testing.assert_close(ops.rmsnorm(x2.cuda(), None, eps=1e-5).cpu(), torch.from_numpy(g["rms_256"]), rtol=1e-5, atol=1e-6)
     t, f = U(16, (2, 3, 10, 32), -2, 2), U(17, (10, 32), -3, 3)
-    x1, x2 = t[..., 0::2], t[..., 1::2]
-    rot = torch.stack((-x2, x1), dim=-1).flatten(-2)
-    ref = t * f.cos() + rot * f.sin()
-    torch.testing.assert_close(ops.rotary(t.cuda(), f.cuda()).cpu(), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ops.rotary(t.cuda(), f.cuda()).cpu(), torch.from_numpy(g["rot_full"]), rtol=1e-5, atol=1e-5)
+    f16 = U(19, (10, 16), -3, 3)
+    torch.testing.assert_close(ops.rotary(t.cuda(), f16.cuda(), start_index=8).cpu(), torch.from_numpy(g["rot_partial_start8"]), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ops.rotary(t.cuda(), f.cuda(), scale=0.5).cpu(), torch.from_numpy(g["rot_scaled"]), rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        ops.rotary(t.cuda(), f.cuda(), start_index=8)
 
 
 def _ref_joint_attention(ctx_qkv, x_qkv, H, kvis, see):

@@ -216,3 +216,34 @@ def test_vq_empty_and_bad_arguments(cb):
     ids = ops.vq_encode(synth.synthetic_vq_rows(7).cuda(), cbc[:100])    # ... but the generic kernel takes any C
     from oracle import clib
     np.testing.assert_array_equal(ids.cpu().numpy(), clib.vq_encode(synth.synthetic_vq_rows(7).numpy(), cb[:100].numpy())[0])
+
+
+def test_vq_coarse_path_guards_its_unit_norm_premise(cb):
+    """the f16 coarse pass is exact only for |x|, |e| <= 1 (F16_EPS is derived for unit vectors).  A code book that
+    is not l2-normalised, or caller-normalised rows (prenormed=True) that are not unit length, must not silently return a wrong id:
+    the pack step / the kernel flag them and the exact scan runs.  Checked against the C oracle, ids and score bits."""
+    from oracle import clib
+    z = synth.synthetic_vq_rows(700, seed=0xBADC0DE)
+    # (a) code book of norm ~10 (rows of very different norms), rows normalised by the kernel
+    scale = (1.0 + 9.0 * synth.hash_uniform(0x5CA1E, (cb.shape[0], 1), 0.0, 1.0))
+    cb10 = (cb * scale).contiguous()
+    ids_ref, best_ref = clib.vq_encode(z.numpy(), cb10.numpy())
+    pk = ops.vq_pack_codebook(cb10.cuda())
+    for coarse in (True, False):
+        ids, best = ops.vq_encode(z.cuda(), pk, packed=True, return_best=True, coarse=coarse)
+        np.testing.assert_array_equal(ids.cpu().numpy(), ids_ref, err_msg=f"norm-10 code book, coarse={coarse}")
+        np.testing.assert_array_equal(best.cpu().numpy().view(np.uint32), best_ref.view(np.uint32))
+    # (b) unit code book, prenormed=True with rows that are NOT unit length (norm ~4 .. 40): the coarse error scales with |x|
+    zz = (z * 10.0).contiguous()
+    ids_ref, best_ref = clib.vq_encode(zz.numpy(), cb.numpy(), normalize=False)
+    pk1 = ops.vq_pack_codebook(cb.cuda())
+    for coarse in (True, False):
+        ids, best = ops.vq_encode(zz.cuda(), pk1, packed=True, return_best=True, prenormed=True, coarse=coarse)
+        np.testing.assert_array_equal(ids.cpu().numpy(), ids_ref, err_msg=f"non-unit prenormed rows, coarse={coarse}")
+        np.testing.assert_array_equal(best.cpu().numpy().view(np.uint32), best_ref.view(np.uint32))
+    # (c) honest prenormed rows (unit length by the canonical l2norm) still take the fast path and agree
+    zn = torch.from_numpy(clib.l2norm16(z.numpy()))
+    ids_ref, best_ref = clib.vq_encode(zn.numpy(), cb.numpy(), normalize=False)
+    ids, best = ops.vq_encode(zn.cuda(), pk1, packed=True, return_best=True, prenormed=True, coarse=True)
+    np.testing.assert_array_equal(ids.cpu().numpy(), ids_ref)
+    np.testing.assert_array_equal(best.cpu().numpy().view(np.uint32), best_ref.view(np.uint32))

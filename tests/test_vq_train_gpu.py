@@ -82,3 +82,45 @@ def test_kmeans_iteration_vs_reference():
     means, bins = cb.kmeans_iteration(samples, samples[:256].clone())
     np.testing.assert_array_equal(bins.cpu().numpy().astype(np.int64), g["kmeans_bins"])
     assert float((means.cpu() - torch.from_numpy(g["kmeans_means"])).abs().max()) <= 2e-6
+
+
+def _two_rank_worker(rank, world, port, q):
+    """one of two data-parallel ranks, both on GPU 0, collectives over gloo (single-GPU box): half of the batch each"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from selftoktokenizer_amd import dist as Dd
+    Dd.init_from_env("gloo")
+    torch.cuda.set_device(0)
+    cb = CodebookEMA(l2norm(synth.hash_normalish(0xD1, (C, D))).cuda(), K, threshold_ema_dead_code=0.2, reset_cluster_size=0.2)
+    z = synth.hash_normalish(0xD2, (B, K, D))
+    lo, hi = Dd.shard_range(B, rank, world)
+    gen = torch.Generator(device="cuda").manual_seed(100 + rank)          # different random streams per rank, as in real training
+    _, ids, n = cb.step(z[lo:hi].cuda(), generator=gen)
+    x_all = l2norm(z).reshape(-1, D).cuda()
+    replaced = cb.cluster_size == cb.reset_abs
+    src = (cb.embed[replaced] @ x_all.t()).argmax(dim=1)                  # which global batch row each replacement is
+    rows_per_rank = (hi - lo) * K
+    q.put((rank, n, cb.embed.cpu().numpy().tobytes(), cb.cluster_size.cpu().numpy().tobytes(),
+           float(((cb.embed[replaced] @ x_all.t()).max(dim=1).values - 1.0).abs().max()),
+           [int(((src // rows_per_rank) == r).sum()) for r in range(world)], ids.cpu().numpy().tobytes()))
+    Dd.shutdown()
+
+
+def test_codebook_step_two_ranks_installs_identical_codes_from_the_global_batch():
+    """multi-rank expire_codes_ must draw the replacements from the GLOBAL batch (every rank samples its share, the shares are
+    all-gathered: vector_quantize_pytorch.py:249-265) and leave every rank with the same code book.  Two ranks on one GPU over gloo."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, n0, e0, c0, d0, s0, _), (_, n1, e1, c1, d1, s1, _) = res
+    assert n0 == n1 and n0 > 0
+    assert e0 == e1 and c0 == c1                        # identical code book and statistics on both ranks
+    assert d0 < 1e-5 and d1 < 1e-5                      # every replacement is a unit-norm vector of the global batch
+    assert s0 == s1 and abs(s0[0] - s0[1]) <= 1 + n0 // 50 and min(s0) > 0     # ... half of them from each rank's shard

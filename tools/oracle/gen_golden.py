@@ -1,7 +1,7 @@
 """Generate tests/golden/*.npz by running the REFERENCE (read-only import, build container only) on the
 hash-generated synthetic weights/inputs, and report how oracle/ compares on the same inputs.
 
-    python tools/oracle/gen_golden.py [stage ...]      stages: keys vq schedule encoder dit vae pipeline pipeline16 renderer cfg k1024 vqtrain
+    python tools/oracle/gen_golden.py [stage ...]      stages: keys vq schedule encoder dit vae pipeline pipeline16 renderer cfg k1024 vqtrain rmsnorm_rotary
 
 A golden file holds only data: inputs that cannot be regenerated from a seed, and the reference's
 outputs.  Weights/images/noise are regenerated from selftoktokenizer_amd.synth by name/seed.
@@ -540,7 +540,39 @@ def stage_vqtrain():
     np.savez_compressed(os.path.join(GOLD, "vqtrain.npz"), **out)
 
 
-STAGES = dict(keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
+def stage_rmsnorm_rotary():
+    """the two optional / off-path element-wise ops of SURVEY 8a (a31, a32), from the reference's OWN classes: RMSNorm (modules.py:
+    49-95; inactive in the shipped configs, qk_norm unset) with and without the learnable scale, and apply_rotary_emb
+    (utils/rotary_embedding_torch.py:37-53; no call site in the reference) incl. the partial-rotation (start_index) and scale forms.
+    Inputs are regenerated from synth by seed; the file holds the reference's outputs only."""
+    H.install()
+    from mimogpt.models.selftok.modules import RMSNorm
+    from mimogpt.utils.rotary_embedding_torch import apply_rotary_emb
+    out = {}
+    x = synth.hash_uniform(14, (7, 24, 64), -2.0, 2.0)
+    w = synth.hash_uniform(15, (64,), 0.9, 1.1)
+    with H.fast_init():
+        rn = RMSNorm(64, elementwise_affine=True, eps=1e-6)
+    with torch.no_grad():
+        rn.weight.copy_(w)
+        out["rms_affine"] = rn(x).numpy()
+        with H.fast_init():
+            out["rms_plain"] = RMSNorm(64, elementwise_affine=False, eps=1e-6)(x).numpy()
+        x2 = synth.hash_uniform(18, (5, 3, 256), -4.0, 4.0)                      # the widest row the kernel takes (dim <= 256), eps 1e-5
+        with H.fast_init():
+            r2 = RMSNorm(256, elementwise_affine=False, eps=1e-5)
+        out["rms_256"] = r2(x2).numpy()
+        t = synth.hash_uniform(16, (2, 3, 10, 32), -2.0, 2.0)
+        f = synth.hash_uniform(17, (10, 32), -3.0, 3.0)
+        out["rot_full"] = apply_rotary_emb(f, t).numpy()
+        f16 = synth.hash_uniform(19, (10, 16), -3.0, 3.0)
+        out["rot_partial_start8"] = apply_rotary_emb(f16, t, start_index=8).numpy()   # rotates features 8..23 only
+        out["rot_scaled"] = apply_rotary_emb(f, t, scale=0.5).numpy()
+    np.savez_compressed(os.path.join(GOLD, "rmsnorm_rotary.npz"), **out)
+    report("rmsnorm_rotary", arrays=sorted(out), rms_absmax=float(np.abs(out["rms_affine"]).max()), rot_absmax=float(np.abs(out["rot_full"]).max()))
+
+
+STAGES = dict(rmsnorm_rotary=stage_rmsnorm_rotary, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
               vae=stage_vae, pipeline=stage_pipeline, pipeline16=stage_pipeline16, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024, vqtrain=stage_vqtrain)
 
 if __name__ == "__main__":
