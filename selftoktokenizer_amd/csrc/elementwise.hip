@@ -10,6 +10,7 @@
 // so the reference's [B,T,H] broadcasts (modules.py:29-37, sd3/mmdit.py:78-83) are never materialised.
 #include "common.h"
 #include "selftok_hip.h"   // the C ABI declared there must match the definitions below
+#include <stdlib.h>
 
 namespace selftok {
 
@@ -108,6 +109,141 @@ __global__ __launch_bounds__(256) void residual_ln_mod_kernel(
             *reinterpret_cast<h4*>(n_blk + split_blk_index(gid, (i * G + gl) * 4, 0, H / 32)) = hh;
             *reinterpret_cast<h4*>(n_blk + split_blk_index(gid, (i * G + gl) * 4, 1, H / 32)) = ll;
             mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+        }
+    }
+    if (n_blk && overflow && !(mx < 65504.0f)) atomicOr(overflow, 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// The same fused pass for the wide rows of the MMDiT / query streams (H = 64 * VPL * 4: one wave per row), re-shaped around what
+// bounds it -- HBM -- (measurements: profiles/r3_ln_variants.txt, r3_hbm_sweep.txt):
+//   * a wave WALKS R rows along the direction in which its modulation operands do not change: per-token tables [T, 6H] (context
+//     stream, encoder queries) -> the same token of R consecutive samples (row stride T); per-sample tables [B, 6H] (image stream)
+//     -> R consecutive tokens of one sample.  shift / scale (HM) and gate (HG), when they are constant along the walk, are read
+//     ONCE per wave and stay in registers: in the one-row-per-wave kernel above they are 18 KB of L2 / Infinity-Cache reads next to
+//     24 KB of row data (+14 ... 20 % at R = 4);
+//   * NT: non-temporal stores for x_out / n_out / the split planes.  Both outputs are consumed by a GEMM that starts after this
+//     kernel has finished; written with the default policy they evict the rows still to be read from L2 / Infinity Cache
+//     (2-read + 2-write stream of 4 x 141 MB: 5.4 TB/s with plain stores, 7.8 TB/s non-temporal, tools/microbench/hbm_sweep.hip).
+// A register-prefetched variant (two row sets per wave, the next row's loads issued before the reduction) was measured and dropped:
+// 256 + 86 registers at H = 1536 leave one wave per SIMD and it is 10 - 25 % slower than letting 2 - 4 waves per SIMD overlap.
+// Arithmetic and its order are exactly those of residual_ln_mod_kernel: results are bit-identical.
+// ---------------------------------------------------------------------------------------
+template <bool NT, typename V>
+__device__ __forceinline__ void stx(V* p, V v)
+{
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <int VPL, bool NT, bool HM, bool HG>
+__global__ __launch_bounds__(256) void residual_ln_mod_walk_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gate,
+    const float* __restrict__ shift, const float* __restrict__ scale,
+    float* __restrict__ x_out, float* __restrict__ n_out,
+    int B, int T, long mod_stride_b, long mod_stride_t, long gate_stride_b, long gate_stride_t, float eps,
+    _Float16* __restrict__ n_blk, int* __restrict__ overflow,
+    int walk_tokens /* 0: R samples of one token (row stride T), 1: R tokens of one sample (row stride 1) */, int R)
+{
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    constexpr int H = 64 * VPL * 4;
+    const int lane = threadIdx.x & 63;
+    const long wave_g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int b0, t0, cnt;
+    long step;
+    if (!walk_tokens) {
+        const long c = wave_g / T;
+        t0 = (int)(wave_g - c * T);
+        b0 = (int)c * R;
+        if (b0 >= B) return;
+        cnt = B - b0 < R ? B - b0 : R;
+        step = T;
+    } else {
+        const int nch = (T + R - 1) / R;
+        b0 = (int)(wave_g / nch);
+        if (b0 >= B) return;
+        t0 = (int)(wave_g - (long)b0 * nch) * R;
+        cnt = T - t0 < R ? T - t0 : R;
+        step = 1;
+    }
+    const long row0 = (long)b0 * T + t0;
+    float4 hs[HM ? VPL : 1], hc[HM ? VPL : 1], hg[HG ? VPL : 1];
+    if (HM) {
+        const float* sh = shift + b0 * mod_stride_b + t0 * mod_stride_t;
+        const float* sc = scale + b0 * mod_stride_b + t0 * mod_stride_t;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { hs[i] = ld4(sh + (i * 64 + lane) * 4); hc[i] = ld4(sc + (i * 64 + lane) * 4); }
+    }
+    if (HG) {
+        const float* gr = gate + b0 * gate_stride_b + t0 * gate_stride_t;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) hg[i] = ld4(gr + (i * 64 + lane) * 4);
+    }
+    float mx = 0.f;
+#pragma unroll 1
+    for (int j = 0; j < cnt; ++j) {
+        const long row = row0 + j * step;
+        const int b = walk_tokens ? b0 : b0 + j, t = walk_tokens ? t0 + j : t0;
+        float4 v[VPL];
+        const float* xr = x + (size_t)row * H;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) v[i] = ld4(xr + (i * 64 + lane) * 4);
+        if (y) {
+            const float* yr = y + (size_t)row * H;
+            const float* gr = (gate && !HG) ? gate + b * gate_stride_b + t * gate_stride_t : nullptr;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const float4 yy = ld4(yr + (i * 64 + lane) * 4);
+                if (HG || gr) {
+                    const float4 g = HG ? hg[i] : ld4(gr + (i * 64 + lane) * 4);
+                    v[i].x = v[i].x + g.x * yy.x; v[i].y = v[i].y + g.y * yy.y;
+                    v[i].z = v[i].z + g.z * yy.z; v[i].w = v[i].w + g.w * yy.w;
+                } else {
+                    v[i].x += yy.x; v[i].y += yy.y; v[i].z += yy.z; v[i].w += yy.w;
+                }
+            }
+            if (x_out) {
+                float* xo = x_out + (size_t)row * H;
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) stx<NT>(reinterpret_cast<f4v*>(xo + (i * 64 + lane) * 4), f4v{v[i].x, v[i].y, v[i].z, v[i].w});
+            }
+        }
+        if (!n_out && !n_blk) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = group_sum<64>(s) * (1.0f / H);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            float a = v[i].x - mean, bq = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + bq * bq) + (c * c + d * d);
+        }
+        const float var = group_sum<64>(q) * (1.0f / H);
+        const float rstd = 1.0f / __builtin_sqrtf(var + eps);
+        float* nr = n_out ? n_out + (size_t)row * H : nullptr;
+        const float* sh = (scale && !HM) ? shift + b * mod_stride_b + t * mod_stride_t : nullptr;
+        const float* sc = (scale && !HM) ? scale + b * mod_stride_b + t * mod_stride_t : nullptr;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            float4 o;
+            o.x = (v[i].x - mean) * rstd; o.y = (v[i].y - mean) * rstd;
+            o.z = (v[i].z - mean) * rstd; o.w = (v[i].w - mean) * rstd;
+            if (HM || sc) {
+                const float4 c4 = HM ? hc[i] : ld4(sc + (i * 64 + lane) * 4), s4 = HM ? hs[i] : ld4(sh + (i * 64 + lane) * 4);
+                o.x = o.x * (1.0f + c4.x) + s4.x; o.y = o.y * (1.0f + c4.y) + s4.y;
+                o.z = o.z * (1.0f + c4.z) + s4.z; o.w = o.w * (1.0f + c4.w) + s4.w;
+            }
+            if (nr) stx<NT>(reinterpret_cast<f4v*>(nr + (i * 64 + lane) * 4), f4v{o.x, o.y, o.z, o.w});
+            if (n_blk) {
+                const f4v ov = {opaque_f32(o.x), opaque_f32(o.y), opaque_f32(o.z), opaque_f32(o.w)};   // see common.h
+                const h4 hh = __builtin_convertvector(ov, h4);
+                const h4 ll = __builtin_convertvector((ov - __builtin_convertvector(hh, f4v)) * 2048.0f, h4);
+                stx<NT>(reinterpret_cast<h4*>(n_blk + split_blk_index(row, (i * 64 + lane) * 4, 0, H / 32)), hh);
+                stx<NT>(reinterpret_cast<h4*>(n_blk + split_blk_index(row, (i * 64 + lane) * 4, 1, H / 32)), ll);
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+            }
         }
     }
     if (n_blk && overflow && !(mx < 65504.0f)) atomicOr(overflow, 1);
@@ -291,6 +427,45 @@ static int residual_ln_mod_launch(const float* x, const float* y, const float* g
     }
     const int rows = B * T;
     if (rows == 0) return SELFTOK_OK;
+    // wide rows: walk kernel (see its comment).  Direction: along the samples when the modulation is per token (or absent), along
+    // the tokens when it is per sample; R rows per wave, fewer when that would leave the chip with < ~6 waves per CU
+    int vpl = 0;
+    switch (H) { case 256: vpl = 1; break; case 512: vpl = 2; break; case 1024: vpl = 4; break; case 1536: vpl = 6; break; default: break; }
+    int variant = 1, R = 8, nt = 1;      // measured: profiles/r3_ln_variants.txt
+#ifdef SELFTOK_TUNE
+    { const char* e = getenv("SELFTOK_LN_VARIANT"); if (e) variant = atoi(e);      // 0: one row per wave (round-1 kernel), 1: walk
+      e = getenv("SELFTOK_LN_R"); if (e) R = atoi(e);
+      e = getenv("SELFTOK_LN_NT"); if (e) nt = atoi(e); }
+#endif
+    if (vpl && variant >= 1) {
+        const bool per_sample_mod = shift ? (mod_stride_t == 0 && mod_stride_b != 0) : (gate && gate_stride_t == 0 && gate_stride_b != 0);
+        const int walk_tokens = per_sample_mod ? 1 : 0;
+        const int extent = walk_tokens ? T : B;
+        if (R > extent) R = extent;
+        while (R > 1 && (long)((extent + R - 1) / R) * (walk_tokens ? B : T) < 6 * 256) R = (R + 1) / 2;
+        const long waves = walk_tokens ? (long)B * ((T + R - 1) / R) : (long)((B + R - 1) / R) * T;
+        const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+        // operands that do not change along the walk are hoisted into registers (template flags: no dead register sets)
+        bool hm = scale && (walk_tokens ? mod_stride_t == 0 : mod_stride_b == 0);
+        bool hg = y && gate && (walk_tokens ? gate_stride_t == 0 : gate_stride_b == 0);
+#ifdef SELFTOK_TUNE
+        { const char* e = getenv("SELFTOK_LN_HOIST"); if (e) { const int m = atoi(e); hm = hm && (m & 1); hg = hg && (m & 2); } }
+#endif
+#define WALK(V, N, M, G)                                                                                                     \
+        hipLaunchKernelGGL((residual_ln_mod_walk_kernel<V, N, M, G>), grid, block, 0, stream, x, y, gate, shift, scale, x_out, n_out, B, T, \
+                           mod_stride_b, mod_stride_t, gate_stride_b, gate_stride_t, eps, n_blk, overflow, walk_tokens, R)
+#define WALK_H(V, N) do { if (hm) { if (hg) WALK(V, N, true, true); else WALK(V, N, true, false); } else { if (hg) WALK(V, N, false, true); else WALK(V, N, false, false); } } while (0)
+#ifdef SELFTOK_TUNE
+#define WALK_NT(V) do { if (nt) WALK_H(V, true); else WALK_H(V, false); } while (0)
+#else
+#define WALK_NT(V) do { (void)nt; WALK_H(V, true); } while (0)
+#endif
+        switch (vpl) { case 1: WALK_NT(1); break; case 2: WALK_NT(2); break; case 4: WALK_NT(4); break; default: WALK_NT(6); break; }
+#undef WALK_NT
+#undef WALK_H
+#undef WALK
+        return check_launch("residual_ln_mod_walk_kernel");
+    }
 #define LAUNCH(G, VPL)                                                                                                  \
     hipLaunchKernelGGL((residual_ln_mod_kernel<G, VPL>), dim3((rows + (256 / G) - 1) / (256 / G)), dim3(256), 0, stream, \
                        x, y, gate, shift, scale, x_out, n_out, rows, T, mod_stride_b, mod_stride_t, gate_stride_b,      \
