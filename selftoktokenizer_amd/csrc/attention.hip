@@ -23,6 +23,7 @@
 #include "common.h"
 #include "selftok_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace selftok {
 
@@ -179,6 +180,9 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
         }
         // sc[r] = S[q = col][key = key0 + (r&3) + 8*(r>>2) + 4*half]
         if (key0 + KT > nkeys) {                             // ragged last tile: mask the padding keys
+            // the empty volatile asm keeps this block a real (wave-uniform) branch: hipcc otherwise if-converts it into 16 x
+            // (v_subrev, v_cmp, v_cndmask) executed on EVERY tile -- 48 VALU ops beside the fp32 MFMAs for one tile per segment
+            asm volatile("; ragged tile");
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= nkeys) sc[r] = -__builtin_inff();
@@ -224,6 +228,195 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
     }
 
     // ---- epilogue: O[q][d] = O^T / l ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, WAVE);
+    const float inv = 1.0f / l_tot;
+    if (row_ok) {
+        float* op = qs.o + (size_t)b * qs.o_bs + (size_t)my_row * qs.o_rs + h * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = 8 * g + 4 * half;
+            *reinterpret_cast<float4*>(op + d0) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *reinterpret_cast<float4*>(op + 32 + d0) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// attn64_dma_kernel: attn64_kernel with the K / V tiles staged by LDS-DMA (round 3).
+// The arithmetic is untouched -- the same chained v_mfma_f32_32x32x2_f32, the same online softmax, bit-identical outputs -- only
+// the way a 32-key tile reaches LDS changes: `global_load_lds_dwordx4` (uniform SGPR base + one constant per-lane offset register,
+// 16 B per lane, 1 KiB = 4 keys per instruction) instead of global_load -> VGPR -> ds_write_b128.  That removes 16 staging VGPRs,
+// the 64-bit address arithmetic, the zero-fill selects and 4 ds_write_b128 per wave and tile from the VALU / LDS issue stream that
+// shares the SIMD with the fp32 MFMAs, and brings the kernel from 140 to <= 128 VGPRs (3 -> 4 waves per SIMD).
+// A DMA writes lane-contiguously, so the K rows cannot be padded (the [key][68] stride of attn64_kernel): the 16-byte chunks of
+// a K row are XOR-swizzled instead -- chunk c of key k sits at position c ^ (k & 15) of its 256-byte row -- applied on the SOURCE
+// side (lane (row, position) fetches chunk position ^ (row & 15)); the fragment reads `ds_read_b128` of a lane group then hit 16
+// different positions = all 64 banks once.  V rows stay natural ([key][64], b32 reads of consecutive lanes).
+// Ragged last tile of a segment: rows past the end are fetched from the segment's LAST key (clamped per-lane offsets, never past
+// the tensor): their scores are masked to -inf, their probabilities are exactly 0, and 0 x (a finite V row) adds nothing.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void attn_lds_dma16(const void* base, unsigned voff, unsigned lds)
+{
+    // M0 = LDS byte address of the 1-KiB piece (hipcc never keeps a value in M0 across statements)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory");
+}
+
+__global__ __launch_bounds__(256) void attn64_dma_kernel(AttnParams P)
+{
+    __shared__ __attribute__((aligned(1024))) float s_kb[2][KT * 64];     // swizzled rows, see above
+    __shared__ __attribute__((aligned(1024))) float s_vb[2][KT * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    int qt, h, b;
+    {
+        const int T = gridDim.x, orig = blockIdx.x;
+        const int q8 = T >> 3, r8 = T & 7, xcd = orig & 7, idx = orig >> 3;
+        const int w = P.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx : orig;
+        qt = w % P.qtiles;
+        h = (w / P.qtiles) % P.H;
+        b = w / (P.qtiles * P.H);
+    }
+    int n0 = P.seg[0].len;
+    if (P.kvis) { int kv = P.kvis[b] + 1; n0 = kv < n0 ? (kv < 0 ? 0 : kv) : n0; }
+    const int rows0 = P.seg[0].q ? n0 : 0;
+    int s, r0;
+    {
+        const int t0 = P.seg[0].q ? (P.seg[0].len + QROWS - 1) / QROWS : 0;
+        if (qt < t0) { s = 0; r0 = qt * QROWS; }
+        else { s = 1; r0 = (qt - t0) * QROWS; }
+    }
+    const int rows_live = (s == 0) ? rows0 : (P.seg[1].q ? P.seg[1].len : 0);
+    if (r0 >= rows_live) return;
+    const AttnSeg& qs = P.seg[s];
+    const int n1 = (s == 1 || P.seg0_sees_seg1) ? P.seg[1].len : 0;
+
+    const int my_row = r0 + wave * 32 + col;
+    const bool row_ok = my_row < rows_live;
+    float qf[32];
+    {
+        const float* qp = qs.q + (size_t)b * qs.q_bs + (size_t)(row_ok ? my_row : (rows_live - 1)) * qs.q_rs + h * 64 + 32 * half;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float4 t = *reinterpret_cast<const float4*>(qp + 4 * j);
+            qf[4 * j] = t.x; qf[4 * j + 1] = t.y; qf[4 * j + 2] = t.z; qf[4 * j + 3] = t.w;
+        }
+    }
+    f32x16 o0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 o1 = o0;
+    const float c = P.scale * 1.4426950408889634f;
+    float m_run = -__builtin_inff(), l_run = 0.f;
+
+    // ---- staging: wave w issues K pieces w, w + 4 and V pieces w, w + 4 of a tile (piece i = keys 4 i .. 4 i + 3 = 1 KiB) ----
+    const int kr = lane >> 4, pos = lane & 15;                 // row inside a piece, 16-byte position inside the row
+    const int ksw = pos ^ ((4 * wave + kr) & 15);              // source chunk of that position (pieces w and w + 4: same rows mod 16)
+    const unsigned lds_k = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&s_kb[0][0];
+    const unsigned lds_v = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&s_vb[0][0];
+    auto stage = [&](int seg, int key0, int nkeys, int buf) {
+        const AttnSeg& ks = P.seg[seg];
+        const char* kb = reinterpret_cast<const char*>(ks.k + (size_t)b * ks.k_bs + (size_t)key0 * ks.k_rs + h * 64);
+        const char* vb = reinterpret_cast<const char*>(ks.v + (size_t)b * ks.v_bs + (size_t)key0 * ks.v_rs + h * 64);
+        const unsigned krs = (unsigned)ks.k_rs * 4u, vrs = (unsigned)ks.v_rs * 4u;
+        if (key0 + KT <= nkeys) {                              // full tile: uniform bases, constant per-lane offsets
+            const unsigned ko = kr * krs + ksw * 16, vo = kr * vrs + pos * 16;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = wave + 4 * u;
+                attn_lds_dma16(kb + (size_t)(4 * i) * krs, ko, lds_k + buf * (KT * 256) + i * 1024);
+                attn_lds_dma16(vb + (size_t)(4 * i) * vrs, vo, lds_v + buf * (KT * 256) + i * 1024);
+            }
+        } else {                                               // ragged last tile of the segment: clamp the source row per lane
+            const int last = nkeys - 1 - key0;                 // >= 0
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = wave + 4 * u;
+                const int row = 4 * i + kr, src = row < last ? row : last;
+                attn_lds_dma16(kb, (unsigned)src * krs + ksw * 16, lds_k + buf * (KT * 256) + i * 1024);
+                attn_lds_dma16(vb, (unsigned)src * vrs + pos * 16, lds_v + buf * (KT * 256) + i * 1024);
+            }
+        }
+    };
+    // fragment-read addresses of the K tile (floats): row col, chunk (8 half + j) at position chunk ^ (col & 15)
+    int kaddr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kaddr[j] = col * 64 + (((8 * half + j) ^ (col & 15)) << 2);
+
+    const int nt0 = (n0 + KT - 1) / KT, nt1 = (n1 + KT - 1) / KT;
+    const int ntiles = nt0 + nt1;
+    if (ntiles == 0) return;
+    stage(nt0 > 0 ? 0 : 1, 0, nt0 > 0 ? n0 : n1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // one 32-key tile; BUF (the LDS buffer it sits in) is a compile-time constant so that every fragment read is
+    // (tile-invariant address register) + (immediate offset): with a run-time buffer index hipcc spends a v_or + v_add per read
+    auto tile = [&](int t, auto BUF) {
+        constexpr int buf = decltype(BUF)::value;
+        const int seg = t < nt0 ? 0 : 1;
+        const int key0 = (seg == 0 ? t : t - nt0) * KT;
+        const int nkeys = seg == 0 ? n0 : n1;
+        const float* s_k = s_kb[buf];
+        const float* s_v = s_vb[buf];
+        if (t + 1 < ntiles) {                                // the next tile's DMAs fly behind this tile's MFMAs
+            const int seg_n = (t + 1) < nt0 ? 0 : 1;
+            stage(seg_n, (seg_n == 0 ? t + 1 : t + 1 - nt0) * KT, seg_n == 0 ? n0 : n1, buf ^ 1);
+        }
+
+        f32x16 sc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float4 kf = *reinterpret_cast<const float4*>(&s_k[kaddr[j]]);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[4 * j + 0], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[4 * j + 1], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[4 * j + 2], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[4 * j + 3], sc, 0, 0, 0);
+        }
+        if (key0 + KT > nkeys) {
+            asm volatile("; ragged tile");                   // a real branch, not 48 if-converted VALU ops per tile (see attn64_kernel)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= nkeys) sc[r] = -__builtin_inff();
+        }
+        float mx;
+        {
+            float m0 = fmaxf(fmaxf(sc[0], sc[1]), sc[2]), m1 = fmaxf(fmaxf(sc[3], sc[4]), sc[5]);
+            float m2 = fmaxf(fmaxf(sc[6], sc[7]), sc[8]), m3 = fmaxf(fmaxf(sc[9], sc[10]), sc[11]);
+            float m4 = fmaxf(fmaxf(sc[12], sc[13]), sc[14]);
+            mx = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), sc[15]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+        const float m_new = fmaxf(m_run, mx * c);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c, -m_new));
+            sc[r] = p;
+            psum += p;
+        }
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            m_run = m_new;
+        }
+        l_run += psum;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int key = (m & 3) + 8 * (m >> 2) + 4 * half;
+            float v0 = s_v[key * 64 + col];
+            float v1 = s_v[key * 64 + 32 + col];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sc[m], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sc[m], o1, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my pieces of tile t + 1 have landed
+        __syncthreads();                                     // everyone's have, and tile t's buffer is free
+    };
+    for (int t = 0; t < ntiles; t += 2) {
+        tile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
+    }
+
     const float l_tot = l_run + __shfl_xor(l_run, 32, WAVE);
     const float inv = 1.0f / l_tot;
     if (row_ok) {
@@ -429,6 +622,7 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
         }
         // sc[r] = log2(e) * scale * S[q = col][key = key0 + (r&3) + 8*(r>>2) + 4*half]
         if (key0 + KT > nkeys) {
+            asm volatile("; ragged tile");                   // a real branch, not 48 if-converted VALU ops per tile (see attn64_kernel)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= nkeys) sc[r] = -__builtin_inff();
@@ -593,6 +787,17 @@ int selftok_attn_f32(const selftok_attn_desc* d, hipStream_t stream)
             return check_launch("attn64_f16x2_kernel");
         }
         if (d->mode != 0) { set_last_error("attn: unknown mode"); return SELFTOK_EINVAL; }
+        // the LDS-DMA staged kernel needs 16-byte aligned K / V rows (strides are multiples of 4 floats by the check above)
+        bool dma = true;
+        for (int s = 0; s < 2; ++s)
+            if (P.seg[s].len > 0 && ((((size_t)P.seg[s].k | (size_t)P.seg[s].v) & 15) != 0 || P.seg[s].k_rs >= (1l << 24) || P.seg[s].v_rs >= (1l << 24))) dma = false;   // 32-bit per-lane byte offsets
+#ifdef SELFTOK_TUNE
+        { const char* e = getenv("SELFTOK_ATTN_VARIANT"); if (e && atoi(e) == 0) dma = false; }      // 0: register-staged kernel of rounds 1-2
+#endif
+        if (dma) {
+            hipLaunchKernelGGL(attn64_dma_kernel, dim3((t0 + t1) * d->H * d->B), dim3(256), 0, stream, P);
+            return check_launch("attn64_dma_kernel");
+        }
         hipLaunchKernelGGL(attn64_kernel, dim3((t0 + t1) * d->H * d->B), dim3(256), 0, stream, P);
         return check_launch("attn64_kernel");
     }

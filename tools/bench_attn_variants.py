@@ -1,0 +1,51 @@
+"""GPU: fp32 attention variants in the tune build (SELFTOK_ATTN_VARIANT 0 = register-staged attn64_kernel of rounds 1-2, 1 = LDS-DMA staged
+attn64_dma_kernel) at the decode step's shapes; outputs must be bit-identical."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["SELFTOK_HIP_LIB"] = os.path.join(ROOT, "tools", "microbench", "libselftok_tune.so")
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from selftoktokenizer_amd import ops  # noqa: E402
+
+B, H = 64, 24
+D = H * 64
+
+
+def ev(fn, n=10):
+    for _ in range(3):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+for n in (512, 358, 77, 20):
+    ctx = torch.randn(B, n, 3 * D, device="cuda")
+    xs = torch.randn(B, 256, 3 * D, device="cuda")
+    S = n + 256
+    fl = 4.0 * B * H * S * S * 64
+    outs, times = {}, {"0": [], "1": []}
+    for rnd in range(5):                       # alternate the variants: the box's clock drifts by several % within a process
+        for var in ("0", "1"):
+            os.environ["SELFTOK_ATTN_VARIANT"] = var
+            oc = torch.zeros(B, n, D, device="cuda")
+            ox = torch.zeros(B, 256, D, device="cuda")
+            f = lambda: ops.attention((ctx[..., :D], ctx[..., D:2 * D], ctx[..., 2 * D:], oc), (xs[..., :D], xs[..., D:2 * D], xs[..., 2 * D:], ox), H, 64)
+            times[var].append(ev(f, n=40))
+            if var in outs:
+                assert torch.equal(outs[var][0], oc) and torch.equal(outs[var][1], ox)
+            outs[var] = (oc, ox)
+    same = torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+    for var, name in (("0", "register-staged (rounds 1-2)"), ("1", "LDS-DMA staged")):
+        t = sorted(times[var])
+        print(json.dumps({"variant": name, "n_ctx": n, "ms_median": round(t[2], 4), "ms_all": [round(v, 4) for v in times[var]],
+                          "TFLOPs_median": round(fl / t[2] / 1e9, 1), "frac_fp32_mfma_peak": round(fl / t[2] / 1e9 / 157.3, 4)}), flush=True)
+    print(f"n_ctx={n}: outputs bit-identical between the variants: {same}; dma / register-staged time (medians) = {sorted(times['1'])[2] / sorted(times['0'])[2]:.4f}", flush=True)
+    assert same
