@@ -59,4 +59,20 @@ __device__ __forceinline__ float opaque_f32(float v)
     return v;
 }
 
+// tools/ builds only (-DSELFTOK_TUNE): shader-clock (s_memtime) and 100 MHz wall-clock (s_memrealtime) stamps of the first workgroup
+// of a kernel -> effective shader clock while that kernel runs (the chip clocks to its power budget).  The product build has none.
+#ifdef SELFTOK_TUNE
+#define SELFTOK_STAMP_DECL(sym) __device__ unsigned long long sym[2]
+#define SELFTOK_STAMP_BEGIN()                                                                                    \
+    unsigned long long stamp_tk0_ = 0, stamp_rt0_ = 0;                                                          \
+    const bool stamp_on_ = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;                              \
+    if (stamp_on_) { stamp_tk0_ = __builtin_readcyclecounter(); stamp_rt0_ = __builtin_amdgcn_s_memrealtime(); }
+#define SELFTOK_STAMP_END(sym)                                                                                   \
+    if (stamp_on_) { sym[0] = __builtin_readcyclecounter() - stamp_tk0_; sym[1] = __builtin_amdgcn_s_memrealtime() - stamp_rt0_; }
+#else
+#define SELFTOK_STAMP_DECL(sym)
+#define SELFTOK_STAMP_BEGIN()
+#define SELFTOK_STAMP_END(sym)
+#endif
+
 }  // namespace selftok

@@ -522,12 +522,15 @@ typedef float vf2 __attribute__((ext_vector_type(2)));
 
 constexpr uint32_t F16_FLAG = 0x80000000u;       // entry.lo bit 31: re-scan the whole stream exactly
 
+SELFTOK_STAMP_DECL(tune_stamp_vq_f16);
+
 template <int RT>
 __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z, const float* __restrict__ packed,
                                                      unsigned long long* __restrict__ partial, int N, int C,
                                                      int tiles_per_split, int normalize)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[2][M_CH * 2048];     // 8 tiles x (2 planes x 64 lanes x 16 B), double buffered
+    SELFTOK_STAMP_BEGIN();
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
@@ -603,34 +606,56 @@ __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z
             const int buf = c & 1;
             if (c + 1 < nchunks) stage(c + 1, buf ^ 1);
             const int base = c * M_CH;
+            // three chained f16 MFMAs per (tile, row block): the four row blocks' chains are written interleaved so that no MFMA
+            // waits for the one before it
+            auto mfma_tile = [&](int j, f32x16 (&acc)[RT]) {
+                const vh8 e0 = *reinterpret_cast<const vh8*>(&s_tile[buf][j * 2048 + lane * 16]);
+                const vh8 e1 = *reinterpret_cast<const vh8*>(&s_tile[buf][j * 2048 + 1024 + lane * 16]);
 #pragma unroll
-            for (int j = 0; j < M_CH; ++j) {
-                if (base + j < nt) {                                   // wave-uniform
-                    const vh8 e0 = *reinterpret_cast<const vh8*>(&s_tile[buf][j * 2048 + lane * 16]);
-                    const vh8 e1 = *reinterpret_cast<const vh8*>(&s_tile[buf][j * 2048 + 1024 + lane * 16]);
-                    const int tile = tile_first + base + j;
+                for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, __builtin_bit_cast(vh8, x0[t]), zero, 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < RT; ++t) {
-                        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, __builtin_bit_cast(vh8, x0[t]), zero, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, __builtin_bit_cast(vh8, x1[t]), acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, __builtin_bit_cast(vh8, x0[t]), acc, 0, 0, 0);
-                        // tile maximum (8 x v_max3), then (m1, m2) <- the two largest of (m1, m2, mt): v_max + v_med3
-                        const float a0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]), a1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
-                        const float a2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]), a3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
-                        const float a4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
-                        const float mt = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), __builtin_fmaxf(__builtin_fmaxf(a3, a4), acc[15]));
-                        m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], mt);
-                        const bool g = mt > m1[t];                      // strict: the earliest tile holding the maximum is t1
-                        m1[t] = __builtin_fmaxf(m1[t], mt);
-                        t1[t] = g ? tile : t1[t];
-                    }
+                for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, __builtin_bit_cast(vh8, x1[t]), acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, __builtin_bit_cast(vh8, x0[t]), acc[t], 0, 0, 0);
+            };
+            // tile maximum (8 x v_max3), then (m1, m2) <- the two largest of (m1, m2, mt): v_max + v_med3
+            auto scan_tile = [&](int j, const f32x16 (&accs)[RT]) {
+                const int tile = tile_first + base + j;
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const f32x16& acc = accs[t];
+                    const float a0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]), a1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
+                    const float a2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]), a3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
+                    const float a4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
+                    const float mt = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), __builtin_fmaxf(__builtin_fmaxf(a3, a4), acc[15]));
+                    m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], mt);
+                    const bool g = mt > m1[t];                      // strict: the earliest tile holding the maximum is t1
+                    m1[t] = __builtin_fmaxf(m1[t], mt);
+                    t1[t] = g ? tile : t1[t];
                 }
+            };
+            f32x16 accA[RT], accB[RT];
+            if (base + M_CH <= nt) {
+                // full chunk, one straight-line block: two accumulator sets ping-pong, the scan of tile j (VALU) is independent of the
+                // MFMAs of tile j + 1 and the scheduler interleaves them -- a scan costs ~15 VALU ops per row block, the 3 MFMAs of a
+                // row block leave ~15 issue slots free.  (Per-tile branches / one accumulator set serialise MFMA -> wait -> scan.)
+                mfma_tile(0, accA);
+#pragma unroll
+                for (int j = 0; j < M_CH; j += 2) {
+                    mfma_tile(j + 1, accB);
+                    scan_tile(j, accA);
+                    if (j + 2 < M_CH) mfma_tile(j + 2, accA);
+                    scan_tile(j + 1, accB);
+                }
+            } else {
+                for (int j = 0; j < M_CH && base + j < nt; ++j) { mfma_tile(j, accA); scan_tile(j, accA); }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     }
 
+    SELFTOK_STAMP_END(tune_stamp_vq_f16);
     const float win = 2.0f * F16_EPS * F16_SCORE_SCALE;
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
@@ -1074,6 +1099,14 @@ int selftok_vq_encode_packed_f32(const float* z, const float* packed, void* ids,
     if (rc || N == 0) return rc;
     return selftok_vq_finalize_packed(workspace, z, packed, ids, best, N, C, Dm, split, flags, stream);
 }
+
+#ifdef SELFTOK_TUNE
+// tools/ builds only: (shader cycles, 100 MHz ticks) of workgroup (0, 0) of the last vq_f16_kernel launch
+int selftok_tune_vq_stamp(unsigned long long* out2)
+{
+    return hipMemcpyFromSymbol(out2, HIP_SYMBOL(tune_stamp_vq_f16), 2 * sizeof(unsigned long long)) == hipSuccess ? SELFTOK_OK : SELFTOK_EHIP;
+}
+#endif
 
 // flags bit0: ids are int32 (default int64).  ln_w/ln_b may be NULL (plain gather).
 int selftok_code_gather_ln_f32(const void* ids, const float* codebook, const float* ln_w, const float* ln_b, float* out,
