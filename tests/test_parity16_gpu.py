@@ -71,13 +71,16 @@ def test_ids_16_images_vs_reference(pipe):
     if nflip:
         de = (cb[torch.from_numpy(ref[mism])] - cb[torch.from_numpy(ids[mism])]).norm(dim=-1).numpy()
         assert (gaps <= dz[mism] * de + 2e-6).all(), (gaps, dz[mism] * de)
-    # (2) ... and that perturbation is small: flips sit only at near-ties of the reference.  Bound = 2 x the largest measured |dz|
-    #     of this run, itself capped by what bf16 VAE noise can produce (CPU oracle vs reference: |dz| max 1e-3 scale)
+    # (2) ... and that perturbation is small: flips sit only at near-ties of the reference.  Bound = 2 x the largest measured |dz| of
+    #     this run, which itself must stay at the level bf16 VAE noise produces (measured: median 5e-4, max 1.7e-3 with the bias
+    #     folded into the convolutions; 5e-3 with the separate bf16 bias add of rounds 1-2 -- profiles/r3_vae_modes_*.txt)
     bound = 2.0 * float(dz.max())
     assert bound < 5e-3, bound
     assert nflip == 0 or float(gaps.max()) < bound
-    # (3) the count stays within a small multiple of the CPU-vs-CPU spread on the same images
-    assert 1 - mism.mean() >= 0.995, nflip
+    assert nflip == 0 or float(gaps.max()) < 1e-3          # measured: largest flip gap 2.6e-4
+    # (3) the count stays within a small multiple of the CPU-vs-CPU spread on the same images (oracle: 7 flips; measured here: 11;
+    #     rounds 1-2: 40)
+    assert nflip <= 24, nflip
     # most flips land on the reference's runner-up code
     if nflip:
         print("flips that went to the reference's runner-up:", int((ids[mism] == g["id2"].astype(np.int64)[mism]).sum()), "of", nflip)
@@ -108,8 +111,9 @@ def test_psnr_16_images_vs_reference(pipe, gemm):
     print(f"   end to end (our latents, our MIOpen bf16 decoder)   : mean {d_e2e.mean():.2e} max {d_e2e.max():.2e} dB   each {np.round(d_e2e, 5)}")
     print(f"   same decoder (reference latents vs ours, one call)  : mean {d_same.mean():.2e} max {d_same.max():.2e} dB")
     print(f"   CPU oracle's bf16 decoder on the reference's latents: mean {d_or.mean():.2e} max {d_or.max():.2e} dB   each {np.round(d_or, 5)}")
-    assert lat_err < 2e-4
+    assert lat_err < 2e-5                                        # measured 2.9e-6 in both arithmetics
     assert d_same.max() < 1e-3                                   # the north star's criterion where only OUR path differs
-    # end to end the delta is the bf16 decoder's implementation noise: it must stay inside (a small multiple of) the spread between
-    # two CPU implementations of the same decoder on the same latents
-    assert d_e2e.max() < max(3.0 * d_or.max(), 3e-3), (d_e2e.max(), d_or.max())
+    # end to end the delta is the bf16 decoder's implementation noise: it stays inside the spread between two CPU implementations of
+    # the same decoder on the same latents (oracle vs reference: mean 3.9e-4, max 1.09e-3 dB; measured here: mean 2.9e-4, max 8.8e-4;
+    # rounds 1-2, separate bias add + solver search: mean 6.1e-3)
+    assert d_e2e.mean() <= 1.5 * d_or.mean() and d_e2e.max() <= 1.5 * d_or.max(), (d_e2e.mean(), d_e2e.max(), d_or.mean(), d_or.max())
