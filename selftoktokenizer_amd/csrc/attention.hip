@@ -48,6 +48,7 @@ struct AttnParams {
     float scale;
     int qtiles;             // 128-row query tiles per (sample, head), both segments
     int xcd_remap;
+    int prio;               // attn64_dma_kernel: raise the wave's issue priority inside its MFMA clusters (s_setprio)
 };
 
 constexpr int KT = 32;           // keys per tile
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(256) void attn64_dma_kernel(AttnParams P)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col = lane & 31;
+    const bool prio = P.prio != 0;
     int qt, h, b;
     {
         const int T = gridDim.x, orig = blockIdx.x;
@@ -363,6 +365,7 @@ __global__ __launch_bounds__(256) void attn64_dma_kernel(AttnParams P)
         }
 
         f32x16 sc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (prio) __builtin_amdgcn_s_setprio(1);             // MFMA cluster: ahead of the co-resident waves' softmax VALU work
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float4 kf = *reinterpret_cast<const float4*>(&s_k[kaddr[j]]);
@@ -371,6 +374,7 @@ __global__ __launch_bounds__(256) void attn64_dma_kernel(AttnParams P)
             sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[4 * j + 2], sc, 0, 0, 0);
             sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[4 * j + 3], sc, 0, 0, 0);
         }
+        if (prio) __builtin_amdgcn_s_setprio(0);
         if (key0 + KT > nkeys) {
             asm volatile("; ragged tile");                   // a real branch, not 48 if-converted VALU ops per tile (see attn64_kernel)
 #pragma unroll
@@ -401,6 +405,7 @@ __global__ __launch_bounds__(256) void attn64_dma_kernel(AttnParams P)
             m_run = m_new;
         }
         l_run += psum;
+        if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             const int key = (m & 3) + 8 * (m >> 2) + 4 * half;
@@ -409,6 +414,7 @@ __global__ __launch_bounds__(256) void attn64_dma_kernel(AttnParams P)
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sc[m], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sc[m], o1, 0, 0, 0);
         }
+        if (prio) __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my pieces of tile t + 1 have landed
         __syncthreads();                                     // everyone's have, and tile t's buffer is free
     };
@@ -782,6 +788,10 @@ int selftok_attn_f32(const selftok_attn_desc* d, hipStream_t stream)
         if (t0 + t1 == 0) return SELFTOK_OK;
         P.qtiles = t0 + t1;
         P.xcd_remap = 1;
+        P.prio = 0;
+#ifdef SELFTOK_TUNE
+        { const char* e = getenv("SELFTOK_ATTN_PRIO"); if (e) P.prio = atoi(e); }
+#endif
         if (d->mode == SELFTOK_ATTN_F16X2) {
             hipLaunchKernelGGL(attn64_f16x2_kernel, dim3((t0 + t1) * d->H * d->B), dim3(256), 0, stream, P, d->overflow);
             return check_launch("attn64_f16x2_kernel");

@@ -62,13 +62,22 @@ __device__ __forceinline__ float opaque_f32(float v)
 // tools/ builds only (-DSELFTOK_TUNE): shader-clock (s_memtime) and 100 MHz wall-clock (s_memrealtime) stamps of the first workgroup
 // of a kernel -> effective shader clock while that kernel runs (the chip clocks to its power budget).  The product build has none.
 #ifdef SELFTOK_TUNE
-#define SELFTOK_STAMP_DECL(sym) __device__ unsigned long long sym[2]
+// sym[0..1]: workgroup (0,0)'s shader cycles and 100 MHz ticks; sym[2 + 3 w ..]: (start tick, end tick, XCC id << 8 | CU-ish hw id) of
+// workgroup w (first 4096 workgroups) -- a residency census: how many workgroups are alive at once, and where
+#define SELFTOK_STAMP_DECL(sym) __device__ unsigned long long sym[2 + 3 * 4096]
 #define SELFTOK_STAMP_BEGIN()                                                                                    \
     unsigned long long stamp_tk0_ = 0, stamp_rt0_ = 0;                                                          \
-    const bool stamp_on_ = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;                              \
+    const bool stamp_on_ = threadIdx.x == 0;                                                                     \
     if (stamp_on_) { stamp_tk0_ = __builtin_readcyclecounter(); stamp_rt0_ = __builtin_amdgcn_s_memrealtime(); }
 #define SELFTOK_STAMP_END(sym)                                                                                   \
-    if (stamp_on_) { sym[0] = __builtin_readcyclecounter() - stamp_tk0_; sym[1] = __builtin_amdgcn_s_memrealtime() - stamp_rt0_; }
+    if (stamp_on_) {                                                                                             \
+        const unsigned long long rt1_ = __builtin_amdgcn_s_memrealtime();                                        \
+        const unsigned wg_ = blockIdx.x + blockIdx.y * gridDim.x;                                                \
+        if (wg_ == 0) { sym[0] = __builtin_readcyclecounter() - stamp_tk0_; sym[1] = rt1_ - stamp_rt0_; }        \
+        if (wg_ < 4096) { unsigned hw_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));         \
+            unsigned xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                   \
+            sym[2 + 3 * wg_] = stamp_rt0_; sym[3 + 3 * wg_] = rt1_; sym[4 + 3 * wg_] = ((unsigned long long)(xcc_ & 0xF) << 32) | hw_; }  \
+    }
 #else
 #define SELFTOK_STAMP_DECL(sym)
 #define SELFTOK_STAMP_BEGIN()

@@ -529,7 +529,11 @@ __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z
                                                      unsigned long long* __restrict__ partial, int N, int C,
                                                      int tiles_per_split, int normalize)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char s_tile[2][M_CH * 2048];     // 8 tiles x (2 planes x 64 lanes x 16 B), double buffered
+    // 8 tiles x (2 planes x 64 lanes x 16 B), double buffered, + 1 KiB of padding: 33 KiB instead of 32 so that FOUR workgroups fit a
+    // CU's 160 KiB, not five.  The launch is sized at four workgroups per CU (1024 at N = 32768); with room for a fifth the
+    // dispatcher packs some CUs with five and leaves others three, and the kernel lasts as long as its fullest CU (residency census
+    // of tools/sweep_vq_f16.py: workgroup lifetimes 42 .. 93 us for identical work, profiles/r3_vq_f16_sweep.txt)
+    __shared__ __attribute__((aligned(16))) unsigned char s_tile[2][M_CH * 2048 + 512];
     SELFTOK_STAMP_BEGIN();
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -606,49 +610,39 @@ __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z
             const int buf = c & 1;
             if (c + 1 < nchunks) stage(c + 1, buf ^ 1);
             const int base = c * M_CH;
-            // three chained f16 MFMAs per (tile, row block): the four row blocks' chains are written interleaved so that no MFMA
-            // waits for the one before it
-            auto mfma_tile = [&](int j, f32x16 (&acc)[RT]) {
-                const vh8 e0 = *reinterpret_cast<const vh8*>(&s_tile[buf][j * 2048 + lane * 16]);
-                const vh8 e1 = *reinterpret_cast<const vh8*>(&s_tile[buf][j * 2048 + 1024 + lane * 16]);
+#ifdef SELFTOK_VQ_PRIO
+            // progress-based priority: a wave drops its issue priority as it gets through its code range, so the waves that share a
+            // SIMD advance together instead of oldest-first (and finish together instead of leaving a one-wave-per-SIMD tail)
+            { const int q4 = (4 * c) / nchunks, q4p = c > 0 ? (4 * (c - 1)) / nchunks : -1;
+              if (q4 != q4p) { if (q4 == 0) __builtin_amdgcn_s_setprio(3); else if (q4 == 1) __builtin_amdgcn_s_setprio(2); else if (q4 == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } }
+#endif
+            // (round 3: a straight-line full-chunk body with two accumulator sets ping-ponging -- the scan of tile j interleaved with
+            // the MFMAs of tile j + 1 -- was built and measured: RT = 4 needs 274 VGPRs (one wave per SIMD) and runs 109 us, RT = 2
+            // 148 VGPRs and 95 us, against 92 - 95 us for the loop below; the kernel is not issue-bound: its workgroups keep the matrix
+            // pipe ~87 % busy in SHADER cycles while the chip runs them at 1.5 - 2.0 GHz under this load (tools/sweep_vq_f16.py clock
+            // stamps, profiles/r3_vq_f16_sweep.txt).  Kept: this loop.)
 #pragma unroll
-                for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, __builtin_bit_cast(vh8, x0[t]), zero, 0, 0, 0);
+            for (int j = 0; j < M_CH; ++j) {
+                if (base + j < nt) {                                   // wave-uniform
+                    const vh8 e0 = *reinterpret_cast<const vh8*>(&s_tile[buf][j * 2048 + lane * 16]);
+                    const vh8 e1 = *reinterpret_cast<const vh8*>(&s_tile[buf][j * 2048 + 1024 + lane * 16]);
+                    const int tile = tile_first + base + j;
 #pragma unroll
-                for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, __builtin_bit_cast(vh8, x1[t]), acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, __builtin_bit_cast(vh8, x0[t]), acc[t], 0, 0, 0);
-            };
-            // tile maximum (8 x v_max3), then (m1, m2) <- the two largest of (m1, m2, mt): v_max + v_med3
-            auto scan_tile = [&](int j, const f32x16 (&accs)[RT]) {
-                const int tile = tile_first + base + j;
-#pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    const f32x16& acc = accs[t];
-                    const float a0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]), a1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
-                    const float a2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]), a3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
-                    const float a4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
-                    const float mt = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), __builtin_fmaxf(__builtin_fmaxf(a3, a4), acc[15]));
-                    m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], mt);
-                    const bool g = mt > m1[t];                      // strict: the earliest tile holding the maximum is t1
-                    m1[t] = __builtin_fmaxf(m1[t], mt);
-                    t1[t] = g ? tile : t1[t];
+                    for (int t = 0; t < RT; ++t) {
+                        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, __builtin_bit_cast(vh8, x0[t]), zero, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, __builtin_bit_cast(vh8, x1[t]), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, __builtin_bit_cast(vh8, x0[t]), acc, 0, 0, 0);
+                        // tile maximum (8 x v_max3), then (m1, m2) <- the two largest of (m1, m2, mt): v_max + v_med3
+                        const float a0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]), a1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
+                        const float a2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]), a3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
+                        const float a4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
+                        const float mt = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), __builtin_fmaxf(__builtin_fmaxf(a3, a4), acc[15]));
+                        m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], mt);
+                        const bool g = mt > m1[t];                      // strict: the earliest tile holding the maximum is t1
+                        m1[t] = __builtin_fmaxf(m1[t], mt);
+                        t1[t] = g ? tile : t1[t];
+                    }
                 }
-            };
-            f32x16 accA[RT], accB[RT];
-            if (base + M_CH <= nt) {
-                // full chunk, one straight-line block: two accumulator sets ping-pong, the scan of tile j (VALU) is independent of the
-                // MFMAs of tile j + 1 and the scheduler interleaves them -- a scan costs ~15 VALU ops per row block, the 3 MFMAs of a
-                // row block leave ~15 issue slots free.  (Per-tile branches / one accumulator set serialise MFMA -> wait -> scan.)
-                mfma_tile(0, accA);
-#pragma unroll
-                for (int j = 0; j < M_CH; j += 2) {
-                    mfma_tile(j + 1, accB);
-                    scan_tile(j, accA);
-                    if (j + 2 < M_CH) mfma_tile(j + 2, accA);
-                    scan_tile(j + 1, accB);
-                }
-            } else {
-                for (int j = 0; j < M_CH && base + j < nt; ++j) { mfma_tile(j, accA); scan_tile(j, accA); }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1102,9 +1096,9 @@ int selftok_vq_encode_packed_f32(const float* z, const float* packed, void* ids,
 
 #ifdef SELFTOK_TUNE
 // tools/ builds only: (shader cycles, 100 MHz ticks) of workgroup (0, 0) of the last vq_f16_kernel launch
-int selftok_tune_vq_stamp(unsigned long long* out2)
+int selftok_tune_vq_stamp(unsigned long long* out, int n)
 {
-    return hipMemcpyFromSymbol(out2, HIP_SYMBOL(tune_stamp_vq_f16), 2 * sizeof(unsigned long long)) == hipSuccess ? SELFTOK_OK : SELFTOK_EHIP;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tune_stamp_vq_f16), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? SELFTOK_OK : SELFTOK_EHIP;
 }
 #endif
 

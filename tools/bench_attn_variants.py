@@ -31,10 +31,11 @@ for n in (512, 358, 77, 20):
     xs = torch.randn(B, 256, 3 * D, device="cuda")
     S = n + 256
     fl = 4.0 * B * H * S * S * 64
-    outs, times = {}, {"0": [], "1": []}
+    outs, times = {}, {"0": [], "1": [], "2": []}
     for rnd in range(5):                       # alternate the variants: the box's clock drifts by several % within a process
-        for var in ("0", "1"):
-            os.environ["SELFTOK_ATTN_VARIANT"] = var
+        for var in ("0", "1", "2"):
+            os.environ["SELFTOK_ATTN_VARIANT"] = "0" if var == "0" else "1"
+            os.environ["SELFTOK_ATTN_PRIO"] = "1" if var == "2" else "0"
             oc = torch.zeros(B, n, D, device="cuda")
             ox = torch.zeros(B, 256, D, device="cuda")
             f = lambda: ops.attention((ctx[..., :D], ctx[..., D:2 * D], ctx[..., 2 * D:], oc), (xs[..., :D], xs[..., D:2 * D], xs[..., 2 * D:], ox), H, 64)
@@ -42,8 +43,8 @@ for n in (512, 358, 77, 20):
             if var in outs:
                 assert torch.equal(outs[var][0], oc) and torch.equal(outs[var][1], ox)
             outs[var] = (oc, ox)
-    same = torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
-    for var, name in (("0", "register-staged (rounds 1-2)"), ("1", "LDS-DMA staged")):
+    same = all(torch.equal(outs["0"][0], outs[v][0]) and torch.equal(outs["0"][1], outs[v][1]) for v in ("1", "2"))
+    for var, name in (("0", "register-staged (rounds 1-2)"), ("1", "LDS-DMA staged"), ("2", "LDS-DMA staged + s_setprio 1 inside the MFMA clusters")):
         t = sorted(times[var])
         print(json.dumps({"variant": name, "n_ctx": n, "ms_median": round(t[2], 4), "ms_all": [round(v, 4) for v in times[var]],
                           "TFLOPs_median": round(fl / t[2] / 1e9, 1), "frac_fp32_mfma_peak": round(fl / t[2] / 1e9 / 157.3, 4)}), flush=True)

@@ -50,16 +50,41 @@ for rt in (1, 2, 4):
         ok = bool(torch.equal(ids, ref.reshape(-1)))
         tm, tf = ev(main), ev(fin)
         clk = ""
-        if hasattr(lib._lib if hasattr(lib, "_lib") else lib, "selftok_tune_vq_stamp") or True:
-            try:
-                st2 = (ctypes.c_ulonglong * 2)()
-                lib.selftok_tune_vq_stamp.restype = ctypes.c_int
-                torch.cuda.synchronize()
-                if lib.selftok_tune_vq_stamp(st2) == 0 and st2[1] > 0:
-                    ghz = st2[0] / (st2[1] * 10.0) / 1.0        # cycles per 10 ns tick -> GHz
-                    mfma_cyc = (32768 // 32 // sp) * rt * 3 * 32   # matrix-pipe cycles this wave's SIMD needs per wave (tiles x row blocks x 3 MFMAs x 32)
-                    clk = f"  WG(0,0): {st2[0]} shader cycles in {st2[1] * 10} ns = {ghz:.2f} GHz; own MFMA issue {mfma_cyc} cycles = {mfma_cyc / st2[0]:.2f} of its lifetime"
-            except AttributeError:
-                pass
+        try:
+            nwg = min(4096, ((n + 128 * rt - 1) // (128 * rt)) * sp)
+            st2 = (ctypes.c_ulonglong * (2 + 3 * 4096))()
+            lib.selftok_tune_vq_stamp.restype = ctypes.c_int
+            torch.cuda.synchronize()
+            if lib.selftok_tune_vq_stamp(st2, 2 + 3 * 4096) == 0 and st2[1] > 0:
+                ghz = st2[0] / (st2[1] * 10.0)                   # shader cycles per 10 ns tick
+                mfma_cyc = (32768 // 32 // sp) * rt * 3 * 32      # matrix-pipe cycles one wave of the workgroup issues (tiles x row blocks x 3 MFMAs x 32)
+                import numpy as np
+                a = np.array(st2[2:2 + 3 * nwg], dtype=np.uint64).reshape(nwg, 3)
+                t0, t1 = a[:, 0].astype(np.int64), a[:, 1].astype(np.int64)
+                base = t0.min()
+                span = (t1.max() - base) * 10e-3                  # us
+                life = (t1 - t0) * 10e-3
+                mid = base + (t1.max() - base) // 2
+                alive_mid = int(((t0 <= mid) & (t1 > mid)).sum())
+                started_1us = int((t0 <= base + 100).sum())
+                hw = (a[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+                xcc = (a[:, 2] >> np.uint64(32)).astype(np.int64)
+                cu = xcc * 4096 + ((hw >> 13) & 7) * 512 + ((hw >> 12) & 1) * 256 + ((hw >> 8) & 15) * 16      # (xcc, se, sh, cu)
+                if os.environ.get("SWEEP_CENSUS") and rt == 4 and sp == 16:
+                    import collections
+                    per_cu = collections.Counter(cu.tolist())
+                    print("    WGs per CU histogram:", sorted(collections.Counter(per_cu.values()).items()), " distinct CUs:", len(per_cu))
+                    for x in range(8):
+                        sel = xcc == x
+                        print(f"    XCC {x}: {int(sel.sum())} WGs, lifetime median {np.median(life[sel]):.1f} us, min {life[sel].min():.1f}, max {life[sel].max():.1f}")
+                    cnt = np.array([per_cu[c] for c in cu.tolist()])
+                    for k in sorted(set(cnt.tolist())):
+                        print(f"    WGs on a CU holding {k}: lifetime median {np.median(life[cnt == k]):.1f} us")
+                    simd = (hw >> 4) & 3
+                    print("    SIMD of each WG's wave 0:", sorted(collections.Counter(simd.tolist()).items()))
+                clk = (f"  WG(0,0) {ghz:.2f} GHz, own MFMA issue {mfma_cyc / st2[0]:.2f} of its lifetime | {nwg} WGs: span {span:.1f} us, WG lifetime median {np.median(life):.1f} us "
+                       f"(min {life.min():.1f} max {life.max():.1f}), alive at mid-kernel {alive_mid}, started within the first 1 us {started_1us}")
+        except AttributeError:
+            pass
         print(f"RT={rt} split={sp:2d}: main {tm * 1e3:7.1f} us ({flops / tm / 1e9 / 2500:.3f} of the f16 peak)  finalize {tf * 1e3:6.1f} us  total {1e3 * (tm + tf):7.1f} us  ids ok: {ok}{clk}", flush=True)
         assert ok
