@@ -271,8 +271,9 @@ def cfg_uncond_forward(sd: SD, x: torch.Tensor, t: torch.Tensor, K: int, tables=
 
 
 def sample_one_step(sd: SD, x: torch.Tensor, i: int, ehs: torch.Tensor, mask: torch.Tensor, sch, tables=None,
-                    cfg_scale: float = 1.0, context_see_xt: bool = True) -> torch.Tensor:
-    """RectifiedFlow.sample_one_step + euler_step 'velocity' (sd3/rectified_flow.py:258-304) for schedule entry i.
+                    cfg_scale: float = 1.0, context_see_xt: bool = True, parameterization: str = "velocity") -> torch.Tensor:
+    """RectifiedFlow.sample_one_step + euler_step (sd3/rectified_flow.py:258-309) for schedule entry i; `parameterization` 'velocity'
+    (shipped configs) or 'x0' (:305-307: the model output is the clean latent, x_prev = v + a_prev (x - v) / a_t).
     cfg_scale != 1: out = u + s (c - u) with u = cfg_inference(...) and c = model(x, t, None, context, mask=) -- that call does
     not forward context_see_xt, which therefore falls back to False (sd3/mmdit.py:1012)."""
     B = x.shape[0]
@@ -285,6 +286,8 @@ def sample_one_step(sd: SD, x: torch.Tensor, i: int, ehs: torch.Tensor, mask: to
         u = cfg_uncond_forward(sd, x, t, ehs.shape[1], tables)
         c = dit_forward(sd, x, t, ehs, mask, False, tables)
         v = u + cfg_scale * (c - u)
+    if parameterization == "x0":
+        return v + a_prev * (x - v) / a_t
     return x - (a_t - a_prev) * v
 
 
@@ -305,7 +308,8 @@ def renderer_forward(sd: SD, ehs: torch.Tensor, tables=None) -> torch.Tensor:
 
 def decode_latent(sd: SD, ids: torch.Tensor, noise: torch.Tensor, stages, k_per_stage, num_steps: int = 50,
                   tables=None, trace: Optional[list] = None, max_steps: Optional[int] = None, uncond_scale: float = 1.0,
-                  prefix_k: Optional[int] = None) -> torch.Tensor:
+                  prefix_k: Optional[int] = None, super_mask: Optional[torch.Tensor] = None,
+                  parameterization: str = "velocity") -> torch.Tensor:
     """SelftokPipeline.decoding up to pred_x0 (SelftokPipeline.py:232-282) + p_sample_loop / euler_step
     (sd3/rectified_flow.py:165-256, 258-309).  The pipeline never forwards uncond_scale (cfg_scale == 1); `uncond_scale` exposes
     p_sample_loop's own argument.  `prefix_k`: p_sample_loop's `super_mask` = the first prefix_k tokens (mask * super_mask,
@@ -321,7 +325,10 @@ def decode_latent(sd: SD, ids: torch.Tensor, noise: torch.Tensor, stages, k_per_
         mask = (torch.arange(K)[None, :] <= int(ks[i])).expand(B, K)
         if prefix_k is not None:
             mask = mask & (torch.arange(K)[None, :] < int(prefix_k))
-        x = sample_one_step(sd, x, i, ehs, mask, sch, tables, cfg_scale=uncond_scale, context_see_xt=True)
+        if super_mask is not None:                       # mask = mask * super_mask (rectified_flow.py:226-227), any visibility pattern
+            mask = mask & torch.as_tensor(super_mask).bool().reshape(-1, K)
+        x = sample_one_step(sd, x, i, ehs, mask, sch, tables, cfg_scale=uncond_scale, context_see_xt=True,
+                            parameterization=parameterization)
         if trace is not None:
             trace.append(x.clone())
     return x

@@ -146,19 +146,20 @@ class MMDiTGPU:
 
     # ---- the 24 joint blocks + final layer ---------------------------------------------------------
     @torch.no_grad()
-    def block0_context_qkv(self, ctx0: torch.Tensor) -> torch.Tensor:
+    def block0_context_qkv(self, ctx0: torch.Tensor, tables=None) -> torch.Tensor:
         """QKV of the context stream in block 0: LN(ctx0)*(1+scale)+shift -> Linear.  Depends on the tokens only (not on
         x_t or t), so the sampler computes it once per decode instead of once per step (the reference recomputes it)."""
         H = DIT_HIDDEN
-        t0 = self.ctx_tables[0][: ctx0.shape[1]]
+        t0 = (tables or self.ctx_tables)[0][: ctx0.shape[1]]
         _, cn = self._ln("model.joint_blocks.0.context_block.attn.qkv", ctx0, shift=t0[:, 0:H], scale=t0[:, H:2 * H])
         return self.lin("model.joint_blocks.0.context_block.attn.qkv", cn)
 
     @torch.no_grad()
     def core(self, xe: torch.Tensor, c: torch.Tensor, ctx: Optional[torch.Tensor], seg0_sees_seg1: bool = True,
-             kvis: Optional[torch.Tensor] = None, cqkv0: Optional[torch.Tensor] = None) -> torch.Tensor:
+             kvis: Optional[torch.Tensor] = None, cqkv0: Optional[torch.Tensor] = None, tables=None) -> torch.Tensor:
         """xe [B,n_x,H] embedded image tokens, c [B,H], ctx [B,n_ctx,H] live context tokens (or None / n_ctx = 0)
-        -> FinalLayer output [B,n_x,64] (before unpatchify)."""
+        -> FinalLayer output [B,n_x,64] (before unpatchify).  `tables`: per-block context adaLN tables whose row j belongs to context
+        row j (default: the position tables; `gather_context` returns the rows of a visibility pattern)."""
         H, NH = DIT_HIDDEN, DIT_HEADS
         B, nx, _ = xe.shape
         n = 0 if ctx is None else ctx.shape[1]
@@ -168,7 +169,7 @@ class MMDiTGPU:
         mods_x = [self.lin(f"model.joint_blocks.{i}.x_block.adaLN_modulation.1", sc) for i in range(DIT_DEPTH)]   # [B,6H]
         mods_c_last = self.lin(f"model.joint_blocks.{DIT_DEPTH - 1}.context_block.adaLN_modulation.1", sc) if has_ctx else None  # [B,2H]
         mods_f = self.lin("model.final_layer.adaLN_modulation.1", sc)                                              # [B,2H]
-        tab = [t[:n] for t in self.ctx_tables]
+        tab = [t[:n] for t in (tables or self.ctx_tables)]
         x = xe
         blk = "model.joint_blocks.{}.{}_block.{}".format
 
@@ -234,11 +235,22 @@ class MMDiTGPU:
         return ops.add_rows_(xe, self._pos_bias(Hh // 2, Ww // 2))
 
     @torch.no_grad()
-    def velocity_tokens(self, x, t_freq, ctx0, n_live: int, context_see_xt: bool = True, cqkv0=None):
+    def velocity_tokens(self, x, t_freq, ctx0, n_live: int, context_see_xt: bool = True, cqkv0=None, tables=None):
         """one model evaluation inside the sampler: returns the FinalLayer tokens [B,256,64]"""
         c = self.time_embed(t_freq)
         ctx = ctx0[:, :n_live].contiguous() if n_live < ctx0.shape[1] else ctx0
-        return self.core(self.embed_image(x), c, ctx if n_live > 0 else None, context_see_xt, cqkv0=cqkv0 if n_live > 0 else None)
+        return self.core(self.embed_image(x), c, ctx if n_live > 0 else None, context_see_xt, cqkv0=cqkv0 if n_live > 0 else None,
+                         tables=tables)
+
+    @torch.no_grad()
+    def gather_context(self, ctx0: torch.Tensor, visible: torch.Tensor):
+        """A visibility pattern over the context tokens that is not a prefix (the reference's `super_mask`, rectified_flow.py:226-227).
+        A masked context token is a key nobody can attend to, and its own row feeds nothing but its keys / values in later blocks
+        (the model returns the image stream only): dropping the masked rows is exact.  Returns the visible rows of ctx0 in token order,
+        the matching rows of the 23 position tables, and the sorted visible positions -- with them the sampler's step mask
+        `arange(K) <= k` is again a PREFIX (of the visible list) and the truncated-context path applies unchanged."""
+        idx = torch.nonzero(visible.to(self.device).reshape(-1).bool())[:, 0]
+        return ctx0[:, idx].contiguous(), [t[idx].contiguous() for t in self.ctx_tables], idx
 
     @torch.no_grad()
     def __call__(self, x=None, t=None, y=None, encoder_hidden_states=None, **kwargs):

@@ -68,9 +68,12 @@ class _Flow(FlowSchedule):
     """`pipe.flow`: RectifiedFlow(50, start, cut_of_k, val_schedule='uniform', shift=1.0, ...) buffers as numpy,
     plus the device-side sampler (p_sample_loop / sample_one_step / euler_step, sd3/rectified_flow.py:165-309)."""
 
-    def __init__(self, num_steps, start, device):
+    def __init__(self, num_steps, start, device, parameterization: str = "velocity"):
         super().__init__(num_steps, start)
         self.device = device
+        if parameterization not in ("velocity", "x0"):
+            raise ValueError(f"parameterization {parameterization!r}: expected 'velocity' or 'x0'")
+        self.parameterization = parameterization                              # euler_step (sd3/rectified_flow.py:301-309)
         # sinusoidal embedding of t*1000 for the scheduled timesteps, evaluated with the reference's CPU arithmetic
         t1000 = torch.from_numpy(self.scheduled_t) * 1000.0
         self.t_freq = sinusoid_host(t1000).to(device)                        # [steps,256]
@@ -81,30 +84,52 @@ class _Flow(FlowSchedule):
     @torch.no_grad()
     def p_sample_loop(self, dit: MMDiTGPU, noise: torch.Tensor, ehs: torch.Tensor, k_table: np.ndarray,
                       context_see_xt: bool = True, uncond_scale: float = 1.0, max_steps: Optional[int] = None,
-                      trace: Optional[list] = None, prefix_k: Optional[int] = None) -> torch.Tensor:
+                      trace: Optional[list] = None, prefix_k: Optional[int] = None, super_mask=None) -> torch.Tensor:
         """`prefix_k`: the reference loop's `super_mask` (rectified_flow.py:226-227, mask = mask * super_mask) for the prefix mask
-        arange(K) < prefix_k -- only the first prefix_k tokens are ever visible (decode from a partial token sequence)."""
+        arange(K) < prefix_k -- only the first prefix_k tokens are ever visible (decode from a partial token sequence).
+        `super_mask`: the same hook for ANY visibility pattern over the K tokens ([K] bool / 0-1, the same for every sample): the visible
+        tokens are gathered once (MMDiTGPU.gather_context) and the step mask is a prefix of that list."""
         B = noise.shape[0]
         x = noise.to(self.device).float().contiguous()
         hp, wp = x.shape[-2] // 2, x.shape[-1] // 2
         ctx0 = dit.embed_context(ehs)                                         # step independent
-        cqkv0 = dit.block0_context_qkv(ctx0)                                  # so is block 0's context QKV
+        tables, vis_pos = None, None
+        if super_mask is not None:
+            sm = torch.as_tensor(super_mask)
+            if sm.dim() == 2:
+                if not bool((sm == sm[:1]).all()):
+                    raise NotImplementedError("a super_mask that differs between the samples of a batch is not implemented "
+                                              "(decode the samples separately, or pass one [K] pattern)")
+                sm = sm[0]
+            if sm.numel() != ctx0.shape[1]:
+                raise ValueError(f"super_mask has {sm.numel()} entries, the tokenizer has K = {ctx0.shape[1]} tokens")
+            ctx0, tables, vis_pos = dit.gather_context(ctx0, sm)
+            vis_pos = vis_pos.cpu().numpy()
+        cqkv0 = dit.block0_context_qkv(ctx0, tables) if ctx0.shape[1] > 0 else None   # block 0's context QKV is step independent too
         steps = self.num_timesteps if max_steps is None else min(max_steps, self.num_timesteps)
         for i in range(steps):
             n_live = int(k_table[i]) + 1                                      # mask = arange(K) <= k  (models_ours.py:353)
             if prefix_k is not None:
                 n_live = min(n_live, int(prefix_k))
+            if vis_pos is not None:                                           # visible tokens at positions < n_live: a prefix of the gathered list
+                n_live = int(np.searchsorted(vis_pos, n_live, side="left"))
             tf = self.t_freq[i:i + 1].expand(B, -1).contiguous()
             if uncond_scale == 1.0:
-                y = dit.velocity_tokens(x, tf, ctx0, n_live, context_see_xt, cqkv0)
+                y = dit.velocity_tokens(x, tf, ctx0, n_live, context_see_xt, cqkv0, tables)
                 yu = None
             else:
                 # CFG branch (rectified_flow.py:280-289): the conditional call omits context_see_xt (-> False) and
                 # the unconditional one sees no context token at all
-                y = dit.velocity_tokens(x, tf, ctx0, n_live, False, cqkv0)
+                y = dit.velocity_tokens(x, tf, ctx0, n_live, False, cqkv0, tables)
                 tfu = self.t_freq_uncond[i:i + 1].expand(B, -1).contiguous()
                 yu = dit.velocity_tokens(x, tfu, ctx0, 0, False)              # cfg_inference: no context key visible at all
-            x, _ = ops.unpatchify_cfg_euler(y, x, float(self.dt[i]), y_uncond=yu, cfg_scale=uncond_scale, C=x.shape[1], hp=hp, wp=wp)
+            if self.parameterization == "x0":
+                # the model output is the clean latent: x_prev = v + a_prev (x - v) / a_t  (euler_step, rectified_flow.py:305-307);
+                # the CFG mix rides in the unpatchify kernel, the update is the reference's own chain of fp32 element-wise ops
+                _, v = ops.unpatchify_cfg_euler(y, None, 0.0, y_uncond=yu, cfg_scale=uncond_scale, C=x.shape[1], hp=hp, wp=wp)
+                x = v + float(self.scheduled_t_prev[i]) * (x - v) / float(self.scheduled_t[i])
+            else:
+                x, _ = ops.unpatchify_cfg_euler(y, x, float(self.dt[i]), y_uncond=yu, cfg_scale=uncond_scale, C=x.shape[1], hp=hp, wp=wp)
             if trace is not None:
                 trace.append(x.clone())
         return x
@@ -153,9 +178,9 @@ class SelftokPipeline():
         if p.get("diffusion_type", "flow") != "flow":
             raise NotImplementedError("diffusion_type != 'flow' (the Gaussian-diffusion sampler is outside the hot path)")
         nsc = p.noise_schedule_config
-        if nsc.get("parameterization", "velocity") != "velocity":
-            raise NotImplementedError("noise_schedule_config.parameterization == 'x0' (rectified_flow.py:305-307) is not implemented; "
-                                      "the shipped configs use 'velocity'")
+        self.parameterization = str(nsc.get("parameterization", "velocity"))
+        if self.parameterization not in ("velocity", "x0"):
+            raise ValueError(f"noise_schedule_config.parameterization {self.parameterization!r}: expected 'velocity' or 'x0'")
         cut = p.get("cut_of_k", None)
         if cut and float(cut) < 1:
             raise NotImplementedError("cut_of_k < 1 (context padding, rectified_flow.py:216-224) is not implemented; the shipped configs do not set it")
@@ -188,7 +213,7 @@ class SelftokPipeline():
         self.cfg_scale = cfg_scale
         self.cut_of_k = p.get("cut_of_k", None) or None
         self._steps = 50
-        self.flow = _Flow(self._steps, self.start, self.device)
+        self.flow = _Flow(self._steps, self.start, self.device, self.parameterization)
         self.k_table = self.diti.to_indices(self.flow.t_long)                # k for each of the 50 steps
         self.cond_vary = True
         self.saved_images = 8
@@ -259,19 +284,20 @@ class SelftokPipeline():
         return out
 
     @torch.no_grad()
-    def _sample(self, xt, ehs, max_steps, uncond_scale, use_graph, prefix_k=None):
+    def _sample(self, xt, ehs, max_steps, uncond_scale, use_graph, prefix_k=None, super_mask=None):
         """the 50-step loop, optionally replayed from a hipGraph captured once per (batch, latent size) -- the loop is
         ~21k kernel launches; at small batch the host cannot issue them as fast as the GPU retires them."""
         if not use_graph:
             return self.flow.p_sample_loop(self.model.model, xt, ehs, self.k_table, context_see_xt=True,
-                                           uncond_scale=uncond_scale, max_steps=max_steps, prefix_k=prefix_k)
-        key = (tuple(xt.shape), tuple(ehs.shape), max_steps, float(uncond_scale), self.model.model.gemm, prefix_k)
+                                           uncond_scale=uncond_scale, max_steps=max_steps, prefix_k=prefix_k, super_mask=super_mask)
+        sm_key = None if super_mask is None else np.asarray(torch.as_tensor(super_mask).cpu()).astype(bool).tobytes()
+        key = (tuple(xt.shape), tuple(ehs.shape), max_steps, float(uncond_scale), self.model.model.gemm, prefix_k, sm_key)
         if key not in self._graphs:
             s_noise = torch.empty(xt.shape, dtype=torch.float32, device=self.device)
             s_ehs = torch.empty_like(ehs)
             s_noise.copy_(xt); s_ehs.copy_(ehs)
             run = lambda: self.flow.p_sample_loop(self.model.model, s_noise, s_ehs, self.k_table, context_see_xt=True,
-                                                  uncond_scale=uncond_scale, max_steps=max_steps, prefix_k=prefix_k)
+                                                  uncond_scale=uncond_scale, max_steps=max_steps, prefix_k=prefix_k, super_mask=super_mask)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):       # warm-up outside capture (hipBLASLt / allocator warm)
@@ -290,12 +316,13 @@ class SelftokPipeline():
     @torch.no_grad()
     def decoding(self, idx, device=None, noise: Optional[torch.Tensor] = None, return_latent: bool = False,
                  max_steps: Optional[int] = None, uncond_scale: float = 1.0, use_graph: bool = False,
-                 prefix_k: Optional[int] = None):
+                 prefix_k: Optional[int] = None, super_mask=None):
         """idx: np.ndarray int64 [B,K] -> bf16 [B,3,H,W] in [0,1] (reference :227-294).  `noise` (extension) replaces the
         `torch.randn` draw from the global CPU generator (:264); `uncond_scale` exposes the dormant CFG branch
         (p_sample_loop's argument of that name).  `prefix_k` (extension): decode from the first prefix_k tokens only -- the
         reference loop's `super_mask` hook with a prefix mask (rectified_flow.py:226-227; README.md:241: an AR model emits the
-        sequence in reverse order, `tokens.from_ar_order` restores it and `tokens.pad_prefix` pads a partial one to [B,K])."""
+        sequence in reverse order, `tokens.from_ar_order` restores it and `tokens.pad_prefix` pads a partial one to [B,K]).
+        `super_mask` (extension): the same hook with any visibility pattern over the K tokens ([K] bool / 0-1 array)."""
         self._say("Begin decoding.")
         if prefix_k is not None and not (0 <= int(prefix_k) <= self.K):
             raise ValueError(f"prefix_k must be in [0, {self.K}]")
@@ -306,7 +333,7 @@ class SelftokPipeline():
         ehs = outs_q if k0 >= self.K - 1 else outs_q * (torch.arange(self.K, device=self.device) <= k0)[None, :, None]
         latent_dim = self.datasize // 8
         xt = noise if noise is not None else torch.randn(B, 16, latent_dim, latent_dim)
-        pred_x0 = self._checked(lambda: self._sample(xt, ehs, max_steps, uncond_scale, use_graph, prefix_k))
+        pred_x0 = self._checked(lambda: self._sample(xt, ehs, max_steps, uncond_scale, use_graph, prefix_k, super_mask))
         recons = self._to_pixels(pred_x0)
         self._say('End decoding.')
         return (recons, pred_x0) if return_latent else recons

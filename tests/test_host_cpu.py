@@ -269,15 +269,15 @@ def test_ar_order_and_prefix_helpers():
 
 
 def test_unsupported_config_knobs_are_refused_not_ignored():
-    """cut_of_k < 1 / parameterization 'x0' change the reference's result; the pipeline must refuse them before touching a GPU"""
+    """cut_of_k < 1 and a non-flow diffusion_type change the reference's result and are not implemented: the pipeline must refuse them
+    before touching a GPU (cut_of_k < 1 cannot even run through the reference's own SelftokPipeline: p_sample_loop concatenates a
+    super_mask the pipeline never passes, rectified_flow.py:216-222).  parameterization 'x0' IS implemented since round 3."""
     src = open(os.path.join(ROOT, "selftoktokenizer_amd", "pipeline.py")).read()
-    assert "cut_of_k < 1" in src and "parameterization" in src and src.count("raise NotImplementedError") >= 3
-    if torch.cuda.is_available():
-        from mimogpt.infer.SelftokPipeline import SelftokPipeline
-        cfg = config.default_config(512)
-        cfg.tokenizer.params.noise_schedule_config.parameterization = "x0"
-        with pytest.raises(NotImplementedError):
-            SelftokPipeline(cfg, None, None, device="cuda", state_dict={}, vae_state_dict={})
+    assert "cut_of_k < 1" in src and src.count("raise NotImplementedError") >= 2
+    from selftoktokenizer_amd.pipeline import _Flow
+    assert _Flow(50, 1.0, "cpu", "x0").parameterization == "x0" and _Flow(50, 1.0, "cpu").parameterization == "velocity"
+    with pytest.raises(ValueError):
+        _Flow(50, 1.0, "cpu", "eps")
 
 
 def test_save_image_uses_the_tensor_dtype_arithmetic(tmp_path):

@@ -336,3 +336,46 @@ def test_full_batch_size_independence(pipe):
     from selftoktokenizer_amd.dist import shard_range
     lo, hi = shard_range(B, 3, 8)
     assert torch.equal(t_chunks[lo:hi], pipe.model.encoder(x0[lo:hi], d=None)[1])
+
+
+@pytest.mark.parametrize("gemm", ["fp32", "f16x2"])
+def test_sampler_options_vs_reference(pipe, gemm):
+    """two dormant branches of the reference's sampler, against its own RectifiedFlow.sample_one_step on the real MMDiT
+    (tests/golden/sampler_options_b1.npz): `parameterization: x0` (euler_step, sd3/rectified_flow.py:305-307) and a NON-prefix
+    `super_mask` (p_sample_loop's mask * super_mask, :226-227) with a hash-random visibility pattern."""
+    g = np.load(os.path.join(GOLD, "sampler_options_b1.npz"))
+    noise = synth.synthetic_noise(1, first_index=21)
+    assert pipe.set_gemm(gemm) == gemm
+    real = pipe.flow.p_sample_loop
+    try:
+        for name, kw, param in (("x0", {}, "x0"), ("supermask", {"super_mask": g["super_mask"]}, "velocity")):
+            trace = []
+            pipe.flow.p_sample_loop = lambda *a, **k: real(*a, trace=trace, **k)
+            pipe.flow.parameterization = param
+            pipe.decoding(g["ids"], noise=noise, max_steps=2, **kw)
+            for n in (1, 2):
+                err = float((trace[n - 1].cpu() - torch.from_numpy(g[f"{name}_after_{n}"])).abs().max())
+                print(f"[{gemm}] {name}: latent after {n} steps vs the reference, max abs err {err:.3e}")
+                assert err < 2e-5
+    finally:
+        pipe.flow.p_sample_loop = real
+        pipe.flow.parameterization = "velocity"
+        pipe.set_gemm("fp32")
+    # the visibility pattern is honoured exactly: ids at masked positions are never read ...
+    ids2 = g["ids"].copy()
+    ids2[:, ~g["super_mask"]] = (ids2[:, ~g["super_mask"]] + 12345) % 32768
+    _, la = pipe.decoding(g["ids"], noise=noise, max_steps=2, super_mask=g["super_mask"], return_latent=True)
+    _, lb = pipe.decoding(ids2, noise=noise, max_steps=2, super_mask=g["super_mask"], return_latent=True)
+    assert torch.equal(la, lb)
+    # ... a prefix pattern equals prefix_k, an all-true pattern equals no mask, and per-sample patterns are refused
+    pre = np.arange(512) < 100
+    _, lc = pipe.decoding(g["ids"], noise=noise, max_steps=2, super_mask=pre, return_latent=True)
+    _, ld = pipe.decoding(g["ids"], noise=noise, max_steps=2, prefix_k=100, return_latent=True)
+    torch.testing.assert_close(lc, ld, rtol=0, atol=2e-5)          # (block 0's context QKV runs as a GEMM over 100 instead of 512 rows per sample)
+    _, le = pipe.decoding(g["ids"], noise=noise, max_steps=2, super_mask=np.ones(512, bool), return_latent=True)
+    _, lf = pipe.decoding(g["ids"], noise=noise, max_steps=2, return_latent=True)
+    torch.testing.assert_close(le, lf, rtol=0, atol=2e-5)
+    with pytest.raises(NotImplementedError):
+        pipe.decoding(np.repeat(g["ids"], 2, 0), noise=synth.synthetic_noise(2), max_steps=1, super_mask=np.stack([pre, ~pre]))
+    with pytest.raises(ValueError):
+        pipe.decoding(g["ids"], noise=noise, max_steps=1, super_mask=np.ones(100, bool))

@@ -1,7 +1,7 @@
 """Generate tests/golden/*.npz by running the REFERENCE (read-only import, build container only) on the
 hash-generated synthetic weights/inputs, and report how oracle/ compares on the same inputs.
 
-    python tools/oracle/gen_golden.py [stage ...]      stages: keys vq schedule encoder dit vae pipeline pipeline16 renderer cfg k1024 vqtrain rmsnorm_rotary
+    python tools/oracle/gen_golden.py [stage ...]      stages: keys vq schedule encoder dit vae pipeline pipeline16 renderer cfg k1024 vqtrain rmsnorm_rotary sampler_options
 
 A golden file holds only data: inputs that cannot be regenerated from a seed, and the reference's
 outputs.  Weights/images/noise are regenerated from selftoktokenizer_amd.synth by name/seed.
@@ -449,6 +449,44 @@ def stage_cfg():
     np.savez_compressed(os.path.join(GOLD, "cfg_b1.npz"), **out)
 
 
+def stage_sampler_options():
+    """two dormant branches of the reference's sampler, from the reference's own RectifiedFlow.sample_one_step on the real MMDiT:
+    (a) `parameterization: x0` (euler_step, sd3/rectified_flow.py:305-307): two steps from the first schedule entries;
+    (b) a NON-prefix `super_mask` (p_sample_loop's mask * super_mask, :226-227): two velocity steps with a hash-random visibility
+        pattern over the 512 tokens (the step mask arange(K) <= k times the pattern)."""
+    cfg, model, sd = tokenizer(CFG_256)
+    H.install()
+    from mimogpt.models.selftok.sd3.rectified_flow import RectifiedFlow
+    from mimogpt.models.selftok.diti_utils import DiTi_cont
+    diti = DiTi_cont(1000, 512, cfg.tokenizer.params.stages, cfg.tokenizer.params.k_per_stage)
+    ids = torch.from_numpy(synth.synthetic_token_ids(1, first_index=21))
+    with torch.no_grad():
+        codes = model.encoder.quantizer.get_output_from_indices(ids)
+        ehs = model.encoder.final_layer_norm3(codes.reshape(1, -1, 16))
+    x = synth.synthetic_noise(1, first_index=21)
+    sch = OS.make_schedule(50)
+    tables = OM.dit_ctx_tables(sd, 512)
+    sup = (synth.hash_u32(0x5A5A, 512) % 3 != 0)                 # ~2/3 of the tokens visible, no structure
+    out = {"ids": ids.numpy(), "super_mask": sup.numpy()}
+    for name, param, smask in (("x0", "x0", None), ("supermask", "velocity", sup)):
+        flow = RectifiedFlow(50, 1.0, None, val_schedule="uniform", shift=1.0, schedule="log_norm", parameterization=param, m=0.0, s=1.0,
+                             force_recon=False, is_eval=True)
+        xr, xo = x.clone(), x.clone()
+        for i in (0, 1):
+            t = torch.tensor([flow.scheduled_t[i]])
+            k = diti.to_indices(torch.tensor([flow.timestep_map[i]]).long())
+            mask = model.encoder.get_encoder_mask(x, k)
+            if smask is not None:
+                mask = mask * smask[None]
+            kw = dict(encoder_hidden_states=ehs, mask=mask, context_see_xt=True)
+            with torch.no_grad():
+                xr, _ = flow.sample_one_step(model.model, xr, t, index=i, model_kwargs=kw, cfg_scale=1.0)
+            xo = OM.sample_one_step(sd, xo, i, ehs, mask.bool(), sch, tables, parameterization=param)
+            report(f"sampler_{name}_step{i}", lat_maxdiff=maxdiff(xr, xo), k=int(k[0]), visible=int(mask.sum()))
+            out[f"{name}_after_{i + 1}"] = xr.numpy()
+    np.savez_compressed(os.path.join(GOLD, "sampler_options_b1.npz"), **out)
+
+
 def stage_k1024():
     """BASELINE configs[2]: the reference's own ImageTokenizer built with k = 1024 (query_tokens / context_pos_embed grow, stage
     split ASSUMED 384,368,144,96,32 -- the reference ships no 1024 config): encoder features + ids, and one MMDiT.forward."""
@@ -572,7 +610,7 @@ def stage_rmsnorm_rotary():
     report("rmsnorm_rotary", arrays=sorted(out), rms_absmax=float(np.abs(out["rms_affine"]).max()), rot_absmax=float(np.abs(out["rot_full"]).max()))
 
 
-STAGES = dict(rmsnorm_rotary=stage_rmsnorm_rotary, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
+STAGES = dict(rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
               vae=stage_vae, pipeline=stage_pipeline, pipeline16=stage_pipeline16, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024, vqtrain=stage_vqtrain)
 
 if __name__ == "__main__":
