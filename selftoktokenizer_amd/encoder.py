@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
+from .modsurface import ModuleSurface
 from .schedule import DiTiCont
 from .weights import ENC_DEPTH, ENC_HEADS, ENC_HIDDEN, ENC_QDIM, ENC_QHEADS, FREQ_DIM
 
@@ -48,7 +49,8 @@ class _Quantizer:
         return ops.code_gather_ln(indices, self._enc.codebook)   # project_out is Identity (dim 16 == 16)
 
 
-class QformerEncoderGPU:
+class QformerEncoderGPU(ModuleSurface):
+    _sd_prefix = "encoder."
     def __init__(self, sd: Dict[str, torch.Tensor], device, K: int):
         g = lambda k: sd[k].to(device=device, dtype=torch.float32).contiguous()
         self.device, self.K = device, K
@@ -68,6 +70,11 @@ class QformerEncoderGPU:
             h = F.linear(ops.silu(h), self.w[p + ".t_embedder.mlp.2.weight"], self.w[p + ".t_embedder.mlp.2.bias"])
             self.tables.append(F.linear(ops.silu(h), self.w[p + ".adaLN_modulation.1.weight"], self.w[p + ".adaLN_modulation.1.bias"]).contiguous())
         self.quantizer = _Quantizer(self)
+
+    def _flat_weights(self):
+        d = dict(self.w)
+        d["encoder.quantizer._codebook.embed"] = self.codebook[None]
+        return d
 
     # ---- helpers -------------------------------------------------------------------------------
     def _pos_bias(self, h: int, w: int) -> torch.Tensor:

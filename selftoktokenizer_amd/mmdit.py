@@ -26,12 +26,14 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
+from .modsurface import ModuleSurface
 from .encoder import sinusoid_host
 from .schedule import DiTiCont
 from .weights import DIT_DEPTH, DIT_HEADS, DIT_HIDDEN, POS_MAX_DIT
 
 
-class MMDiTGPU:
+class MMDiTGPU(ModuleSurface):
+    _sd_prefix = "model."
     GEMM_MODES = ("fp32", "f16x2")
     PRESPLIT = True     # f16x2 mode: producers (LN-modulate, attention, fc1+GELU) hand the next Linear its input already split
 

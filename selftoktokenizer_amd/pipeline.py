@@ -20,6 +20,7 @@ import torch
 from . import _lib, ops, weights as W
 from .encoder import QformerEncoderGPU, sinusoid_host
 from .mmdit import MMDiTGPU
+from .modsurface import ModuleSurface
 from .schedule import DiTiCont, FlowSchedule
 from .vae import AutoencoderKLGPU
 
@@ -47,21 +48,19 @@ def norm_ip(img, low=-1, high=1):
     return ops.clamp01_(img)
 
 
-class _Tokenizer:
-    """`pipe.model` : the ImageTokenizer surface (image_tokenizer.py:58-159) the pipeline and users touch."""
+class _Tokenizer(ModuleSurface):
+    """`pipe.model` : the ImageTokenizer surface (image_tokenizer.py:58-159) the pipeline and users touch: `.encoder`, `.model`
+    (the MMDiT), `.diti`, `.k`, and the read-only Module surface (`state_dict()` has the reference checkpoint's keys)."""
 
     def __init__(self, encoder, model, diti):
         self.encoder, self.model, self.diti = encoder, model, diti
         self.k = diti.K
+        self.device = encoder.device
 
-    def set_eval(self):
-        return self
-
-    def eval(self):
-        return self
-
-    def to(self, *a, **k):
-        return self
+    def _flat_weights(self):
+        d = dict(self.encoder._flat_weights())
+        d.update(self.model._flat_weights())
+        return d
 
 
 class _Flow(FlowSchedule):

@@ -32,6 +32,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
+from .modsurface import ModuleSurface
 
 ONES_PAD = 8          # extra input channels per convolution: [ones, 0, 0, 0, 0, 0, 0, 0]
 
@@ -59,7 +60,8 @@ class _Deterministic:
         return False
 
 
-class AutoencoderKLGPU:
+class AutoencoderKLGPU(ModuleSurface):
+    _sd_prefix = ""
     def __init__(self, vsd: Dict[str, torch.Tensor], device, dtype=torch.bfloat16):
         assert dtype == torch.bfloat16, "the HIP GroupNorm+SiLU epilogue is bf16 (the reference runs the VAE in bf16)"
         self.device, self.dtype = device, dtype
@@ -77,13 +79,6 @@ class AutoencoderKLGPU:
                 wb[:, C, kh // 2, kw // 2] = self.w[k[:-len("weight")] + "bias"]
                 self.wb[k[:-len(".weight")]] = wb.contiguous()
         self._tails = {}
-
-    # diffusers-ish plumbing so the pipeline code reads like the reference
-    def to(self, *a, **k):
-        return self
-
-    def eval(self):
-        return self
 
     def _gn_silu(self, name, x, act=True):
         return ops.groupnorm_silu(x.contiguous(), self.w[name + ".weight"], self.w[name + ".bias"], 32, 1e-6, act)

@@ -27,6 +27,18 @@ def test_api_surface(pipe):
     assert pipe.K == 512 and pipe._steps == 50
     assert hasattr(pipe, "vae") and hasattr(pipe, "flow") and hasattr(pipe.model, "encoder") and hasattr(pipe.model, "model")
     assert pipe.flow.timestep_map.shape == (50,)
+    # the read-only nn.Module surface users of the reference touch on pipe.model / pipe.vae (SelftokPipeline.py:163, 200-208)
+    sd_ref = W.expected_shapes(512)
+    sd = pipe.model.state_dict()
+    assert set(sd) <= set(sd_ref) and all(tuple(sd[k].shape) == tuple(sd_ref[k]) for k in sd) and len(sd) > 900
+    assert "quantizer._codebook.embed" in pipe.model.encoder.state_dict() and "joint_blocks.0.x_block.attn.qkv.weight" in pipe.model.model.state_dict()
+    assert pipe.model.eval() is pipe.model and pipe.model.set_eval() is pipe.model and pipe.vae.eval() is pipe.vae
+    assert pipe.vae.to("cuda") is pipe.vae and pipe.model.to(pipe.device) is pipe.model
+    assert sum(p.numel() for p in pipe.model.model.parameters()) > 2.0e9 and all(p.is_cuda for p in pipe.vae.parameters())
+    with pytest.raises(NotImplementedError):
+        pipe.model.train()
+    with pytest.raises(NotImplementedError):
+        pipe.vae.to("cpu")
     with pytest.raises(ValueError):
         from mimogpt.infer.SelftokPipeline import SelftokPipeline
         SelftokPipeline(default_config(512), None, None, model_type="sdxl", device="cuda")
