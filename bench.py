@@ -59,6 +59,7 @@ def parse(argv=None):
     ap.add_argument("--decoder", default="diffusion", choices=["diffusion", "renderer"])
     ap.add_argument("--decode-steps", type=int, default=None, help="debug only: truncate the 50-step loop (marks the line invalid)")
     ap.add_argument("--gemm", default=None, choices=["fp32", "f16x2"], help="arithmetic of the MMDiT block Linears of the headline number")
+    ap.add_argument("--vae", default=None, choices=["parity", "fast"], help="VAE arithmetic (vae.AutoencoderKLGPU); default parity")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-token-check", action="store_true")
     ap.add_argument("--no-kernel-roofs", action="store_true")
@@ -483,7 +484,7 @@ def main(argv=None):
     cfg = default_config(K, renderer=renderer)
     sd = W.synthetic_state_dict(W.expected_shapes(K, renderer=renderer), device=dev)
     vsd = W.synthetic_vae_state_dict(device=dev)
-    pipe = SelftokPipeline(cfg, None, None, device=dev, state_dict=sd, vae_state_dict=vsd, verbose=False, gemm=args.gemm)
+    pipe = SelftokPipeline(cfg, None, None, device=dev, state_dict=sd, vae_state_dict=vsd, verbose=False, gemm=args.gemm, vae_mode=args.vae)
     gemm_main = pipe.model.model.gemm
 
     images = synth.synthetic_images(B, device=dev, first_index=rank * B)          # resident in HBM
@@ -560,7 +561,7 @@ def main(argv=None):
         "config": {"workload": "BASELINE configs[%d]: batch %d x 256x256 per GPU, %d-token encode + %s decode"
                                % (3 if renderer else (2 if K == 1024 else 1), B, K, "one-step renderer" if renderer else "50-step diffusion"),
                    "global_batch": world * B, "tokens": K, "decode_steps": 1 if renderer else (args.decode_steps or 50),
-                   "gemm": gemm_main, "arithmetic": arith[gemm_main], "parallelism": "batch-shard x%d" % world,
+                   "gemm": gemm_main, "arithmetic": arith[gemm_main], "vae": pipe.vae.mode, "parallelism": "batch-shard x%d" % world,
                    "api": "pipe.encoding(images) -> id all-gather -> pipe.decoding(ids.cpu().numpy()) (noise from the CPU generator, as the reference)",
                    "weights": "hash-generated, architecture of tokenizer_512_ckpt"},
         "ranks": world, "backend": backend if world > 1 else None,

@@ -149,11 +149,14 @@ def _on_own_device(fn):
 class SelftokPipeline():
     def __init__(self, cfg, ckpt_path, sd3_path, datasize=256, start=1.0, cfg_scale=1, model_type='sd3',
                  dtype=torch.bfloat16, ema_decoder=False, device=None, state_dict: Optional[Dict[str, torch.Tensor]] = None,
-                 vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, verbose: bool = True, gemm: Optional[str] = None):
+                 vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, verbose: bool = True, gemm: Optional[str] = None,
+                 vae_mode: Optional[str] = None):
         """cfg: parse_args_from_yaml(...) ; ckpt_path: tokenizer .pth ; sd3_path: diffusers SD3 folder (…/vae/…).
         `state_dict` / `vae_state_dict` (extensions) bypass the files, e.g. with weights.synthetic_state_dict().
         `gemm` (extension): arithmetic of the MMDiT block Linears, 'fp32' (hipBLASLt fp32) or 'f16x2' (fp32-equivalent
-        split GEMM on the f16 matrix cores, csrc/gemm_split.hip); default from $SELFTOK_GEMM, else DEFAULT_GEMM."""
+        split GEMM on the f16 matrix cores, csrc/gemm_split.hip); default from $SELFTOK_GEMM, else DEFAULT_GEMM.
+        `vae_mode` (extension): 'parity' (default; bias inside the accumulation, deterministic GEMM algorithm) or 'fast'
+        (MIOpen's searched solvers, 1.8x faster convolutions, looser parity: see vae.AutoencoderKLGPU); default from $SELFTOK_VAE."""
         _lib.load()                                                           # fail loudly if the HIP library is missing
         if device is None:
             device = "cuda"
@@ -168,9 +171,9 @@ class SelftokPipeline():
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         with torch.cuda.device(self.device):                                  # our launches use the current device's stream
-            self._build(cfg, ckpt_path, sd3_path, start, cfg_scale, dtype, ema_decoder, state_dict, vae_state_dict, verbose, gemm)
+            self._build(cfg, ckpt_path, sd3_path, start, cfg_scale, dtype, ema_decoder, state_dict, vae_state_dict, verbose, gemm, vae_mode)
 
-    def _build(self, cfg, ckpt_path, sd3_path, start, cfg_scale, dtype, ema_decoder, state_dict, vae_state_dict, verbose, gemm):
+    def _build(self, cfg, ckpt_path, sd3_path, start, cfg_scale, dtype, ema_decoder, state_dict, vae_state_dict, verbose, gemm, vae_mode=None):
         p = cfg.tokenizer.params
         p.noise_schedule_config.is_eval = cfg.common.is_eval
         # configuration knobs the reference honours but this hot path does not implement: refuse, never ignore silently
@@ -191,7 +194,7 @@ class SelftokPipeline():
 
         vsd = vae_state_dict if vae_state_dict is not None else W.load_vae_checkpoint(sd3_path)
         W.check_vae_state_dict(vsd)
-        self.vae = AutoencoderKLGPU(vsd, self.device, dtype)
+        self.vae = AutoencoderKLGPU(vsd, self.device, dtype, mode=vae_mode or os.environ.get("SELFTOK_VAE") or "parity")
 
         self.verbose = verbose
         self._say("Loading all...")

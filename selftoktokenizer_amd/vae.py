@@ -62,12 +62,21 @@ class _Deterministic:
 
 class AutoencoderKLGPU(ModuleSurface):
     _sd_prefix = ""
-    def __init__(self, vsd: Dict[str, torch.Tensor], device, dtype=torch.bfloat16):
+    MODES = ("parity", "fast")
+
+    def __init__(self, vsd: Dict[str, torch.Tensor], device, dtype=torch.bfloat16, mode: str = "parity"):
+        """mode 'parity' (default): bias inside the accumulation + MIOpen's GEMM algorithm (module docstring).  mode 'fast': the
+        rounds 1-2 arithmetic -- `F.conv2d(x, w, b)` with whatever solver MIOpen's (non-benchmarking) search picks: 1.8x faster
+        convolutions, but 40 instead of 11 flipped tokens per 8192 and a 6e-3 instead of 3e-4 dB PSNR delta against the reference, and
+        latents that are not bit-stable from call to call.  For throughput runs that do not compare against the reference."""
         assert dtype == torch.bfloat16, "the HIP GroupNorm+SiLU epilogue is bf16 (the reference runs the VAE in bf16)"
+        if mode not in self.MODES:
+            raise ValueError(f"VAE mode {mode!r}: expected one of {self.MODES}")
+        self.mode = mode
         self.device, self.dtype = device, dtype
         # no benchmarking Find (see the module docstring); a value the caller exported wins.  MIOpen reads it when it first searches.
         os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
-        self.deterministic = True
+        self.deterministic = mode == "parity"
         self.w = {k: v.to(device=device, dtype=dtype).contiguous() for k, v in vsd.items()}
         # convolution weights with the bias folded in: [O, C + 8, kh, kw], bias in the centre tap of channel C
         self.wb = {}
@@ -97,6 +106,8 @@ class AutoencoderKLGPU(ModuleSurface):
 
     def _conv(self, name, x, stride=1, padding=1):
         """conv2d with the bias inside the fp32 accumulation (module docstring): one rounding to bf16, as the reference's CPU conv"""
+        if self.mode == "fast":
+            return F.conv2d(x, self.w[name + ".weight"], self.w[name + ".bias"], stride=stride, padding=padding)
         return F.conv2d(torch.cat((x, self._tail(x)), dim=1), self.wb[name], None, stride=stride, padding=padding)
 
     def _flags(self):

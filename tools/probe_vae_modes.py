@@ -28,6 +28,11 @@ MODES = {
     "bias fold + FAST find, solver free (non-deterministic flag off)": ({}, {"nondet": True}),
     "bias fold + MIOpen default find (DYNAMIC_HYBRID), solver free": ({"MIOPEN_FIND_MODE": "DYNAMIC_HYBRID"}, {"nondet": True}),
     "separate bias add (rounds 1-2) + deterministic + FAST find": ({}, {"sepbias": True}),
+    # which solver family is the inaccurate one?  (MIOPEN_DEBUG_CONV_* switch whole families off; the Find then picks among the rest)
+    "bias fold, solver free, Winograd off": ({"MIOPEN_DEBUG_CONV_WINOGRAD": "0"}, {"nondet": True}),
+    "bias fold, solver free, Winograd + direct off": ({"MIOPEN_DEBUG_CONV_WINOGRAD": "0", "MIOPEN_DEBUG_CONV_DIRECT": "0"}, {"nondet": True}),
+    "bias fold, solver free, only implicit GEMM": ({"MIOPEN_DEBUG_CONV_WINOGRAD": "0", "MIOPEN_DEBUG_CONV_DIRECT": "0", "MIOPEN_DEBUG_CONV_GEMM": "0", "MIOPEN_DEBUG_CONV_FFT": "0"}, {"nondet": True}),
+    "bias fold, default find (hybrid), Winograd off": ({"MIOPEN_FIND_MODE": "DYNAMIC_HYBRID", "MIOPEN_DEBUG_CONV_WINOGRAD": "0"}, {"nondet": True}),
 }
 
 
