@@ -45,6 +45,36 @@ class _Posterior:
         return self.moments[:, : self.moments.shape[1] // 2]
 
 
+def _bits_f32(u: int) -> float:
+    return float(torch.tensor(u if u < (1 << 31) else u - (1 << 32), dtype=torch.int32).view(torch.float32))
+
+
+_LOG2E, _LN_FLT_MIN, _LN_FLT_MAX = _bits_f32(0x3fb8aa3b), _bits_f32(0xc2aeac50), _bits_f32(0x42b17218)
+_FEXP_C = [float(torch.tensor(c, dtype=torch.float32)) for c in (0.00010703434948458272, 0.30354260500649682, -0.22433836478672356, -0.079204240219773236)]
+
+
+def fexp_u20(x: torch.Tensor) -> torch.Tensor:
+    """exp(x) exactly as torch's CPU flash-attention kernel evaluates it for bf16 / fp16 inputs: `Vectorized<float>::fexp_u20()`
+    (ATen/cpu/vec/vec512/vec512_float.h in the torch 2.10 wheel; Malossi et al., "Fast Exponential Computation on SIMD Architectures"):
+    2^(x log2 e) with the fractional part corrected by a degree-3 polynomial and the result assembled in the exponent / mantissa bits
+    by a float -> int truncation -- relative error up to 1.05e-4.  The reference's CPU run computes the un-normalised softmax
+    probabilities of the VAE's attention block with it, and at bf16 output resolution that error decides 15 % of the block's output
+    roundings: with the accurate exp the block agrees with the CPU in 83 % of its elements, with this one in 99.6 % (measured on
+    the CPU itself).  fp32 multiply / subtract as the AVX-512 code does them; its FMAs are reproduced through fp64 (a 24 x 24-bit
+    product is exact there, the sum is rounded to fp32 once)."""
+    src = x * _LOG2E
+    frac = src - torch.floor(src)
+    fd = frac.double()
+    res = (fd * _FEXP_C[3] + _FEXP_C[2]).float()
+    res = (fd * res.double() + _FEXP_C[1]).float()
+    res = (fd * res.double() + _FEXP_C[0]).float()
+    src = src - res
+    ci = (src.double() * float(2 ** 23) + float(2 ** 23) * 127.0).float().to(torch.int32)        # cvttps: truncation
+    ci = torch.where(x < _LN_FLT_MIN, torch.zeros_like(ci), ci)
+    ci = torch.where(x > _LN_FLT_MAX, torch.full_like(ci, 0x7F800000), ci)
+    return ci.view(torch.float32)
+
+
 class _Deterministic:
     """torch.backends.cudnn.deterministic (= MIOpen's GEMM algorithm on ROCm) for the duration of a VAE call, then restored"""
 
@@ -136,16 +166,17 @@ class AutoencoderKLGPU(ModuleSurface):
             return torch.baddbmm(self.w[name + ".bias"].to(f), t, self.w[name + ".weight"].to(f).t().expand(B, -1, -1)).to(self.dtype)
         q, k, v = lin(p + ".to_q", h).to(f), lin(p + ".to_k", h).to(f), lin(p + ".to_v", h).to(f)
         # online softmax over key blocks of 512, the way torch's CPU flash kernel walks them (ATen FlashAttentionKernel.cpp,
-        # kvSplitSize = 512): the un-normalised probabilities are rounded to bf16 relative to the RUNNING maximum of their block, the
-        # row sums come from the fp32 values, the accumulator is rescaled by exp(old max - new max) -- same rounding points, so the
-        # result agrees with the reference's CPU run except at rounding ties
+        # kvSplitSize = 512): the un-normalised probabilities -- from the kernel's own fast exp, fexp_u20 -- are rounded to bf16
+        # relative to the RUNNING maximum of their block, the row sums come from the fp32 values, the accumulator is rescaled by
+        # exp(old max - new max) (accurate exp), the output is dst * (1 / sum): same rounding points, so the result agrees with the
+        # reference's CPU run except at rounding ties of the two GEMMs' fp32 sums (99.6 % of the elements, measured on the CPU)
         T, scale, KV = H * W, C ** -0.5, 512
         m = l = acc = None
         for n0 in range(0, T, KV):
             sc = torch.bmm(q, k[:, n0:n0 + KV].transpose(1, 2)) * scale
             bm = sc.amax(dim=-1, keepdim=True)
             m_new = bm if m is None else torch.maximum(m, bm)
-            pr = torch.exp(sc - m_new)
+            pr = fexp_u20(sc - m_new)                          # the CPU kernel's fast exp for reduced types, see fexp_u20
             ps = pr.sum(dim=-1, keepdim=True)
             pv = torch.bmm(pr.to(self.dtype).to(f), v[:, n0:n0 + KV])
             if m is None:
@@ -154,7 +185,7 @@ class AutoencoderKLGPU(ModuleSurface):
                 al = torch.exp(m - m_new)
                 l, acc = ps + al * l, acc * al + pv
             m = m_new
-        a = (acc / l).to(self.dtype)
+        a = (acc * (1.0 / l)).to(self.dtype)                 # dst * sum_reciprocal, as the CPU kernel
         a = lin(p + ".to_out.0", a.to(f))
         return x + a.transpose(1, 2).reshape(B, C, H, W)
 
