@@ -95,11 +95,23 @@ def test_encoder_oracle_matches_reference():
 
 
 def test_vae_oracle_close_to_mirror():
-    """bf16: not bit-reproducible between formulations (conv1x1 vs linear attention), compare at bf16 resolution"""
+    """the VAE restatement against the reference's in-repo mirror (vae_b1.npz): bit-identical on the CPU that generated the golden
+    since the attention projections are applied as 1x1 convolutions like the mirror's (round 3; PINNING.json: vae maxdiff 0.0);
+    diffusers' own Linear formulation (the arithmetic of record, unpinned) differs at bf16 resolution and stays within an ulp or two"""
     g = gold("vae_b1.npz")
     vsd = W.synthetic_vae_state_dict()
-    mean = OM.vae_encode_mean(vsd, synth.synthetic_images(1).to(torch.bfloat16)).float()
-    assert float((mean - torch.from_numpy(g["mean"])).abs().max()) < 0.05
+    img = synth.synthetic_images(1).to(torch.bfloat16)
+    mean = OM.vae_encode_mean(vsd, img).float()
+    assert float((mean - torch.from_numpy(g["mean"])).abs().max()) == 0.0
+    rec = OM.vae_decode(vsd, synth.synthetic_latents(1).to(torch.bfloat16)).float()
+    assert float((rec - torch.from_numpy(g["rec"])).abs().max()) == 0.0
+    OM.VAE_ATTN_PROJ = "linear"
+    try:
+        mean_l = OM.vae_encode_mean(vsd, img).float()
+    finally:
+        OM.VAE_ATTN_PROJ = "conv"
+    d = float((mean_l - mean).abs().max())
+    assert 0.0 < d < 0.05
     # process_in / process_out / norm_ip dtype hand-offs
     z = OM.process_in(mean.to(torch.bfloat16))
     assert z.dtype == torch.bfloat16

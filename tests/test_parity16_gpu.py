@@ -7,8 +7,9 @@ Where the numbers come from: the tokenizer / DiT path is fp32 and agrees with th
 bf16 SD3-VAE is the one stage whose arithmetic no two implementations share bit for bit (the reference's CPU convolutions, the
 oracle's CPU convolutions with Linear attention, MIOpen's GPU kernels): its latents differ by +-1 bf16 ulp (0.0156 .. 0.031 at
 |x| = 2 .. 4) on a fraction of the elements.  That perturbation, pushed through the encoder, moves a unit feature by |dz|; a
-token can flip only if its reference gap is below |dz| * |e_ref - e_new|.  The CPU oracle's own spread against the reference on
-the same images is stored in the golden file and printed next to the GPU's."""
+token can flip only if its reference gap is below |dz| * |e_ref - e_new|.  The yardstick stored in the golden file and printed next
+to the GPU's numbers is a SECOND CPU implementation of the same VAE -- oracle/ with the attention projections in diffusers' own
+Linear formulation (the oracle's default, 1x1 convolutions like the mirror, is bit-identical to the reference and would read 0)."""
 import os
 
 import numpy as np
@@ -57,12 +58,12 @@ def test_ids_16_images_vs_reference(pipe):
     mo = g["tokens_oracle"].astype(np.int64) != ref
     edges = [0, 1e-6, 3e-6, 1e-5, 3e-5, 1e-4, 3e-4, 1e-3, 1e-2, 1.0]
     print(f"\ne2e ids vs the reference pipeline, {B} images: match {1 - mism.mean():.6f} ({nflip} flips of {mism.size}); "
-          f"CPU oracle vs reference on the same images: {1 - mo.mean():.6f} ({int(mo.sum())} flips)")
+          f"second CPU implementation (Linear attention projections) vs reference on the same images: {1 - mo.mean():.6f} ({int(mo.sum())} flips)")
     print("reference gap (top1 - top2) of the flipped tokens:", np.sort(gaps))
     print("  histogram of flip gaps      :", _hist(gaps, edges))
     print("  histogram of ALL token gaps :", _hist(g["gap"].reshape(-1), edges))
     print(f"VAE latent delta vs reference: max {float(dx.abs().max()):.4f} rms {float(dx.pow(2).mean().sqrt()):.5f} "
-          f"(bf16 ulp at |x| in [2,4) = 0.0156; oracle vs reference rms {float((torch.from_numpy(g['x0_oracle_bf16']).view(torch.bfloat16).float() - torch.from_numpy(g['x0_bf16']).view(torch.bfloat16).float()).pow(2).mean().sqrt()):.5f})")
+          f"(bf16 ulp at |x| in [2,4) = 0.0156; second CPU implementation vs reference rms {float((torch.from_numpy(g['x0_oracle_bf16']).view(torch.bfloat16).float() - torch.from_numpy(g['x0_bf16']).view(torch.bfloat16).float()).pow(2).mean().sqrt()):.5f})")
     print(f"unit-feature delta |dz| per token: median {np.median(dz):.2e} p99 {np.quantile(dz, 0.99):.2e} max {dz.max():.2e}")
     print(f"tokens whose reference gap is below 2 |dz| (could flip under this noise): {int((g['gap'] < 2 * dz).sum())}; flipped: {nflip}")
     # (1) every flip is explained by the measured upstream perturbation: for unit codes the score difference between the reference's
@@ -78,7 +79,7 @@ def test_ids_16_images_vs_reference(pipe):
     assert bound < 5e-3, bound
     assert nflip == 0 or float(gaps.max()) < bound
     assert nflip == 0 or float(gaps.max()) < 1e-3          # measured: largest flip gap 2.6e-4
-    # (3) the count stays within a small multiple of the CPU-vs-CPU spread on the same images (oracle: 7 flips; measured here: 11;
+    # (3) the count stays within a small multiple of the CPU-vs-CPU spread on the same images (second CPU implementation: 7 flips; measured here: 10-14;
     #     rounds 1-2: 40)
     assert nflip <= 24, nflip
     # most flips land on the reference's runner-up code
@@ -115,13 +116,13 @@ def test_psnr_16_images_vs_reference(pipe, gemm):
     print(f"[{gemm}] reconstruction PSNR vs original, |ours - reference| over {B} images (reference mean {g['psnr_ref'].mean():.4f} dB):")
     print(f"   end to end (our latents, our MIOpen bf16 decoder)   : mean {d_e2e.mean():.2e} max {d_e2e.max():.2e} dB   each {np.round(d_e2e, 5)}")
     print(f"   same decoder (reference latents vs ours, one call)  : mean {d_same.mean():.2e} max {d_same.max():.2e} dB")
-    print(f"   CPU oracle's bf16 decoder on the reference's latents: mean {d_or.mean():.2e} max {d_or.max():.2e} dB   each {np.round(d_or, 5)}")
+    print(f"   second CPU implementation's decoder on the reference's latents: mean {d_or.mean():.2e} max {d_or.max():.2e} dB   each {np.round(d_or, 5)}")
     print(f"   floor: reference latents vs themselves * (1 + 2^-22), same decoder call: mean {d_floor.mean():.2e} max {d_floor.max():.2e} dB")
     assert lat_err < 2e-5                                        # measured 2.9e-6 in both arithmetics
     # the north star's 1e-3 dB where only OUR path differs: met on average with a wide margin; the maximum over 16 images sits at the
     # metric's own floor (see d_floor: latents that differ by 3e-6 already reach ~1e-3 dB on single images)
     assert d_same.mean() < 5e-4 and d_same.max() < 2e-3, (d_same.mean(), d_same.max())
     # end to end the delta is the bf16 decoder's implementation noise: it stays inside the spread between two CPU implementations of
-    # the same decoder on the same latents (oracle vs reference: mean 3.9e-4, max 1.09e-3 dB; measured here: mean 2.9e-4, max 8.8e-4;
+    # the same decoder on the same latents (second CPU implementation vs reference: mean 3.9e-4, max 1.09e-3 dB; measured here: mean 2.9e-4, max 8.8e-4;
     # rounds 1-2, separate bias add + solver search: mean 6.1e-3)
     assert d_e2e.mean() < 1e-3 and d_e2e.mean() <= 1.5 * d_or.mean() and d_e2e.max() <= 2.0 * d_or.max(), (d_e2e.mean(), d_e2e.max(), d_or.mean(), d_or.max())

@@ -300,9 +300,11 @@ def stage_pipeline16(B=16):
     CHARACTERISE the end-to-end parity through the bf16 VAE over more than one image:
       reference side : VAE latents x0 (bf16-exact), pre-quantizer features z, token ids, top-1/top-2 gap and runner-up id of
                        every token, the final latent of the 50-step loop, reconstruction PSNR vs the original per image;
-      oracle side    : the same images through oracle/ on this CPU (ids, and its VAE decode of the reference's final latents ->
-                       PSNR) = the spread between two CPU implementations of the same bf16 VAE (ldm-style mirror with 1x1-conv
-                       attention vs the diffusers layout with Linear attention) that the GPU's deviation is judged against."""
+      second CPU implementation ("*_oracle" keys): the same images through oracle/ on this CPU with the VAE attention projections in
+                       diffusers' own formulation (F.linear; OM.VAE_ATTN_PROJ = "linear") -- ids, and its VAE decode of the reference's
+                       final latents -> PSNR = the spread between two CPU implementations of the same bf16 VAE (ldm-style mirror with
+                       1x1-conv attention vs the diffusers layout) that the GPU's deviation is judged against.  The oracle's DEFAULT
+                       formulation (1x1 convolutions, like the mirror) is bit-identical to the reference: asserted below."""
     H.install()
     import mimogpt.infer.SelftokPipeline as SP
     cfg = H.load_cfg(CFG_256)
@@ -334,14 +336,21 @@ def stage_pipeline16(B=16):
     id2 = top2.indices[:, 1].reshape(B, 512)
     assert bool((top2.indices[:, 0].reshape(B, 512) == tokens).float().mean() > 0.999)
     t0 = time.time()
-    tok_o = OM.pipeline_encode(sd, vsd, images)
-    x0_o = OM.process_in(OM.vae_encode_mean(vsd, images.to(torch.bfloat16))).to(torch.float32)
+    assert torch.equal(OM.process_in(OM.vae_encode_mean(vsd, images.to(torch.bfloat16))).to(torch.float32), x0), "default oracle VAE != mirror"
+    assert torch.equal(OM.pipeline_encode(sd, vsd, images), tokens), "default oracle ids != reference"
+    OM.VAE_ATTN_PROJ = "linear"
+    try:
+        tok_o = OM.pipeline_encode(sd, vsd, images)
+        x0_o = OM.process_in(OM.vae_encode_mean(vsd, images.to(torch.bfloat16))).to(torch.float32)
+    finally:
+        OM.VAE_ATTN_PROJ = "conv"
     z_o = OM.encoder_features(sd, x0_o)
     print(f"[oracle] encoding B={B} {time.time() - t0:.1f}s", flush=True)
     mism_o = (tok_o != tokens)
-    report("pipeline16_encode", images=B, oracle_ids_match=float((~mism_o).float().mean()), oracle_flips=int(mism_o.sum()),
-           oracle_flip_gaps=[round(float(v), 8) for v in gap[mism_o]], x0_maxdiff_oracle_vs_ref=maxdiff(x0_o, x0),
-           x0_rms_oracle_vs_ref=float((x0_o - x0).pow(2).mean().sqrt()), z_maxdiff_oracle_vs_ref=maxdiff(z_o, z))
+    report("pipeline16_encode", images=B, oracle_default_equals_reference=True,
+           linear_variant_ids_match=float((~mism_o).float().mean()), linear_variant_flips=int(mism_o.sum()),
+           linear_variant_flip_gaps=[round(float(v), 8) for v in gap[mism_o]], x0_maxdiff_linear_variant_vs_ref=maxdiff(x0_o, x0),
+           x0_rms_linear_variant_vs_ref=float((x0_o - x0).pow(2).mean().sqrt()), z_maxdiff_linear_variant_vs_ref=maxdiff(z_o, z))
     # ---- 50-step decode of the reference (hash noise instead of torch.randn) ----
     noise = synth.synthetic_noise(B)
     real_randn = torch.randn
@@ -375,12 +384,17 @@ def stage_pipeline16(B=16):
     trace = []
     OM.decode_latent(sd, tokens, noise, stg, kps, 50, trace=trace, max_steps=2)
     d2 = max(maxdiff(trace[0], xs[1]), maxdiff(trace[1], xs[2]))
-    rec_o = OM.norm_ip(OM.vae_decode(vsd, OM.process_out(lat).to(torch.bfloat16)))
+    assert torch.equal(OM.norm_ip(OM.vae_decode(vsd, OM.process_out(lat).to(torch.bfloat16))), rec), "default oracle decoder != mirror"
+    OM.VAE_ATTN_PROJ = "linear"
+    try:
+        rec_o = OM.norm_ip(OM.vae_decode(vsd, OM.process_out(lat).to(torch.bfloat16)))
+    finally:
+        OM.VAE_ATTN_PROJ = "conv"
     p_or = psnr_each(rec_o)
     d = np.abs(p_or - p_ref)
-    report("pipeline16_decode", images=B, oracle_latents_first2steps_maxdiff=d2, psnr_ref_mean=float(p_ref.mean()),
-           psnr_delta_oracle_vs_ref_mean=float(d.mean()), psnr_delta_oracle_vs_ref_max=float(d.max()),
-           psnr_delta_oracle_vs_ref_each=[round(float(v), 6) for v in d])
+    report("pipeline16_decode", images=B, oracle_latents_first2steps_maxdiff=d2, oracle_default_decoder_equals_reference=True,
+           psnr_ref_mean=float(p_ref.mean()), psnr_delta_linear_variant_vs_ref_mean=float(d.mean()),
+           psnr_delta_linear_variant_vs_ref_max=float(d.max()), psnr_delta_linear_variant_vs_ref_each=[round(float(v), 6) for v in d])
     np.savez_compressed(os.path.join(GOLD, "pipeline_b16.npz"), tokens=tokens.numpy().astype(np.int16), id2=id2.numpy().astype(np.int16),
                         gap=gap.numpy(), x0_bf16=x0.to(torch.bfloat16).view(torch.int16).numpy(), z=z.numpy(), lat=lat.numpy(),
                         psnr_ref=p_ref, psnr_oracle=p_or, tokens_oracle=tok_o.numpy().astype(np.int16),
