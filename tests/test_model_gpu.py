@@ -154,18 +154,29 @@ def test_renderer_vs_reference():
 
 
 def test_vae_vs_mirror():
-    """bf16 VAE: the reference arithmetic of record (diffusers) is unavailable; golden = in-repo mirror on CPU.
-    bf16 convolutions are not bit-reproducible across libraries, so compare at bf16 resolution."""
+    """bf16 VAE against the reference's in-repo mirror run on the CPU (vae_b1.npz; the arithmetic of record, diffusers, is unavailable).
+    A bf16 network is chaotic at the ulp level: fp32 summation-order differences flip 0.05 % of a convolution's
+    output roundings and compound to ~85 % of the latent elements one ulp off at the end -- so the comparison is statistical: the rms
+    deviation must stay below one bf16 ulp of the typical magnitude, the maximum within a few ulps, and the parity mode must beat the
+    rounds 1-2 arithmetic (`mode='fast'`: separate bf16 bias add, searched MIOpen solvers) on both."""
     g = gold("vae_b1.npz")
     from selftoktokenizer_amd.vae import AutoencoderKLGPU
-    vae = AutoencoderKLGPU(W.synthetic_vae_state_dict(), torch.device("cuda"))
     img = synth.synthetic_images(1).to(torch.bfloat16)
-    mean = vae.encode(img.cuda())[0].mode().float().cpu()
-    ref = torch.from_numpy(g["mean"])
-    e1 = float((mean - ref).abs().max())
-    rec = vae.decode(synth.synthetic_latents(1).to(torch.bfloat16).cuda())[0].float().cpu()
-    ref2 = torch.from_numpy(g["rec"])
-    e2 = float((rec - ref2).abs().max())
-    mse = float(((rec - ref2) ** 2).mean())
-    print("vae enc err", e1, "dec err", e2, "dec psnr vs mirror (range 2)", 10 * np.log10(4.0 / mse))
-    assert e1 < 0.05 * float(ref.abs().max()) and e2 < 0.05 * float(ref2.abs().max())
+    lat = synth.synthetic_latents(1).to(torch.bfloat16)
+    ref, ref2 = torch.from_numpy(g["mean"]), torch.from_numpy(g["rec"])
+    res = {}
+    for mode in ("parity", "fast"):
+        vae = AutoencoderKLGPU(W.synthetic_vae_state_dict(), torch.device("cuda"), mode=mode)
+        mean = vae.encode(img.cuda())[0].mode().float().cpu()
+        rec = vae.decode(lat.cuda())[0].float().cpu()
+        d1, d2 = mean - ref, rec - ref2
+        res[mode] = (float(d1.abs().max()), float(d1.pow(2).mean().sqrt()), float(d2.abs().max()), float(d2.pow(2).mean().sqrt()))
+        print(f"vae [{mode}] vs mirror: encoder mean max {res[mode][0]:.4f} rms {res[mode][1]:.5f} (|mean| max {float(ref.abs().max()):.2f}); "
+              f"decoder max {res[mode][2]:.4f} rms {res[mode][3]:.5f} (|rec| max {float(ref2.abs().max()):.2f}), "
+              f"decoder PSNR vs mirror (range 2) {10 * np.log10(4.0 / max(res[mode][3] ** 2, 1e-12)):.2f} dB")
+        if mode == "parity":       # bit-stable: a second call returns the same bits
+            assert torch.equal(vae.encode(img.cuda())[0].mode().float().cpu(), mean)
+    e1, r1, e2, r2 = res["parity"]
+    assert e1 <= 0.0313 and r1 < 0.0078            # encoder: <= 2 ulps at |x| in [2, 4) anywhere, rms below one ulp at |x| ~ 1
+    assert e2 <= 0.0625 and r2 < 0.0117            # decoder output (|rec| up to 3.3: 4 ulps anywhere, rms below 3/4 ulp at |x| in [2, 4))
+    assert r1 < res["fast"][1] and r2 < res["fast"][3]
