@@ -1,0 +1,667 @@
+/* libselftok_cpu.so -- the C ABI of include/selftok_hip.h compiled for the CPU ("same symbols compiled for CPU =
+ * the CPU restatement").  TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+ * (selftoktokenizer_amd/, mimogpt/) never does and has no CPU fallback.
+ *
+ * Every entry point takes HOST pointers, ignores `stream`, and computes what the gfx950 kernel of the same name computes
+ * (the .hip files under selftoktokenizer_amd/csrc, each of which cites the reference call site it replaces):
+ *   - bit for bit where the GPU arithmetic is order-defined on both sides: the VQ nearest-code lookup (canonical l2norm, k-ordered FMA
+ *     chain, first maximum, NaN-as-maximum: vector_quantize_pytorch.py:854,561,125-143), code gather + LayerNorm16, the fused
+ *     residual / LayerNorm / modulate pass INCLUDING its wave-shuffle reduction order, the split-activation producers, latent format
+ *     in/out, norm_ip, patchify, unpatchify + CFG + Euler, add_rows, RMSNorm's sum order;
+ *   - to fp32 rounding where the GPU uses hardware transcendentals or matrix-core summation orders (v_exp_f32, v_rsq_f32, MFMA
+ *     accumulation): attention, the f16x2-split Linear (same three-term arithmetic a0 w0 + 2^-11 (a0 w1 + a1 w0), k-ordered fp32
+ *     accumulation), GELU, SiLU, sin/cos tables, GroupNorm statistics.
+ * Opaque buffers (the packed code book, the packed f16x2 weight, the VQ workspace) have the GPU library's SIZES; the packed code book and
+ * the split-activation layout are also the GPU's byte for byte (interchangeable), the packed weight image is the GPU's tile order.
+ *
+ * Build: gcc -O2 -fopenmp -ffp-contract=off -shared -fPIC -I../include selftok_cpu.c -o libselftok_cpu.so -lm   (oracle/Makefile)
+ */
+#include "selftok_hip.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static _Thread_local char g_err[256] = "";
+static int fail(const char* m) { strncpy(g_err, m, sizeof(g_err) - 1); return SELFTOK_EINVAL; }
+const char* selftok_last_error(void) { return g_err; }
+int selftok_version(void) { return 100; }
+
+/* ---- scalar helpers ----------------------------------------------------------------------------------------------------------- */
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t orderable(float f) { uint32_t u = f2u(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+static inline float from_orderable(uint32_t k) { return u2f((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+#define KEY_NAN 0xFFFFFFFFu
+
+/* IEEE binary16 <-> binary32, round to nearest even (what v_cvt_f16_f32 / v_cvt_pk_f16_f32 do) */
+static inline uint16_t f32_to_f16(float f)
+{
+    uint32_t x = f2u(f), sign = (x >> 16) & 0x8000u, ax = x & 0x7FFFFFFFu;
+    if (ax >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((ax > 0x7F800000u) ? 0x200u | ((ax >> 13) & 0x3FFu) : 0));   /* inf / NaN */
+    if (ax >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                       /* rounds to >= 65520 -> inf */
+    if (ax < 0x38800000u) {                                                         /* subnormal half or zero */
+        if (ax < 0x33000000u) return (uint16_t)sign;                                /* < 2^-25 -> 0 */
+        uint32_t e = ax >> 23, m = (ax & 0x7FFFFFu) | 0x800000u;
+        int shift = 126 - (int)e;                                                   /* 14 .. 24 */
+        uint32_t r = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1))) r++;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ax - 0x38000000u, rem = r & 0x1FFFu;                               /* rebias exponent 127 -> 15 */
+    r >>= 13;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) r++;
+    return (uint16_t)(sign | r);
+}
+static inline float f16_to_f32(uint16_t h)
+{
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1F, m = h & 0x3FFu;
+    if (e == 0) {
+        if (m == 0) return u2f(sign);
+        float v = (float)m * 5.9604644775390625e-08f;                               /* m * 2^-24 */
+        return (sign ? -v : v);
+    }
+    if (e == 31) return u2f(sign | 0x7F800000u | (m << 13));
+    return u2f(sign | ((e + 112) << 23) | (m << 13));
+}
+static inline float bf2f(uint16_t u) { return u2f(((uint32_t)u) << 16); }
+static inline uint16_t f2bf(float f)
+{
+    uint32_t u = f2u(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float rbf(float f) { return bf2f(f2bf(f)); }
+
+/* ================================================================================================================================
+ * VQ nearest-code lookup (csrc/vq.hip)
+ * ============================================================================================================================== */
+#define VD 16
+static void l2norm16(const float* z, float* x)
+{
+    float a[8], s;
+    for (int j = 0; j < 8; ++j) a[j] = fmaf(z[j + 8], z[j + 8], z[j] * z[j]);
+    s = a[0];
+    for (int j = 1; j < 8; ++j) s = s + a[j];
+    float nrm = sqrtf(s);
+    nrm = (nrm > 1e-12f) ? nrm : 1e-12f;
+    if (s != s) nrm = s;
+    for (int k = 0; k < VD; ++k) x[k] = z[k] / nrm;
+}
+static inline int packed_offset(int i, int k) { const int m = k >> 1, lane = (k & 1) * 32 + i; return (m >> 2) * 256 + lane * 4 + (m & 3); }
+
+/* code c of a raw [C,16] book or of the fragment-ordered packed image */
+static inline void load_code(const float* book, int packed, int c, float* e)
+{
+    if (!packed) { memcpy(e, book + (size_t)c * VD, VD * sizeof(float)); return; }
+    const float* t = book + (size_t)(c >> 5) * 512;
+    for (int k = 0; k < VD; ++k) e[k] = t[packed_offset(c & 31, k)];
+}
+static void vq_rows(const float* z, const float* book, int packed, void* ids, float* best, int N, int C, int flags)
+{
+    const int norm = (flags & SELFTOK_PRENORMED) ? 0 : 1;
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < N; ++r) {
+        float x[VD], e[VD];
+        if (norm) l2norm16(z + (size_t)r * VD, x); else memcpy(x, z + (size_t)r * VD, sizeof(x));
+        float bv = -INFINITY; int bi = 0, nan = 0;
+        for (int c = 0; c < C && !nan; ++c) {
+            load_code(book, packed, c, e);
+            float s = 0.f;
+            for (int k = 0; k < VD; ++k) s = fmaf(x[k], e[k], s);
+            if (s != s) { nan = 1; bi = c; }
+            else if (s > bv) { bv = s; bi = c; }
+        }
+        if (flags & SELFTOK_IDS_I32) ((int32_t*)ids)[r] = bi; else ((long long*)ids)[r] = bi;
+        if (best) best[r] = nan ? u2f(0x7FC00000u) : bv;
+    }
+}
+size_t selftok_vq_workspace_bytes(int N, int C) { (void)C; return (size_t)128 * (size_t)(N > 0 ? N : 1) * sizeof(unsigned long long); }
+size_t selftok_vq_packed_bytes(int C, int D) { return ((size_t)C * D + 64) * sizeof(float) + (size_t)C * D * 2 * sizeof(uint16_t); }
+int selftok_vq_encode_f32(const float* z, const float* codebook, void* ids, float* best, void* workspace, int N, int C, int D, int flags, hipStream_t s)
+{
+    (void)s; (void)workspace;
+    if (N == 0 && D == VD && C > 0) return SELFTOK_OK;
+    if (D != VD || C <= 0 || N < 0 || !z || !codebook || !ids) return fail("vq_encode: bad argument");
+    vq_rows(z, codebook, 0, ids, best, N, C, flags);
+    return SELFTOK_OK;
+}
+int selftok_vq_pack_codebook(const float* cb, float* packed, int C, int D, hipStream_t s)
+{
+    (void)s;
+    if (!cb || !packed || D != VD || C <= 0 || (C & 31)) return fail("vq_pack: need D==16 and C%32==0");
+    uint32_t flag = 0;
+    uint16_t* p16 = (uint16_t*)(packed + (size_t)C * VD + 64);
+    memset(packed + (size_t)C * VD, 0, 64 * sizeof(float));
+    for (int c = 0; c < C; ++c) {
+        const int t = c >> 5, i = c & 31;
+        float n2 = 0.f;
+        for (int k = 0; k < VD; ++k) {
+            const float v = cb[(size_t)c * VD + k];
+            packed[(size_t)t * 512 + packed_offset(i, k)] = v;
+            const float vs = v * 128.0f;
+            const uint16_t hi = f32_to_f16(vs);
+            uint16_t* tile = p16 + (size_t)t * 1024;
+            tile[((k >> 3) * 32 + i) * 8 + (k & 7)] = hi;
+            tile[512 + ((k >> 3) * 32 + i) * 8 + (k & 7)] = f32_to_f16(vs - f16_to_f32(hi));
+            if (!(fabsf(v) < 1.0e18f)) flag |= 1u;
+            if (!(fabsf(vs) < 60000.f)) flag |= 2u;
+            n2 = fmaf(v, v, n2);
+        }
+        if (!(n2 <= 1.01f)) flag |= 4u;
+    }
+    memcpy(packed + (size_t)C * VD, &flag, 4);
+    return SELFTOK_OK;
+}
+int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, void* workspace, int* nsplit_out, int N, int C, int D, int flags, hipStream_t s)
+{
+    (void)s;
+    if (nsplit_out) *nsplit_out = 0;
+    if (N == 0 && D == VD && C > 0 && !(C & 31) && nsplit_out) return SELFTOK_OK;
+    if (D != VD || C <= 0 || (C & 31) || N < 0 || !z || !packed || !workspace || !nsplit_out) return fail("vq_argmax_partial_packed: bad argument");
+    /* one exact candidate per row: (orderable(best) << 32) | ~idx -- the workspace format is private to the library */
+    long long* idx = (long long*)malloc((size_t)(N > 0 ? N : 1) * sizeof(long long));
+    float* bst = (float*)malloc((size_t)(N > 0 ? N : 1) * sizeof(float));
+    if (!idx || !bst) { free(idx); free(bst); return fail("out of memory"); }
+    vq_rows(z, packed, 1, idx, bst, N, C, flags & ~SELFTOK_IDS_I32);
+    unsigned long long* ws = (unsigned long long*)workspace;
+    for (int r = 0; r < N; ++r) {
+        float v = bst[r]; if (v == 0.0f) v = 0.0f;
+        uint32_t hi = (v != v) ? KEY_NAN : orderable(v);
+        ws[r] = ((unsigned long long)hi << 32) | (uint32_t)(~(uint32_t)idx[r]);
+    }
+    free(idx); free(bst);
+    *nsplit_out = 1;
+    return SELFTOK_OK;
+}
+int selftok_vq_finalize_packed(const void* workspace, const float* z, const float* packed, void* ids, float* best, int N, int C, int D, int nsplit, int flags, hipStream_t s)
+{
+    (void)s; (void)z; (void)packed;
+    if (N == 0) return SELFTOK_OK;
+    if (!workspace || !ids || N < 0 || nsplit <= 0 || D != VD || (C & 31)) return fail("vq_finalize_packed: bad argument");
+    const unsigned long long* ws = (const unsigned long long*)workspace;
+    for (int r = 0; r < N; ++r) {
+        const uint32_t hi = (uint32_t)(ws[r] >> 32), id = ~(uint32_t)ws[r];
+        if (flags & SELFTOK_IDS_I32) ((int32_t*)ids)[r] = (int32_t)id; else ((long long*)ids)[r] = id;
+        if (best) best[r] = (hi == KEY_NAN) ? u2f(0x7FC00000u) : from_orderable(hi);
+    }
+    return SELFTOK_OK;
+}
+int selftok_vq_encode_packed_f32(const float* z, const float* packed, void* ids, float* best, void* workspace, int N, int C, int D, int flags, hipStream_t s)
+{
+    if (!ids && N != 0) return fail("vq_encode_packed: bad argument");
+    int split = 0;
+    int rc = selftok_vq_argmax_partial_packed_f32(z, packed, workspace, &split, N, C, D, flags, s);
+    if (rc || N == 0) return rc;
+    return selftok_vq_finalize_packed(workspace, z, packed, ids, best, N, C, D, split, flags, s);
+}
+int selftok_code_gather_ln_f32(const void* ids, const float* cb, const float* ln_w, const float* ln_b, float* out, int n, int C, int D, float eps, int flags, hipStream_t s)
+{
+    (void)s;
+    if (n == 0) return SELFTOK_OK;
+    if (D != VD || n < 0 || !ids || !cb || !out || ((ln_w == NULL) != (ln_b == NULL))) return fail("code_gather_ln: bad argument");
+    for (int r = 0; r < n; ++r) {
+        long long id = (flags & SELFTOK_IDS_I32) ? ((const int32_t*)ids)[r] : ((const long long*)ids)[r];
+        if (id < 0) id += C;
+        id = id < 0 ? 0 : (id >= C ? C - 1 : id);
+        float v[VD];
+        memcpy(v, cb + (size_t)id * VD, sizeof(v));
+        if (ln_w) {
+            float mean = 0.f, var = 0.f;
+            for (int k = 0; k < VD; ++k) mean += v[k];
+            mean *= (1.0f / VD);
+            for (int k = 0; k < VD; ++k) { float d = v[k] - mean; var = fmaf(d, d, var); }
+            var *= (1.0f / VD);
+            const float rstd = 1.0f / sqrtf(var + eps);
+            for (int k = 0; k < VD; ++k) v[k] = (v[k] - mean) * rstd * ln_w[k] + ln_b[k];
+        }
+        memcpy(out + (size_t)r * VD, v, sizeof(v));
+    }
+    return SELFTOK_OK;
+}
+int selftok_vq_ema_accumulate_f32(const float* z, const void* ids, float* bins, float* esum, int N, int C, int D, int flags, hipStream_t s)
+{
+    (void)s;
+    if (N == 0) return SELFTOK_OK;
+    if (D != VD || N < 0 || C <= 0 || !z || !ids || !bins || !esum) return fail("vq_ema_accumulate: bad argument");
+    for (int r = 0; r < N; ++r) {
+        long id = (flags & SELFTOK_IDS_I32) ? ((const int32_t*)ids)[r] : (long)((const long long*)ids)[r];
+        if (id < 0 || id >= C) continue;
+        float x[VD];
+        if (flags & SELFTOK_PRENORMED) memcpy(x, z + (size_t)r * VD, sizeof(x)); else l2norm16(z + (size_t)r * VD, x);
+        for (int k = 0; k < VD; ++k) esum[(size_t)id * VD + k] += x[k];
+        bins[id] += 1.0f;
+    }
+    return SELFTOK_OK;
+}
+int selftok_vq_tpc_update_f32(float* tpc, const void* ids, int B, int K, int C, float w, int flags, hipStream_t s)
+{
+    (void)s;
+    if (!tpc || K <= 0 || C <= 0 || (C & 3) || B < 0 || (B > 0 && !ids)) return fail("vq_tpc_update: bad argument (C % 4 == 0)");
+    const long n = (long)K * C;
+    if (w < 0.5f) { for (long i = 0; i < n; ++i) tpc[i] = fmaf(w, -tpc[i], tpc[i]); }
+    else { const float k = 1.0f - w; for (long i = 0; i < n; ++i) tpc[i] *= k; }
+    const float add = B > 0 ? w / (float)B : 0.f;
+    for (long i = 0; i < (long)B * K; ++i) {
+        long id = (flags & SELFTOK_IDS_I32) ? ((const int32_t*)ids)[i] : (long)((const long long*)ids)[i];
+        if (id < 0 || id >= C) continue;
+        tpc[(size_t)(i % K) * C + id] += add;
+    }
+    return SELFTOK_OK;
+}
+
+/* ================================================================================================================================
+ * fused element-wise passes (csrc/elementwise.hip)
+ * ============================================================================================================================== */
+static inline size_t split_blk_index(long row, int k, int plane, int KT)
+{
+    return ((((size_t)(row >> 4) * KT + (k >> 5)) * 2 + plane) << 9) + ((row & 15) << 5) + (k & 31);
+}
+/* the kernels' group_sum<G>: butterfly of xor-shuffles, every lane ends with the same value */
+static float butterfly(float* v, int G)
+{
+    float t[64];
+    for (int o = G / 2; o > 0; o >>= 1) {
+        for (int l = 0; l < G; ++l) t[l] = v[l] + v[l ^ o];
+        memcpy(v, t, (size_t)G * sizeof(float));
+    }
+    return v[0];
+}
+static int ln_mod(const float* x, const float* y, const float* gate, const float* shift, const float* scale, float* x_out, float* n_out, uint16_t* n_blk,
+                  int* overflow, int B, int T, int H, long msb, long mst, long gsb, long gst, float eps)
+{
+    if (!x || B < 0 || T < 0 || ((shift == NULL) != (scale == NULL)) || (n_blk && (H % 32)) || (!n_out && !n_blk && !(y && x_out))) return fail("residual_ln_mod: bad argument");
+    int G, VPL;
+    switch (H) { case 64: G = 16; VPL = 1; break; case 256: G = 64; VPL = 1; break; case 512: G = 64; VPL = 2; break; case 1024: G = 64; VPL = 4; break;
+                 case 1536: G = 64; VPL = 6; break; default: return fail("residual_ln_mod: unsupported hidden size (64/256/512/1024/1536)"); }
+    const long rows = (long)B * T;
+    int ovf = 0;
+#pragma omp parallel for schedule(static) reduction(| : ovf)
+    for (long gid = 0; gid < rows; ++gid) {
+        const long b = gid / T, t = gid - b * T;
+        float v[1536], part[64];
+        const float* xr = x + (size_t)gid * H;
+        memcpy(v, xr, (size_t)H * sizeof(float));
+        if (y) {
+            const float* yr = y + (size_t)gid * H;
+            const float* gr = gate ? gate + b * gsb + t * gst : NULL;
+            for (int c = 0; c < H; ++c) v[c] = gr ? v[c] + gr[c] * yr[c] : v[c] + yr[c];
+            if (x_out) memcpy(x_out + (size_t)gid * H, v, (size_t)H * sizeof(float));
+        }
+        if (!n_out && !n_blk) continue;
+        /* lane l owns float4 chunks (i * G + l), i < VPL: per-lane partial in chunk order, then the butterfly */
+        for (int l = 0; l < G; ++l) {
+            float s = 0.f;
+            for (int i = 0; i < VPL; ++i) { const float* q = v + (size_t)(i * G + l) * 4; s += (q[0] + q[1]) + (q[2] + q[3]); }
+            part[l] = s;
+        }
+        const float mean = butterfly(part, G) * (1.0f / H);
+        for (int l = 0; l < G; ++l) {
+            float q2 = 0.f;
+            for (int i = 0; i < VPL; ++i) {
+                const float* q = v + (size_t)(i * G + l) * 4;
+                const float a = q[0] - mean, bq = q[1] - mean, c = q[2] - mean, d = q[3] - mean;
+                q2 += (a * a + bq * bq) + (c * c + d * d);
+            }
+            part[l] = q2;
+        }
+        const float var = butterfly(part, G) * (1.0f / H);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        const float* sh = shift ? shift + b * msb + t * mst : NULL;
+        const float* sc = scale ? scale + b * msb + t * mst : NULL;
+        float mx = 0.f;
+        for (int c = 0; c < H; ++c) {
+            float o = (v[c] - mean) * rstd;
+            if (sc) o = o * (1.0f + sc[c]) + sh[c];
+            if (n_out) n_out[(size_t)gid * H + c] = o;
+            if (n_blk) {
+                const uint16_t hh = f32_to_f16(o);
+                n_blk[split_blk_index(gid, c, 0, H / 32)] = hh;
+                n_blk[split_blk_index(gid, c, 1, H / 32)] = f32_to_f16((o - f16_to_f32(hh)) * 2048.0f);
+                mx = fmaxf(mx, fabsf(o));
+            }
+        }
+        if (n_blk && !(mx < 65504.0f)) ovf |= 1;
+    }
+    if (ovf && overflow) *overflow |= ovf;
+    return SELFTOK_OK;
+}
+int selftok_residual_ln_mod_f32(const float* x, const float* y, const float* gate, const float* shift, const float* scale, float* x_out, float* n_out,
+                                int B, int T, int H, long msb, long mst, long gsb, long gst, float eps, hipStream_t s)
+{
+    (void)s;
+    return ln_mod(x, y, gate, shift, scale, x_out, n_out, NULL, NULL, B, T, H, msb, mst, gsb, gst, eps);
+}
+int selftok_residual_ln_mod_split(const float* x, const float* y, const float* gate, const float* shift, const float* scale, float* x_out, void* n_blk, int* overflow,
+                                  int B, int T, int H, long msb, long mst, long gsb, long gst, float eps, hipStream_t s)
+{
+    (void)s;
+    if (!n_blk) return fail("residual_ln_mod_split: null output");
+    return ln_mod(x, y, gate, shift, scale, x_out, NULL, (uint16_t*)n_blk, overflow, B, T, H, msb, mst, gsb, gst, eps);
+}
+static inline float gelu_tanh(float x) { const float k0 = 0.7978845608028654f, k1 = 0.044715f; return 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x))); }
+int selftok_bias_gelu_f32(float* h, const float* bias, long rows, int cols, hipStream_t s)
+{
+    (void)s;
+    if (!h || rows < 0 || cols <= 0 || (cols & 3)) return fail("bias_gelu: cols must be a multiple of 4");
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) { float v = h[r * cols + c]; if (bias) v += bias[c]; h[r * cols + c] = gelu_tanh(v); }
+    return SELFTOK_OK;
+}
+int selftok_silu_f32(const float* in, float* out, long n, hipStream_t s)
+{
+    (void)s;
+    if (!in || !out || n < 0) return fail("silu: bad argument");
+    for (long i = 0; i < n; ++i) out[i] = in[i] / (1.0f + expf(-in[i]));
+    return SELFTOK_OK;
+}
+int selftok_add_rows_f32(const float* in, const float* table, float* out, int B, long per_sample, hipStream_t s)
+{
+    (void)s;
+    if (!in || !table || !out || B < 0 || per_sample <= 0 || (per_sample & 3)) return fail("add_rows: bad argument");
+    for (long i = 0; i < (long)B * per_sample; ++i) out[i] = in[i] + table[i % per_sample];
+    return SELFTOK_OK;
+}
+int selftok_timestep_embed_f32(const float* t, const float* freqs, float* out, int n, int dim, float t_scale, hipStream_t s)
+{
+    (void)s;
+    if (!t || !freqs || !out || n < 0 || dim <= 0 || (dim & 1)) return fail("timestep_embed: bad argument");
+    const int half = dim / 2;
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < half; ++c) { const float a = (t[r] * t_scale) * freqs[c]; out[(size_t)r * dim + c] = cosf(a); out[(size_t)r * dim + half + c] = sinf(a); }
+    return SELFTOK_OK;
+}
+int selftok_patchify_f32(const float* x, float* out, int B, int C, int Hh, int Ww, hipStream_t s)
+{
+    (void)s;
+    if (!x || !out || B < 0 || C <= 0 || (Hh & 1) || (Ww & 1)) return fail("patchify: bad argument");
+    const int hp = Hh / 2, wp = Ww / 2;
+    for (int b = 0; b < B; ++b) for (int h = 0; h < hp; ++h) for (int w = 0; w < wp; ++w) for (int c = 0; c < C; ++c) {
+        const float* src = x + (((size_t)b * C + c) * Hh + 2 * h) * Ww + 2 * w;
+        float* o = out + (((size_t)b * hp + h) * wp + w) * (C * 4) + c * 4;
+        o[0] = src[0]; o[1] = src[1]; o[2] = src[Ww]; o[3] = src[Ww + 1];
+    }
+    return SELFTOK_OK;
+}
+int selftok_unpatchify_cfg_euler_f32(const float* yc, const float* yu, const float* x, float* x_out, float* v_out, int B, int C, int hp, int wp, float dt, float cfg, hipStream_t s)
+{
+    (void)s;
+    if (!yc || B < 0 || (x_out && !x) || (!x_out && !v_out)) return fail("unpatchify_cfg_euler: bad argument");
+    const int Hh = 2 * hp, Ww = 2 * wp;
+    for (int b = 0; b < B; ++b) for (int c = 0; c < C; ++c) for (int row = 0; row < Hh; ++row) for (int col = 0; col < Ww; ++col) {
+        const int h = row >> 1, p = row & 1, w = col >> 1, q = col & 1;
+        const size_t tok = ((size_t)b * hp + h) * wp + w, f = (size_t)(p * 2 + q) * C + c;
+        float v = yc[tok * (4 * C) + f];
+        if (yu) { const float u = yu[tok * (4 * C) + f]; v = u + cfg * (v - u); }
+        const size_t o = (((size_t)b * C + c) * Hh + row) * Ww + col;
+        if (v_out) v_out[o] = v;
+        if (x_out) x_out[o] = x[o] - dt * v;
+    }
+    return SELFTOK_OK;
+}
+int selftok_rmsnorm_f32(const float* x, const float* w, float* out, long rows, int dim, float eps, hipStream_t s)
+{
+    (void)s;
+    if (!x || !out || rows < 0 || dim <= 0) return fail("rmsnorm: bad argument");
+    for (long r = 0; r < rows; ++r) {
+        float part[64];
+        for (int l = 0; l < 16; ++l) { float a = 0.f; for (int c = l; c < dim; c += 16) a += x[r * dim + c] * x[r * dim + c]; part[l] = a; }
+        const float ss = butterfly(part, 16);
+        const float rr = 1.0f / sqrtf(ss / dim + eps);          /* the GPU uses v_rsq_f32 (1 ulp) */
+        for (int c = 0; c < dim; ++c) out[r * dim + c] = x[r * dim + c] * rr * (w ? w[c] : 1.0f);
+    }
+    return SELFTOK_OK;
+}
+int selftok_rotary_f32(const float* t, const float* freqs, float* out, long rows, int seq, int dim, float scale, hipStream_t s)
+{
+    (void)s;
+    if (!t || !freqs || !out || rows < 0 || seq <= 0 || dim <= 0 || (dim & 1)) return fail("rotary: bad argument");
+    for (long r = 0; r < rows; ++r) {
+        const float* f = freqs + (size_t)(r % seq) * dim;
+        for (int pr = 0; pr < dim / 2; ++pr) {
+            const float x1 = t[r * dim + 2 * pr], x2 = t[r * dim + 2 * pr + 1], f1 = f[2 * pr], f2 = f[2 * pr + 1];
+            out[r * dim + 2 * pr] = x1 * cosf(f1) * scale + (-x2) * sinf(f1) * scale;
+            out[r * dim + 2 * pr + 1] = x2 * cosf(f2) * scale + x1 * sinf(f2) * scale;
+        }
+    }
+    return SELFTOK_OK;
+}
+
+/* ================================================================================================================================
+ * fp32-equivalent Linear on fp16 pairs (csrc/gemm_split.hip):  x = x0 + x1 2^-11,  a.w ~ a0 w0 + 2^-11 (a0 w1 + a1 w0)
+ * ============================================================================================================================== */
+#define BN 128
+#define BK 32
+#define W_TILE_HALFS 8192          /* one (n-block, k-tile): [plane 2][g 4][n 128][8] */
+size_t selftok_linear_f16x2_packed_bytes(int N, int K) { return (N > 0 && K > 0 && N % BN == 0 && K % BK == 0) ? (size_t)4 * N * K : 0; }
+size_t selftok_split_f16x2_bytes(long rows, int cols) { return (rows >= 0 && cols > 0 && cols % 32 == 0) ? (size_t)((rows + 15) / 16) * 16 * cols * 4 : 0; }
+static inline void split1(float v, uint16_t* hi, uint16_t* lo) { *hi = f32_to_f16(v); *lo = f32_to_f16((v - f16_to_f32(*hi)) * 2048.0f); }
+static inline size_t wp_index(int n, int k, int plane, int KT)
+{
+    const int nb = n / BN, nl = n % BN, kt = k / BK, g = (k % BK) / 8;
+    return ((size_t)nb * KT + kt) * W_TILE_HALFS + (size_t)plane * 4096 + (size_t)g * 1024 + (size_t)nl * 8 + (k & 7);
+}
+int selftok_linear_f16x2_pack_weight(const float* W, void* packed, int N, int K, int* overflow, hipStream_t s)
+{
+    (void)s;
+    if (!W || !packed || selftok_linear_f16x2_packed_bytes(N, K) == 0) return fail("linear_f16x2_pack_weight: need N % 128 == 0 and K % 32 == 0");
+    uint16_t* p = (uint16_t*)packed;
+    int ovf = 0;
+    for (int n = 0; n < N; ++n) for (int k = 0; k < K; ++k) {
+        const float v = W[(size_t)n * K + k];
+        split1(v, &p[wp_index(n, k, 0, K / BK)], &p[wp_index(n, k, 1, K / BK)]);
+        if (!(fabsf(v) < 65504.0f)) ovf = 2;
+    }
+    if (ovf && overflow) *overflow |= ovf;
+    return SELFTOK_OK;
+}
+int selftok_split_f16x2_f32(const float* x, long ld, void* blk, long rows, int cols, int* overflow, hipStream_t s)
+{
+    (void)s;
+    if (!x || !blk || rows < 0 || cols <= 0 || (cols % 32)) return fail("split_f16x2: bad argument");
+    uint16_t* p = (uint16_t*)blk;
+    int ovf = 0;
+    for (long r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) {
+        const float v = x[r * ld + c];
+        split1(v, &p[split_blk_index(r, c, 0, cols / 32)], &p[split_blk_index(r, c, 1, cols / 32)]);
+        if (!(fabsf(v) < 65504.0f)) ovf = 1;
+    }
+    if (ovf && overflow) *overflow |= ovf;
+    return SELFTOK_OK;
+}
+/* x sigmoid(2u): the GEMM epilogue's form of the tanh-GELU (gemm_split.hip gelu_tanh_f) */
+static inline float gelu_sig(float x) { const float k0 = 0.7978845608028654f, k1 = 0.044715f; const float u = k0 * (x + k1 * x * x * x); return x * (1.0f / (1.0f + exp2f(u * (-2.0f * 1.4426950408889634f)))); }
+/* row m of (a0, a1) against weight row n: separate fp32 accumulators for the high and the two low terms, combined once.  One
+ * v_mfma_f32_32x32x16_f16 adds 16 exact fp16 x fp16 products to its fp32 accumulator with ONE rounding: modelled as a double sum of the
+ * 16 products (exact: 22-bit products, 16 of them) rounded to fp32 together with the accumulator, k-blocks in ascending order. */
+static float dot_split(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* wp, int n, int K)
+{
+    float hi = 0.f, lo = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        double sh = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int k = k0; k < k0 + 16; ++k) {
+            const double a0 = f16_to_f32(a_hi[k]), a1 = f16_to_f32(a_lo[k]);
+            const double w0 = f16_to_f32(wp[wp_index(n, k, 0, K / BK)]), w1 = f16_to_f32(wp[wp_index(n, k, 1, K / BK)]);
+            sh += a0 * w0; s1 += a0 * w1; s2 += a1 * w0;
+        }
+        hi = (float)((double)hi + sh);
+        lo = (float)((double)lo + s1);
+        lo = (float)((double)lo + s2);
+    }
+    return hi + lo * (1.0f / 2048.0f);
+}
+static int linear_core(const float* A, long lda, const uint16_t* a_blk, const void* packed, const float* bias, float* out, uint16_t* out_blk, long ldo,
+                       const float* resid, long ldr, const float* gate, long gsb, long gst, int T, int M, int N, int K, int flags, int* overflow)
+{
+    if (!packed || selftok_linear_f16x2_packed_bytes(N, K) == 0 || M < 0) return fail("linear_f16x2: bad argument (N % 128 == 0, K % 32 == 0)");
+    const uint16_t* wp = (const uint16_t*)packed;
+    int ovf = 0;
+#pragma omp parallel for schedule(static) reduction(| : ovf)
+    for (int m = 0; m < M; ++m) {
+        uint16_t ah[6144], al[6144];
+        for (int k = 0; k < K; ++k) {
+            if (A) { const float v = A[(size_t)m * lda + k]; split1(v, &ah[k], &al[k]); if (!(fabsf(v) < 65504.0f)) ovf |= 1; }
+            else { ah[k] = a_blk[split_blk_index(m, k, 0, K / 32)]; al[k] = a_blk[split_blk_index(m, k, 1, K / 32)]; }
+        }
+        for (int n = 0; n < N; ++n) {
+            float v = dot_split(ah, al, wp, n, K) + (bias ? bias[n] : 0.f);
+            if (flags & SELFTOK_LINEAR_GELU) v = gelu_sig(v);
+            if (resid) {
+                const float g = gate ? gate[(size_t)(m / T) * gsb + (size_t)(m % T) * gst + n] : 1.0f;
+                v = gate ? resid[(size_t)m * ldr + n] + g * v : resid[(size_t)m * ldr + n] + v;
+            }
+            if (!(fabsf(v) < INFINITY)) ovf |= 1;
+            if (out) out[(size_t)m * ldo + n] = v;
+            if (out_blk) { split1(v, &out_blk[split_blk_index(m, n, 0, N / 32)], &out_blk[split_blk_index(m, n, 1, N / 32)]); if (!(fabsf(v) < 65504.0f)) ovf |= 1; }
+        }
+    }
+    if (ovf && overflow) *overflow |= ovf;
+    return SELFTOK_OK;
+}
+int selftok_linear_f16x2_f32(const float* A, long lda, const void* packed, const float* bias, float* out, long ldo, int M, int N, int K, int flags, int* overflow, hipStream_t s)
+{
+    (void)s;
+    if (!A || !out || K > 6144) return fail("linear_f16x2: bad argument");
+    return linear_core(A, lda, NULL, packed, bias, out, NULL, ldo, NULL, 0, NULL, 0, 0, 1, M, N, K, flags, overflow);
+}
+int selftok_linear_f16x2_split(const void* a_blk, const void* packed, const float* bias, float* out, void* out_blk, long ldo, int M, int N, int K, int flags, int* overflow, hipStream_t s)
+{
+    (void)s;
+    if (!a_blk || (!out && !out_blk) || K > 6144) return fail("linear_f16x2_split: bad argument");
+    return linear_core(NULL, 0, (const uint16_t*)a_blk, packed, bias, out, (uint16_t*)out_blk, ldo, NULL, 0, NULL, 0, 0, 1, M, N, K, flags, overflow);
+}
+int selftok_linear_f16x2_split_residual(const void* a_blk, const void* packed, const float* bias, const float* resid, long ldr, const float* gate, long gsb, long gst, int T,
+                                        float* out, long ldo, int M, int N, int K, int* overflow, hipStream_t s)
+{
+    (void)s;
+    if (!a_blk || !resid || !out || T <= 0 || K > 6144) return fail("linear_f16x2_split_residual: bad argument");
+    return linear_core(NULL, 0, (const uint16_t*)a_blk, packed, bias, out, NULL, ldo, resid, ldr, gate, gsb, gst, T, M, N, K, 0, overflow);
+}
+
+/* ================================================================================================================================
+ * two-segment attention with the implicit prefix-visibility mask (csrc/attention.hip)
+ * ============================================================================================================================== */
+int selftok_attn_f32(const selftok_attn_desc* d, hipStream_t s)
+{
+    (void)s;
+    if (!d || d->B < 0 || d->H <= 0) return fail("attn: bad descriptor");
+    if (d->head_dim != 64 && d->head_dim != 16) return fail("attn: head_dim must be 64 or 16");
+    const int Dh = d->head_dim;
+    if (Dh == 16 && (d->seg[0].len != 0 || d->kvis || !d->seg[1].q)) return fail("attn(head_dim 16): single unmasked segment only");
+    if (d->mode != 0 && d->mode != SELFTOK_ATTN_F16X2) return fail("attn: unknown mode");
+    int ovf = 0;
+#pragma omp parallel for collapse(2) schedule(dynamic) reduction(| : ovf)
+    for (int b = 0; b < d->B; ++b) for (int h = 0; h < d->H; ++h) {
+        int n0 = d->seg[0].len;
+        if (d->kvis) { int kv = d->kvis[b] + 1; n0 = kv < n0 ? (kv < 0 ? 0 : kv) : n0; }
+        for (int sg = 0; sg < 2; ++sg) {
+            const selftok_attn_seg* qs = &d->seg[sg];
+            if (!qs->q || qs->len <= 0) continue;
+            const int rows = sg == 0 ? n0 : qs->len;
+            const int n1 = (sg == 1 || d->seg0_sees_seg1) ? d->seg[1].len : 0;
+            const int nk = n0 + n1;
+            float* sc = (float*)malloc((size_t)(nk > 0 ? nk : 1) * sizeof(float));
+            for (int r = 0; r < rows; ++r) {
+                const float* q = qs->q + (size_t)b * qs->q_bs + (size_t)r * qs->q_rs + h * Dh;
+                float mx = -INFINITY;
+                for (int j = 0; j < nk; ++j) {
+                    const selftok_attn_seg* ks = &d->seg[j < n0 ? 0 : 1];
+                    const int kj = j < n0 ? j : j - n0;
+                    const float* k = ks->k + (size_t)b * ks->k_bs + (size_t)kj * ks->k_rs + h * Dh;
+                    float a = 0.f;
+                    for (int e = 0; e < Dh; ++e) { a = fmaf(q[e], k[e], a); if (d->mode && (!(fabsf(q[e]) < 65504.0f) || !(fabsf(k[e]) < 65504.0f))) ovf |= 4; }
+                    sc[j] = a * d->scale;
+                    mx = fmaxf(mx, sc[j]);
+                }
+                float l = 0.f, o[64];
+                for (int e = 0; e < Dh; ++e) o[e] = 0.f;
+                for (int j = 0; j < nk; ++j) {
+                    const selftok_attn_seg* ks = &d->seg[j < n0 ? 0 : 1];
+                    const int kj = j < n0 ? j : j - n0;
+                    const float* v = ks->v + (size_t)b * ks->v_bs + (size_t)kj * ks->v_rs + h * Dh;
+                    const float p = expf(sc[j] - mx);
+                    l += p;
+                    for (int e = 0; e < Dh; ++e) { o[e] = fmaf(p, v[e], o[e]); if (d->mode && !(fabsf(v[e]) < 65504.0f)) ovf |= 4; }
+                }
+                const float inv = 1.0f / l;
+                const long row_g = (long)b * qs->len + r;
+                for (int e = 0; e < Dh; ++e) {
+                    const float val = o[e] * inv;
+                    if (d->mode == SELFTOK_ATTN_F16X2 && d->o_blk[sg]) {
+                        uint16_t* ob = (uint16_t*)d->o_blk[sg];
+                        split1(val, &ob[split_blk_index(row_g, h * Dh + e, 0, d->H * Dh / 32)], &ob[split_blk_index(row_g, h * Dh + e, 1, d->H * Dh / 32)]);
+                    } else if (qs->o) {
+                        qs->o[(size_t)b * qs->o_bs + (size_t)r * qs->o_rs + h * Dh + e] = val;
+                    }
+                }
+            }
+            free(sc);
+        }
+    }
+    if (ovf && d->overflow) *d->overflow |= ovf;
+    return SELFTOK_OK;
+}
+
+/* ================================================================================================================================
+ * bf16 epilogues around the VAE convolutions (csrc/vae.hip)
+ * ============================================================================================================================== */
+int selftok_groupnorm_silu_bf16(const void* xv, const void* wv, const void* bv, void* outv, int B, int C, int HW, int groups, float eps, int apply_silu, hipStream_t s)
+{
+    (void)s;
+    if (!xv || !wv || !bv || !outv || B < 0 || groups <= 0 || C % groups || (HW & 7)) return fail("groupnorm_silu: need C%groups==0 and H*W%8==0");
+    const uint16_t *x = (const uint16_t*)xv, *w = (const uint16_t*)wv, *bb = (const uint16_t*)bv;
+    uint16_t* out = (uint16_t*)outv;
+    const int cpg = C / groups;
+    const long n = (long)cpg * HW;
+#pragma omp parallel for schedule(static)
+    for (long bg = 0; bg < (long)B * groups; ++bg) {
+        const int g = (int)(bg % groups);
+        const uint16_t* xs = x + bg * n;
+        double s1 = 0.0, s2 = 0.0;
+        for (long i = 0; i < n; ++i) s1 += bf2f(xs[i]);
+        const float mean = (float)(s1 / (double)n);
+        for (long i = 0; i < n; ++i) { const double dd = (double)bf2f(xs[i]) - (double)mean; s2 += dd * dd; }
+        const float var = (float)(s2 / (double)n);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        for (long i = 0; i < n; ++i) {
+            const int ch = g * cpg + (int)(i / HW);
+            float yv = rbf((bf2f(xs[i]) - mean) * rstd * bf2f(w[ch]) + bf2f(bb[ch]));
+            if (apply_silu) yv = yv / (1.0f + expf(-yv));
+            out[bg * n + i] = f2bf(yv);
+        }
+    }
+    return SELFTOK_OK;
+}
+int selftok_latent_process_in(const void* mv, float* out, int B, int c_in, int c_keep, int HW, float shift, float scale, hipStream_t s)
+{
+    (void)s;
+    if (!mv || !out || B < 0 || c_keep > c_in) return fail("latent_process_in: bad argument");
+    const uint16_t* m = (const uint16_t*)mv;
+    for (int b = 0; b < B; ++b) for (int c = 0; c < c_keep; ++c) for (int p = 0; p < HW; ++p) {
+        const float z = bf2f(m[((size_t)b * c_in + c) * HW + p]);
+        out[((size_t)b * c_keep + c) * HW + p] = rbf(rbf(z - rbf(shift)) * scale);
+    }
+    return SELFTOK_OK;
+}
+int selftok_latent_process_out(const float* z, void* outv, long n, float shift, float scale, hipStream_t s)
+{
+    (void)s;
+    if (!z || !outv || n < 0) return fail("latent_process_out: bad argument");
+    uint16_t* out = (uint16_t*)outv;
+    for (long i = 0; i < n; ++i) out[i] = f2bf((z[i] / scale) + shift);
+    return SELFTOK_OK;
+}
+int selftok_clamp01_bf16(void* imgv, long n, hipStream_t s)
+{
+    (void)s;
+    if (!imgv || n < 0) return fail("clamp01: bad argument");
+    uint16_t* img = (uint16_t*)imgv;
+    for (long i = 0; i < n; ++i) {
+        const float x0 = bf2f(img[i]);
+        float v = (x0 != x0) ? x0 : fminf(fmaxf(x0, -1.0f), 1.0f);
+        v = rbf(v - (-1.0f));
+        img[i] = f2bf(v / 2.0f);
+    }
+    return SELFTOK_OK;
+}
