@@ -354,12 +354,12 @@ def _linear(kind, flags=0, M=70, N=256, K=160, seed=33):
     return fn
 
 
-case("linear_f16x2_f32", exact=False, tol=3e-6)(_linear("f32"))
-case("linear_f16x2_f32_gelu", exact=False, tol=3e-6)(_linear("f32", GELU))
-case("linear_f16x2_split", exact=False, tol=3e-6)(_linear("split"))
-case("linear_f16x2_split_to_split", exact=False, tol=3e-6)(_linear("split_to_split", GELU))
-case("linear_f16x2_split_residual_gate", exact=False, tol=3e-6)(_linear("resid_gate"))
-case("linear_f16x2_split_residual_nogate", exact=False, tol=3e-6)(_linear("resid"))
+case("linear_f16x2_f32", exact=False, tol=1e-6)(_linear("f32"))
+case("linear_f16x2_f32_gelu", exact=False, tol=1e-6)(_linear("f32", GELU))
+case("linear_f16x2_split", exact=False, tol=1e-6)(_linear("split"))
+case("linear_f16x2_split_to_split", exact=False, tol=1e-6)(_linear("split_to_split", GELU))
+case("linear_f16x2_split_residual_gate", exact=False, tol=1e-6)(_linear("resid_gate"))
+case("linear_f16x2_split_residual_nogate", exact=False, tol=1e-6)(_linear("resid"))
 
 
 # ---- attention --------------------------------------------------------------------------------------------------------------------
