@@ -88,6 +88,19 @@ int selftok_vq_ema_accumulate_f32(const float* z, const void* ids, float* bins, 
 /* timestep_p_over_c [K,C] <- lerp(itself, mean_b one_hot(ids[b,k]), weight)  (:568-578, ema_inplace :66-72) with ids [B,K]
  * (the ids of ALL ranks: gather the ids instead of all-reducing the dense [K,C] mean); C % 4 == 0. */
 int selftok_vq_tpc_update_f32(float* tpc, const void* ids, int B, int K, int C, float weight, int flags, hipStream_t stream);
+/* Entropy regularisers of VectorQuantize.forward in training (vector_quantize_pytorch.py:1006-1031 with calc_entropy :89-100 and
+ * calc_ema_entropy :109-118) without the [B, K, C] probability tensor.  With p = softmax_c(scale * <l2norm(z[b,k]), codebook[c]>)
+ * (scale = 10, :1007), z [B, K, 16] as for selftok_vq_encode_f32 (flag SELFTOK_PRENORMED honoured), codebook [C, 16] unit-norm rows:
+ *   rowstats [B*K, 2] = (1 / sum_c exp(logit), H(p[b,k,:]))                 -> entropy_to_min = mean of column 1
+ *   colmean  [K, C]   = mean_b p[b, k, :]   (NULL: skipped)                  -> ap of calc_ema_entropy; its mean over k is calc_entropy's ap
+ * selftok_vq_softmax_backward_f32: given g = dF/d(colmean) [K, C] for any scalar F of colmean (the caller differentiates the small
+ * [K, C] epilogue), grad_z [B, K, 16] = dF/dz through the softmax, the scores and the l2norm (codebook detached, as
+ * `embed.detach()` :559).  workspace: selftok_vq_softmax_workspace_bytes(B*K) bytes, 16-byte aligned, shared by both calls. */
+size_t selftok_vq_softmax_workspace_bytes(int N);
+int selftok_vq_softmax_stats_f32(const float* z, const float* codebook, float* rowstats, float* colmean, void* workspace, int B, int K, int C, int D,
+                                 float scale, int flags, hipStream_t stream);
+int selftok_vq_softmax_backward_f32(const float* z, const float* codebook, const float* rowstats, const float* g_colmean, float* grad_z, void* workspace,
+                                    int B, int K, int C, int D, float scale, int flags, hipStream_t stream);
 
 /* ---- fused residual + LayerNorm + adaLN modulate ---------------------------------------------
  *   x' = x + gate*y ;  n = LN(x') * (1 + scale) + shift          (LN: no affine, eps)

@@ -250,6 +250,84 @@ int selftok_vq_tpc_update_f32(float* tpc, const void* ids, int B, int K, int C, 
     return SELFTOK_OK;
 }
 
+/* ---- entropy regularisers without the [B, K, C] tensor (csrc/vq_entropy.hip): same reductions, scalar loops in double ------------------ */
+size_t selftok_vq_softmax_workspace_bytes(int N) { return (size_t)8 * (size_t)(N > 0 ? N : 1) * 36 * sizeof(float); }
+static void unit_row(const float* z, float* x, int norm, float* nrm_out)
+{
+    if (norm) {
+        l2norm16(z, x);
+        float a[8], s;
+        for (int j = 0; j < 8; ++j) a[j] = fmaf(z[j + 8], z[j + 8], z[j] * z[j]);
+        s = a[0];
+        for (int j = 1; j < 8; ++j) s = s + a[j];
+        float n = sqrtf(s);
+        *nrm_out = (n > 1e-12f) ? n : 1e-12f;
+    } else { memcpy(x, z, VD * sizeof(float)); *nrm_out = 1.0f; }
+}
+static inline float score16(const float* x, const float* e) { float s = 0.f; for (int k = 0; k < VD; ++k) s = fmaf(x[k], e[k], s); return s; }
+int selftok_vq_softmax_stats_f32(const float* z, const float* cb, float* rowstats, float* colmean, void* workspace, int B, int K, int C, int D,
+                                 float scale, int flags, hipStream_t s)
+{
+    (void)s;
+    if (D != VD || B < 0 || K <= 0 || C <= 0 || K > 65535) return fail("vq_softmax_stats: bad argument (D == 16, K <= 65535)");
+    if (B == 0) return SELFTOK_OK;
+    if (!z || !cb || !rowstats || !workspace) return fail("vq_softmax_stats: null pointer");
+    const int norm = (flags & SELFTOK_PRENORMED) ? 0 : 1;
+    const long N = (long)B * K;
+#pragma omp parallel for schedule(static)
+    for (long n = 0; n < N; ++n) {
+        float x[VD], nr;
+        unit_row(z + n * VD, x, norm, &nr);
+        double S = 0.0, T = 0.0;
+        for (int c = 0; c < C; ++c) { const double l = (double)(score16(x, cb + (size_t)c * VD) * scale); const double p = exp(l); S += p; T += p * l; }
+        rowstats[2 * n] = (float)(1.0 / S);
+        rowstats[2 * n + 1] = (float)(log(S) - T / S);
+    }
+    if (!colmean) return SELFTOK_OK;
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < K; ++k) {
+        double* acc = (double*)calloc((size_t)C, sizeof(double));
+        for (int b = 0; b < B; ++b) {
+            const long n = (long)b * K + k;
+            float x[VD], nr;
+            unit_row(z + n * VD, x, norm, &nr);
+            const double inv = rowstats[2 * n];
+            for (int c = 0; c < C; ++c) acc[c] += exp((double)(score16(x, cb + (size_t)c * VD) * scale)) * inv;
+        }
+        for (int c = 0; c < C; ++c) colmean[(size_t)k * C + c] = (float)(acc[c] / B);
+        free(acc);
+    }
+    return SELFTOK_OK;
+}
+int selftok_vq_softmax_backward_f32(const float* z, const float* cb, const float* rowstats, const float* g, float* grad_z, void* workspace,
+                                    int B, int K, int C, int D, float scale, int flags, hipStream_t s)
+{
+    (void)s;
+    if (D != VD || B < 0 || K <= 0 || C <= 0 || K > 65535) return fail("vq_softmax_backward: bad argument (D == 16, K <= 65535)");
+    if (B == 0) return SELFTOK_OK;
+    if (!z || !cb || !rowstats || !g || !grad_z || !workspace) return fail("vq_softmax_backward: null pointer");
+    const int norm = (flags & SELFTOK_PRENORMED) ? 0 : 1;
+    const long N = (long)B * K;
+#pragma omp parallel for schedule(static)
+    for (long n = 0; n < N; ++n) {
+        const int k = (int)(n % K);
+        float x[VD], nr;
+        unit_row(z + n * VD, x, norm, &nr);
+        double A[VD] = {0}, m[VD] = {0}, t = 0.0;
+        const double inv = rowstats[2 * n];
+        for (int c = 0; c < C; ++c) {
+            const float* e = cb + (size_t)c * VD;
+            const double p = exp((double)(score16(x, e) * scale)) * inv, pg = p * g[(size_t)k * C + c];
+            t += pg;
+            for (int q = 0; q < VD; ++q) { m[q] += p * e[q]; A[q] += pg * e[q]; }
+        }
+        double gx[VD], xd = 0.0;
+        for (int q = 0; q < VD; ++q) { gx[q] = (double)scale / B * (A[q] - t * m[q]); xd += x[q] * gx[q]; }
+        for (int q = 0; q < VD; ++q) grad_z[n * VD + q] = (float)(norm ? (gx[q] - x[q] * xd) / nr : gx[q]);
+    }
+    return SELFTOK_OK;
+}
+
 /* ================================================================================================================================
  * fused element-wise passes (csrc/elementwise.hip)
  * ============================================================================================================================== */

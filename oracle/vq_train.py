@@ -107,3 +107,37 @@ def kmeans_iteration(samples: torch.Tensor, means: torch.Tensor, all_reduce=None
         all_reduce(new_means)
     new_means = l2norm(new_means)
     return torch.where(zero[:, None], means, new_means), bins
+
+
+def entropy_terms(z: torch.Tensor, embed: torch.Tensor, tpc: torch.Tensor, diversity_weight: float, smart_re_K: bool = True,
+                  ema_entropy_ratio: float = 0.7, reg=(0.25, 0.5)) -> Dict[str, torch.Tensor]:
+    """the entropy regularisers of VectorQuantize.forward in training (:1006-1031), on the materialised [1, B, K, C] score tensor as
+    the reference computes them: z [B,K,D] pre-norm (autograd-capable), embed [C,D] (detached, :559), tpc = timestep_p_over_c [K,C].
+      calc_entropy (:89-100) on the 10x scaled scores of all B*K rows: entropy_to_max = H(mean_n p), entropy_to_min = mean_n H(p_n)
+      calc_ema_entropy (:109-118): ema_p = tpc (1 - ratio_d) + mean_b p ratio_d with ratio_d = 1 - ema_entropy_ratio (:1015);
+          entropy of every token position, and of the means over 64 groups of positions (tensor_split(64))
+      get_group_perplexity (:456-459), the weight ramp between reg[0] and reg[1] (:1021-1024), diversity_loss (:1026 / :1028).
+    The reference's own call passes `min_ref=` to calc_entropy, which takes no such argument (TypeError, :1008-1010): the value
+    restated is the call without it."""
+    C = embed.shape[0]
+    distances = torch.einsum("h n d, h c d -> h n c", l2norm(z.float()).reshape(1, -1, z.shape[-1]), embed.detach()[None]).reshape(1, *z.shape[:2], C)
+    scaled = distances * 10.0
+    p = scaled.flatten(end_dim=-2).softmax(dim=-1)
+    ap = p.mean(dim=0)
+    out = {"entropy_to_max": -(ap * torch.log(ap)).sum(dim=-1), "entropy_to_min": (-(p * torch.log(p)).sum(dim=-1)).mean()}
+    if smart_re_K:
+        ratio_d = 1.0 - ema_entropy_ratio
+        apk = scaled.softmax(dim=-1)[0].mean(dim=0)
+        ema_p = tpc * (1 - ratio_d) + apk * ratio_d
+        out["codebook_entropy"] = (-(ema_p * torch.log(ema_p)).sum(dim=-1)).mean()
+        grp = torch.stack([t.mean(dim=0) for t in ema_p.tensor_split(64, dim=0)], dim=0)
+        out["group_entropy"] = (-(grp * torch.log(grp)).sum(dim=-1)).mean()
+        entropy = 0.5 * (out["codebook_entropy"] + out["group_entropy"])
+        out["perplexity"] = torch.exp(-torch.sum(tpc * torch.log(tpc + 1e-10), dim=-1)).mean()
+        frac = float(out["perplexity"]) / C
+        w = 0.5 if frac < reg[0] else max(0.5 - 0.5 / (reg[1] - reg[0]) * (frac - reg[0]), 0.0)
+        out["codebook_ent_weight"] = torch.tensor(w)
+        out["diversity_loss"] = -diversity_weight * w * entropy
+    else:
+        out["diversity_loss"] = -diversity_weight * out["entropy_to_max"]
+    return out

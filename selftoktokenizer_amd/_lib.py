@@ -26,6 +26,9 @@ SIGNATURES = {
     "selftok_vq_finalize_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "selftok_vq_ema_accumulate_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "selftok_vq_tpc_update_f32": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "selftok_vq_softmax_workspace_bytes": (_sz, [_i]),
+    "selftok_vq_softmax_stats_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "selftok_vq_softmax_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "selftok_code_gather_ln_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "selftok_residual_ln_mod_f32": (_i, [_vp] * 7 + [_i, _i, _i, _l, _l, _l, _l, _f, _vp]),
     "selftok_bias_gelu_f32": (_i, [_vp, _vp, _l, _i, _vp]),

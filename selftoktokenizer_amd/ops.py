@@ -111,6 +111,40 @@ def vq_ema_accumulate(z: torch.Tensor, ids: torch.Tensor, C: int, prenormed: boo
     return bins, esum
 
 
+def vq_softmax_stats(z: torch.Tensor, codebook: torch.Tensor, scale: float = 10.0, colmean: bool = True, prenormed: bool = False):
+    """The two reductions of p = softmax_c(scale * <l2norm(z[b,k]), codebook[c]>) that the reference's entropy regularisers read from
+    its materialised [B, K, C] tensor (calc_entropy / calc_ema_entropy, vector_quantize_pytorch.py:89-118): z [B,K,16] ->
+    (rowstats [B*K, 2] = (1 / sum_c exp, H(p[b,k,:])), colmean [K, C] = mean_b p[b,k,:] or None)."""
+    _need_cuda(z, codebook)
+    assert z.dim() == 3 and codebook.dim() == 2 and z.shape[-1] == codebook.shape[1]
+    zz, cb = z.contiguous().float(), codebook.contiguous().float()
+    B, K, Dm = zz.shape
+    C = cb.shape[0]
+    lib = _lib.load()
+    rows = torch.empty(B * K, 2, dtype=torch.float32, device=z.device)
+    cm = torch.empty(K, C, dtype=torch.float32, device=z.device) if colmean else None
+    ws = torch.empty(lib.selftok_vq_softmax_workspace_bytes(B * K), dtype=torch.uint8, device=z.device)
+    _lib.check(lib.selftok_vq_softmax_stats_f32(_p(zz), _p(cb), _p(rows), _p(cm), _p(ws), B, K, C, Dm, float(scale), PRENORMED if prenormed else 0, _stream()),
+               "selftok_vq_softmax_stats_f32")
+    return rows, cm
+
+
+def vq_softmax_backward(z: torch.Tensor, codebook: torch.Tensor, rowstats: torch.Tensor, g_colmean: torch.Tensor, scale: float = 10.0,
+                        prenormed: bool = False) -> torch.Tensor:
+    """dF/dz [B,K,16] for a scalar F of vq_softmax_stats' colmean, given g_colmean = dF/d(colmean) [K, C] (code book detached)."""
+    _need_cuda(z, codebook, rowstats, g_colmean)
+    zz, cb, g = z.contiguous().float(), codebook.contiguous().float(), g_colmean.contiguous().float()
+    B, K, Dm = zz.shape
+    C = cb.shape[0]
+    assert tuple(g.shape) == (K, C) and tuple(rowstats.shape) == (B * K, 2) and rowstats.is_contiguous() and rowstats.dtype == torch.float32
+    lib = _lib.load()
+    grad = torch.empty_like(zz)
+    ws = torch.empty(lib.selftok_vq_softmax_workspace_bytes(B * K), dtype=torch.uint8, device=z.device)
+    _lib.check(lib.selftok_vq_softmax_backward_f32(_p(zz), _p(cb), _p(rowstats), _p(g), _p(grad), _p(ws), B, K, C, Dm, float(scale),
+                                                   PRENORMED if prenormed else 0, _stream()), "selftok_vq_softmax_backward_f32")
+    return grad
+
+
 def vq_tpc_update_(tpc: torch.Tensor, ids: torch.Tensor, weight: float) -> torch.Tensor:
     """in place: tpc [K,C] <- lerp(tpc, mean over samples of one_hot(ids [B,K]), weight)  (vector_quantize_pytorch.py:568-578)"""
     _need_cuda(tpc, ids)

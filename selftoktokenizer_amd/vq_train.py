@@ -13,12 +13,14 @@ tokenizer's single code book (32768 x 16, decay 0.99, smart reactivation over th
   * dead codes are replaced by batch vectors drawn with torch.multinomial on the device (the reference draws with numpy on the
     host, :166-168); the statistics are the same, the random stream is not.
 
-The differentiable part of the reference's VectorQuantize.forward in training (commitment / entropy losses, straight-through
-estimator) needs autograd through the encoder and stays outside this inference-centred hot path.
+The entropy regularisers of VectorQuantize.forward in training (:1006-1031) are here too, forward AND backward, without the
+[B, K, C] probability tensor the reference materialises (csrc/vq_entropy.hip): `softmax_colmean` is a torch.autograd.Function whose
+backward is one more fused pass, so `CodebookEMA.entropy_regularisers(z, ...)` returns a diversity loss that back-propagates into
+whatever produced z.  The commitment loss / straight-through estimator are plain element-wise torch on [B, K, 16] and need no kernel.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -28,6 +30,34 @@ from . import dist as D, ops
 
 def l2norm(t: torch.Tensor) -> torch.Tensor:
     return F.normalize(t, p=2, dim=-1)
+
+
+class _SoftmaxColMean(torch.autograd.Function):
+    """(mean_b softmax_c(scale <l2norm(z[b,k]), e_c>) [K,C], row entropies [B*K]) with a fused backward for the first output
+    (csrc/vq_entropy.hip); the row entropies are a logged quantity in the reference (`deterministic_entropy`, :1030) and carry no
+    gradient here."""
+
+    @staticmethod
+    def forward(ctx, z, codebook, scale):
+        rows, colmean = ops.vq_softmax_stats(z, codebook, scale)
+        ctx.save_for_backward(z, codebook, rows)
+        ctx.scale = scale
+        ent = rows[:, 1].clone()
+        ctx.mark_non_differentiable(ent)
+        return colmean, ent
+
+    @staticmethod
+    def backward(ctx, g_colmean, _g_ent):
+        z, codebook, rows = ctx.saved_tensors
+        # the softmax backward p (g - sum_c p g) does not change when a constant is added to a row of g; an entropy's g = -(1 + log ap)
+        # is such a constant plus a small variation: remove the row means first, or A - t m cancels 3-4 digits in fp32
+        g = g_colmean - g_colmean.mean(dim=1, keepdim=True)
+        return ops.vq_softmax_backward(z, codebook, rows, g, ctx.scale).view_as(z), None, None
+
+
+def softmax_colmean(z: torch.Tensor, codebook: torch.Tensor, scale: float = 10.0):
+    """z [B,K,16] (pre-norm), codebook [C,16] (treated as a constant, `embed.detach()` :559) -> (ap_k [K,C], H(p_n) [B*K])"""
+    return _SoftmaxColMean.apply(z, codebook.detach(), float(scale))
 
 
 class CodebookEMA:
@@ -90,6 +120,35 @@ class CodebookEMA:
             self._packed = None
             n_react = self.expire_codes_(z, generator)
         return quantize, ids, n_react
+
+    # ---- entropy regularisers (:1006-1031) -------------------------------------------------------------------------------
+    def entropy_regularisers(self, z: torch.Tensor, diversity_weight: float, smart_re_K: bool = True, ema_entropy_ratio: float = 0.7,
+                             reg=(0.25, 0.5)) -> Dict[str, torch.Tensor]:
+        """calc_entropy (:89-100) + calc_ema_entropy (:109-118) + the perplexity-ramped weight (:1019-1026) on this rank's batch,
+        z [B,K,16] = the features `step` quantised (call it after `step`: the reference reads timestep_p_over_c after that forward's
+        update).  `diversity_loss` is differentiable with respect to z; the other entries are the reference's log values.  The
+        reference's own call site raises TypeError (`calc_entropy(..., min_ref=...)`, :1008-1010): this is the call without the
+        stray keyword."""
+        ap_k, row_entropy = softmax_colmean(z, self.embed, 10.0)
+        out = {"entropy_to_min": row_entropy.mean()}
+        ap = ap_k.mean(dim=0)                                                            # mean over all B*K rows
+        out["entropy_to_max"] = -(ap * torch.log(ap)).sum(dim=-1)
+        if smart_re_K:
+            tpc = self.timestep_p_over_c
+            ratio_d = 1.0 - ema_entropy_ratio                                            # :1015
+            ema_p = tpc * (1 - ratio_d) + ap_k * ratio_d
+            out["codebook_entropy"] = (-(ema_p * torch.log(ema_p)).sum(dim=-1)).mean()
+            grp = torch.stack([t.mean(dim=0) for t in ema_p.tensor_split(64, dim=0)], dim=0)
+            out["group_entropy"] = (-(grp * torch.log(grp)).sum(dim=-1)).mean()
+            entropy = 0.5 * (out["codebook_entropy"] + out["group_entropy"])
+            out["perplexity"] = torch.exp(-torch.sum(tpc * torch.log(tpc + 1e-10), dim=-1)).mean()     # get_group_perplexity (:456-459)
+            frac = float(out["perplexity"]) / self.C                                     # one host read, as the reference's `if frac < reg[0]`
+            w = 0.5 if frac < reg[0] else max(0.5 - 0.5 / (reg[1] - reg[0]) * (frac - reg[0]), 0.0)
+            out["codebook_ent_weight"] = torch.tensor(w, device=z.device)
+            out["diversity_loss"] = -diversity_weight * w * entropy
+        else:
+            out["diversity_loss"] = -diversity_weight * out["entropy_to_max"]
+        return out
 
     # ---- dead codes ------------------------------------------------------------------------------------------------------
     def expired_codes(self) -> torch.Tensor:

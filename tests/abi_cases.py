@@ -191,6 +191,47 @@ def _(alloc):
     return "selftok_vq_tpc_update_f32", [tpc.ptr, alloc(ids).ptr, 3, 4, 32, 0.75, I32, None], dict(tpc=tpc)
 
 
+def _softmax_inputs(seed, B, K, C):
+    r = rng(seed)
+    return f32(r.standard_normal((B, K, 16))), unit_rows(r.standard_normal((C, 16)))
+
+
+def _softmax_stats(B, K, C, flags=0, colmean=True, seed=13):
+    def fn(alloc):
+        z, cb = _softmax_inputs(seed, B, K, C)
+        if flags & PRENORMED:
+            z = unit_rows(z)
+        rows, cm = alloc(np.zeros((B * K, 2), np.float32)), alloc(np.zeros((K, C), np.float32))
+        ws = alloc(np.zeros(8 * B * K * 36, np.float32))
+        outs = dict(rowstats=rows)
+        if colmean:
+            outs["colmean"] = cm
+        return "selftok_vq_softmax_stats_f32", [alloc(z).ptr, alloc(cb).ptr, rows.ptr, cm.ptr if colmean else None, ws.ptr, B, K, C, 16, 10.0, flags, None], outs
+    return fn
+
+
+def _softmax_backward(B, K, C, flags=0, seed=14):
+    def fn(alloc):
+        z, cb = _softmax_inputs(seed, B, K, C)
+        if flags & PRENORMED:
+            z = unit_rows(z)
+        g = f32(rng(seed + 1).standard_normal((K, C)))
+        rows, grad = alloc(np.zeros((B * K, 2), np.float32)), alloc(np.zeros((B, K, 16), np.float32))
+        ws = alloc(np.zeros(8 * B * K * 36, np.float32))
+        zz, cc = alloc(z), alloc(cb)
+        pre = [("selftok_vq_softmax_stats_f32", [zz.ptr, cc.ptr, rows.ptr, None, ws.ptr, B, K, C, 16, 10.0, flags, None])]
+        return ("selftok_vq_softmax_backward_f32", [zz.ptr, cc.ptr, rows.ptr, alloc(g).ptr, grad.ptr, ws.ptr, B, K, C, 16, 10.0, flags, None], dict(grad_z=grad), pre)
+    return fn
+
+
+case("vq_softmax_stats", exact=False, tol=2e-6)(_softmax_stats(5, 7, 300))
+case("vq_softmax_stats_ragged_large", exact=False, tol=2e-6)(_softmax_stats(70, 3, 2051))
+case("vq_softmax_stats_prenormed_rows_only", exact=False, tol=2e-6)(_softmax_stats(4, 9, 512, PRENORMED, colmean=False))
+case("vq_softmax_backward", exact=False, tol=5e-6)(_softmax_backward(5, 7, 300))
+case("vq_softmax_backward_ragged_large", exact=False, tol=5e-6)(_softmax_backward(70, 3, 2051))
+case("vq_softmax_backward_prenormed", exact=False, tol=5e-6)(_softmax_backward(4, 9, 512, PRENORMED))
+
+
 # ---- fused residual / LayerNorm / modulate ----------------------------------------------------------------------------------------
 def _ln(H, B, T, resid, gated, mod, per_token, split=False, seed=11):
     def fn(alloc):

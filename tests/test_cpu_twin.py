@@ -188,6 +188,42 @@ def test_vq_training_statistics_match_the_one_hot_form(twin):
         np.testing.assert_allclose(tpc, ref, rtol=1e-6, atol=1e-7)
 
 
+def test_entropy_regularisers_match_reference_golden(twin):
+    """vq_entropy.npz = the reference's calc_entropy / calc_ema_entropy / get_group_perplexity on its own CosineSimCodebook's distances and
+    torch autograd through them (tools/oracle/gen_golden.py vq_entropy).  Here: the two reductions from the C ABI, the small [K, C]
+    epilogue in torch (autograd gives g = dF/d colmean), the backward from the C ABI."""
+    g = np.load(os.path.join(GOLD, "vq_entropy.npz"))
+    C, K, B = 2048, 128, 6
+    embed0 = np.ascontiguousarray(F.normalize(synth.hash_normalish(int(g["embed0_seed"]), (C, 16)), dim=-1).numpy())
+    ws = np.zeros(twin.selftok_vq_softmax_workspace_bytes(B * K) // 4, np.float32)
+    for case in (0, 1):
+        dw, ratio, r0, r1, w = g[f"args_{case}"]
+        z = np.ascontiguousarray(synth.hash_normalish(int(g[f"seed_{case}"]), (B, K, 16)).numpy())
+        rows, cm = np.zeros((B * K, 2), np.float32), np.zeros((K, C), np.float32)
+        assert twin.selftok_vq_softmax_stats_f32(ptr(z), ptr(embed0), ptr(rows), ptr(cm), ptr(ws), B, K, C, 16, 10.0, 0, None) == 0
+        np.testing.assert_allclose(rows[:, 1].mean(), g[f"entropy_to_min_{case}"], rtol=2e-6)
+        apk = torch.from_numpy(cm).requires_grad_(True)
+        ap = apk.mean(0)
+        e_max = -(ap * ap.log()).sum()
+        np.testing.assert_allclose(e_max.item(), g[f"entropy_to_max_{case}"], rtol=2e-6)
+        tpc = torch.from_numpy(g[f"tpc_{case}"])
+        ema = tpc * ratio + apk * (1 - ratio)
+        c_ent = (-(ema * ema.log()).sum(-1)).mean()
+        grp = torch.stack([t.mean(0) for t in ema.tensor_split(64, dim=0)])
+        g_ent = (-(grp * grp.log()).sum(-1)).mean()
+        np.testing.assert_allclose(c_ent.item(), g[f"codebook_entropy_{case}"], rtol=2e-6)
+        np.testing.assert_allclose(g_ent.item(), g[f"group_entropy_{case}"], rtol=2e-6)
+        loss = -dw * w * 0.5 * (c_ent + g_ent)
+        np.testing.assert_allclose(loss.item(), g[f"diversity_loss_{case}"], rtol=3e-6)
+        for F_, key in ((loss, f"grad_z_{case}"), (-dw * e_max, f"grad_z_entropy_to_max_{case}")):
+            (gc,) = torch.autograd.grad(F_, apk, retain_graph=True)
+            gc = np.ascontiguousarray(gc.float().numpy())
+            gz = np.zeros((B, K, 16), np.float32)
+            assert twin.selftok_vq_softmax_backward_f32(ptr(z), ptr(embed0), ptr(rows), ptr(gc), ptr(gz), ptr(ws), B, K, C, 16, 10.0, 0, None) == 0
+            ref = g[key]
+            assert np.abs(gz - ref).max() <= 2e-5 * np.abs(ref).max(), (key, np.abs(gz - ref).max(), np.abs(ref).max())
+
+
 # ---- fused residual / LayerNorm / modulate against torch-CPU --------------------------------------------------------------------------
 @pytest.mark.parametrize("H", [64, 256, 512, 1024, 1536])
 @pytest.mark.parametrize("per_token", [False, True])

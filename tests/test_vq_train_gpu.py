@@ -124,3 +124,96 @@ def test_codebook_step_two_ranks_installs_identical_codes_from_the_global_batch(
     assert e0 == e1 and c0 == c1                        # identical code book and statistics on both ranks
     assert d0 < 1e-5 and d1 < 1e-5                      # every replacement is a unit-norm vector of the global batch
     assert s0 == s1 and abs(s0[0] - s0[1]) <= 1 + n0 // 50 and min(s0) > 0     # ... half of them from each rank's shard
+
+
+def _entropy_epilogue_torch(z, embed, tpc, dw, ratio, w, dtype=torch.float32):
+    """the reference's formulation on the materialised [N, C] tensor (vector_quantize_pytorch.py:89-118, 1006-1031), on the GPU"""
+    embed, tpc = embed.to(dtype), tpc.to(dtype)
+    p = (torch.nn.functional.normalize(z.to(dtype), dim=-1).reshape(-1, z.shape[-1]) @ embed.t() * 10.0).softmax(dim=-1)
+    ap = p.mean(0)
+    e_max = -(ap * ap.log()).sum()
+    e_min = (-(p * p.log()).sum(-1)).mean()
+    apk = p.reshape(z.shape[0], z.shape[1], -1).mean(0)
+    ema = tpc * ratio + apk * (1 - ratio)
+    c_ent = (-(ema * ema.log()).sum(-1)).mean()
+    grp = torch.stack([t.mean(0) for t in ema.tensor_split(64, dim=0)])
+    g_ent = (-(grp * grp.log()).sum(-1)).mean()
+    return dict(entropy_to_max=e_max, entropy_to_min=e_min, codebook_entropy=c_ent, group_entropy=g_ent, diversity_loss=-dw * w * 0.5 * (c_ent + g_ent))
+
+
+def test_entropy_regularisers_vs_reference():
+    """SURVEY 8f rank 4, the part that was missing through round 2: calc_entropy / calc_ema_entropy / the perplexity-ramped diversity loss and
+    its gradient with respect to the features, against the reference's own functions + torch autograd (vq_entropy.npz)."""
+    g = np.load(os.path.join(GOLD, "vq_entropy.npz"))
+    Ce, Ke, Be = 2048, 128, 6
+    embed0 = l2norm(synth.hash_normalish(int(g["embed0_seed"]), (Ce, D))).cuda()
+    for case in (0, 1):
+        dw, ratio, r0, r1, w = (float(v) for v in g[f"args_{case}"])
+        cb = CodebookEMA(embed0, Ke)
+        cb.timestep_p_over_c = torch.from_numpy(g[f"tpc_{case}"]).cuda()
+        z = synth.hash_normalish(int(g[f"seed_{case}"]), (Be, Ke, D)).cuda().requires_grad_(True)
+        out = cb.entropy_regularisers(z, dw, True, ratio, (r0, r1))
+        assert abs(float(out["codebook_ent_weight"]) - w) < 1e-6
+        for k in ("entropy_to_max", "entropy_to_min", "codebook_entropy", "group_entropy", "perplexity", "diversity_loss"):
+            ref = float(g[f"{k}_{case}"])
+            assert abs(out[k].item() - ref) <= 3e-6 * abs(ref), (k, out[k].item(), ref)
+        out["diversity_loss"].backward()
+        ref = torch.from_numpy(g[f"grad_z_{case}"])
+        err = float((z.grad.cpu() - ref).abs().max()) / float(ref.abs().max())
+        print(f"case {case}: d(diversity_loss)/dz max err {err:.2e} of max |grad| {float(ref.abs().max()):.2e}")
+        assert err < 2e-5
+        z2 = z.detach().clone().requires_grad_(True)                                   # the smart_re_K == 0 branch: -w H(mean p)
+        cb.entropy_regularisers(z2, dw, False)["diversity_loss"].backward()
+        ref = torch.from_numpy(g[f"grad_z_entropy_to_max_{case}"])
+        assert float((z2.grad.cpu() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+def test_entropy_regularisers_full_size_vs_materialised():
+    """the tokenizer's shapes (C = 32768, K = 512) at B = 16: the fused passes against the reference's formulation on the materialised
+    [8192, 32768] tensor on the same GPU (1 GiB per copy; the reference shape B = 64 needs 4.3 GB per copy), values and gradient; timings
+    of both are printed."""
+    Bf, Kf, Cf = 16, 512, 32768
+    embed = l2norm(synth.hash_normalish(0xC0DE, (Cf, D))).cuda()
+    z0 = (synth.hash_normalish(0x5EED, (Bf, Kf, D)) * 3.0).cuda()
+    cb = CodebookEMA(embed, Kf)
+    cb.step(z0, freeze_codebook=True)                                                    # a realistic timestep_p_over_c
+    dw, ratio, w = 0.3, 0.7, 0.5
+
+    def fused():
+        zz = z0.clone().requires_grad_(True)
+        o = cb.entropy_regularisers(zz, dw, True, ratio, (0.25, 0.5))
+        o["diversity_loss"].backward()
+        return zz, o
+
+    def materialised():
+        zz = z0.clone().requires_grad_(True)
+        o = _entropy_epilogue_torch(zz, embed, cb.timestep_p_over_c, dw, ratio, w)
+        o["diversity_loss"].backward()
+        return zz, o
+
+    def timed(fn):
+        fn()                                                                             # warm-up: allocator, first launches
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); res = fn(); b.record(); torch.cuda.synchronize()
+        return res, a.elapsed_time(b)
+
+    (z, out), ms_fused = timed(fused)
+    assert abs(float(out["codebook_ent_weight"]) - w) < 1e-6
+    (zr, ref), ms_torch = timed(materialised)
+    print(f"fused forward+backward {ms_fused:.1f} ms, materialised torch fp32 {ms_torch:.1f} ms (N = {Bf * Kf}, C = {Cf})")
+    z64 = z0.clone().requires_grad_(True)                                                # the yardstick: the same formulation in fp64
+    ref64 = _entropy_epilogue_torch(z64, embed, cb.timestep_p_over_c, dw, ratio, float(out["codebook_ent_weight"]), torch.float64)
+    ref64["diversity_loss"].backward()
+    for k, v in ref64.items():
+        assert abs(float(out[k]) - float(v)) <= 3e-6 * abs(float(v)), (k, float(out[k]), float(v))
+        assert abs(float(ref[k]) - float(v)) <= 3e-5 * abs(float(v)), k
+    gmax = float(z64.grad.abs().max())
+    err, err32 = float((z.grad - z64.grad).abs().max()) / gmax, float((zr.grad - z64.grad).abs().max()) / gmax
+    print(f"gradient max err vs fp64: fused {err:.2e}, materialised torch fp32 {err32:.2e} (of max |grad| {gmax:.2e})")
+    assert err < 2e-5 and err <= 2 * err32 + 1e-6
+    # kernel-level: row statistics and column means against the materialised softmax
+    rows, cm = ops.vq_softmax_stats(z0, embed)
+    p = (torch.nn.functional.normalize(z0, dim=-1).reshape(-1, D) @ embed.t() * 10.0).softmax(dim=-1)
+    torch.testing.assert_close(rows[:, 1], -(p * p.log()).sum(-1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(cm, p.reshape(Bf, Kf, Cf).mean(0), rtol=2e-5, atol=1e-9)

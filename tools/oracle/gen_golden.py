@@ -592,6 +592,62 @@ def stage_vqtrain():
     np.savez_compressed(os.path.join(GOLD, "vqtrain.npz"), **out)
 
 
+def stage_vq_entropy():
+    """entropy regularisers of the training forward (vector_quantize_pytorch.py:1006-1031): the reference's OWN calc_entropy /
+    calc_ema_entropy / get_group_perplexity on the `distances` its CosineSimCodebook returns in train() mode (after that forward's
+    timestep_p_over_c update), and torch autograd through them for d(diversity_loss)/dz.  Pins oracle/vq_train.py:entropy_terms.
+    (VectorQuantize.forward itself cannot reach these lines: it passes min_ref= to calc_entropy, a TypeError.)"""
+    H.install()
+    import torch.distributed as dist
+    from oracle import vq_train as VT
+    from mimogpt.models.selftok.vector_quantize_pytorch import CosineSimCodebook, gumbel_sample, l2norm, calc_entropy, calc_ema_entropy
+    from functools import partial
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    C, D, K, B = 2048, 16, 128, 6
+    gs = partial(gumbel_sample, stochastic=False, reinmax=False, straight_through=False)
+    cb = CosineSimCodebook(dim=D, codebook_size=C, kmeans_init=False, decay=0.99, threshold_ema_dead_code=0, use_ddp=False,
+                           gumbel_sample=gs, sample_codebook_temp=1.0, smart_re_K=K)
+    embed0 = l2norm(synth.hash_normalish(0xC0DEB00C, (C, D)))
+    cb.embed.data.copy_(embed0[None]); cb.embed_avg.data.copy_(embed0[None])
+    cb.train()
+    with torch.enable_grad():                                        # the generator runs with autograd off
+        return _vq_entropy_cases(cb, embed0, l2norm, calc_entropy, calc_ema_entropy, VT, C, D, K, B)
+
+
+def _vq_entropy_cases(cb, embed0, l2norm, calc_entropy, calc_ema_entropy, VT, C, D, K, B):
+    out = {}
+    worst = 0.0
+    for case, (dw, ratio, reg, seed) in enumerate(((0.1, 0.7, [0.25, 0.5], 0xE17), (1.0, 0.4, [0.001, 0.9], 0xE18))):
+        z = synth.hash_normalish(seed, (B, K, D)).requires_grad_(True)
+        _, ids, distances, _ = cb(l2norm(z), freeze_codebook=True)                 # [1, B, K, C]; updates timestep_p_over_c first (:568-578)
+        tpc = cb.timestep_p_over_c[0].clone()
+        scaled = distances * 10.0
+        e_max, e_min = calc_entropy(scaled.flatten(end_dim=-2))
+        c_ent, g_ent = calc_ema_entropy(scaled, tpc, ratio_d=1. - ratio)
+        perp = cb.get_group_perplexity().mean()
+        frac = perp / C
+        w = 0.5 if frac < reg[0] else max((0.5 - 0.5 / (reg[1] - reg[0]) * (frac - reg[0])), 0.0)
+        loss = -dw * w * (0.5 * (c_ent + g_ent))
+        (gz,) = torch.autograd.grad(loss, z, retain_graph=True)
+        (gz_max,) = torch.autograd.grad(-dw * e_max, z)                              # the smart_re_K == 0 branch (:1028)
+        o = VT.entropy_terms(z, embed0, tpc, dw, True, ratio, reg)
+        (gz_o,) = torch.autograd.grad(o["diversity_loss"], z)
+        ref = dict(entropy_to_max=e_max, entropy_to_min=e_min, codebook_entropy=c_ent, group_entropy=g_ent, perplexity=perp, diversity_loss=loss)
+        for k, v in ref.items():
+            worst = max(worst, maxdiff(v.detach(), o[k].detach()))
+            out[f"{k}_{case}"] = np.float32(float(v))
+        worst = max(worst, maxdiff(gz, gz_o) / float(gz.abs().max()))
+        out[f"tpc_{case}"], out[f"grad_z_{case}"], out[f"grad_z_entropy_to_max_{case}"] = tpc.numpy(), gz.numpy(), gz_max.numpy()
+        out[f"ids_{case}"] = ids.numpy()
+        out[f"args_{case}"] = np.asarray([dw, ratio, reg[0], reg[1], float(w)], np.float64)
+        out[f"seed_{case}"] = np.int64(seed)
+    out["embed0_seed"] = np.int64(0xC0DEB00C)
+    report("vq_entropy", cases=2, worst_oracle_vs_reference=worst)
+    np.savez_compressed(os.path.join(GOLD, "vq_entropy.npz"), **out)
+
+
 def stage_rmsnorm_rotary():
     """the two optional / off-path element-wise ops of SURVEY 8a (a31, a32), from the reference's OWN classes: RMSNorm (modules.py:
     49-95; inactive in the shipped configs, qk_norm unset) with and without the learnable scale, and apply_rotary_emb
@@ -624,7 +680,7 @@ def stage_rmsnorm_rotary():
     report("rmsnorm_rotary", arrays=sorted(out), rms_absmax=float(np.abs(out["rms_affine"]).max()), rot_absmax=float(np.abs(out["rot_full"]).max()))
 
 
-STAGES = dict(rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
+STAGES = dict(vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
               vae=stage_vae, pipeline=stage_pipeline, pipeline16=stage_pipeline16, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024, vqtrain=stage_vqtrain)
 
 if __name__ == "__main__":
