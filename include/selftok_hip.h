@@ -226,6 +226,28 @@ int selftok_latent_process_out(const float* z, void* out_bf16, long n, float shi
 /* norm_ip(recons,-1,1) in place (SelftokPipeline.py:135-137,290). */
 int selftok_clamp01_bf16(void* img, long n, hipStream_t stream);
 
+/* ---- SD3-VAE convolutions and GroupNorm, channels-last (round 3; csrc/conv.hip) -----------------------------------------------
+ * The bf16 convolutions of the VAE (ResnetBlock conv1/conv2/nin_shortcut, Downsample, Upsample, conv_in, conv_out:
+ * sd3/sd3_impls.py:228-262, 286-318, 340-456) as one implicit-GEMM kernel on the bf16 matrix cores with the reference's CPU
+ * arithmetic: fp32 accumulation of bf16 products, bias added inside it, ONE rounding to bf16.
+ *   x [B, H, W, Cin] bf16 (Cin % 8 == 0), out / residual [B, Ho, Wo, ldo] bf16, channels [0, Cstore) written (Cstore % 4 == 0,
+ *   Cout <= Cstore <= ldo; channels >= Cout are zero), bias [Cout] bf16 or NULL.
+ *   ksize 3: padding 1; stride 2 (ksize 3 only) = Downsample's F.pad(x, (0,1,0,1)) + stride-2 convolution, Ho = H / 2.
+ *   upsample 1: the input is read as its nearest-neighbour 2x upsample (Upsample.forward), Ho = 2 H; never materialised.
+ *   residual: out = bf16(bf16(conv + bias) + residual), the two roundings of `x + h` (ResnetBlock.forward :262).
+ * Weights: the checkpoint's [Cout, Cin, k, k] bf16 tensor packed once by selftok_conv2d_pack_weight_bf16 into an opaque image of
+ * selftok_conv2d_packed_bytes(Cout, Cin, ksize, bn) bytes; bn = output channels per workgroup, 128 (Cout >= 64) or 32 (narrow
+ * outputs: encoder conv_out, decoder conv_out); the same bn must be passed to the convolution. */
+size_t selftok_conv2d_packed_bytes(int Cout, int Cin, int ksize, int bn);
+int selftok_conv2d_pack_weight_bf16(const void* w, void* packed, int Cout, int Cin, int ksize, int bn, hipStream_t stream);
+int selftok_conv2d_nhwc_bf16(const void* x, const void* packed, const void* bias, const void* residual, void* out, int B, int H, int W, int Cin, int Cout,
+                             int Cstore, int ldo, int ksize, int stride, int upsample, int bn, hipStream_t stream);
+/* GroupNorm(groups, eps, affine) [+ SiLU] on [B, HW, C] bf16 (channels-last): selftok_groupnorm_silu_bf16's arithmetic, statistics
+ * accumulated in fp64 and reduced in a fixed order (deterministic).  C / 8 must divide 256, (C / groups) % 4 == 0. */
+size_t selftok_groupnorm_nhwc_workspace_bytes(int B, int HW, int C);
+int selftok_groupnorm_silu_nhwc_bf16(const void* x, const void* weight, const void* bias, void* out, void* workspace, int B, int HW, int C, int groups,
+                                     float eps, int apply_silu, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -743,3 +743,97 @@ int selftok_clamp01_bf16(void* imgv, long n, hipStream_t s)
     }
     return SELFTOK_OK;
 }
+
+/* ================================================================================================================================
+ * channels-last bf16 convolution and GroupNorm (csrc/conv.hip): plain loops, double accumulation (the GPU sums fp32 in matrix-core
+ * order; both round once to bf16, so they agree except at rounding ties of the sum)
+ * ============================================================================================================================== */
+size_t selftok_conv2d_packed_bytes(int Cout, int Cin, int ksize, int bn)
+{
+    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3) || (bn != 32 && bn != 128)) return 0;
+    return (size_t)((Cout + bn - 1) / bn) * ((Cin + 31) / 32) * ksize * ksize * bn * 32 * sizeof(uint16_t);
+}
+static inline size_t conv_pk_index(int co, int c, int tap, int taps, int bn, int ncb)
+{
+    return ((((size_t)(co / bn) * ncb + c / 32) * taps + tap) * bn + co % bn) * 32 + c % 32;
+}
+int selftok_conv2d_pack_weight_bf16(const void* wv, void* pv, int Cout, int Cin, int ksize, int bn, hipStream_t s)
+{
+    (void)s;
+    const size_t bytes = selftok_conv2d_packed_bytes(Cout, Cin, ksize, bn);
+    if (!wv || !pv || bytes == 0) return fail("conv2d_pack_weight: bad argument (ksize 1|3, bn 32|128)");
+    const uint16_t* w = (const uint16_t*)wv;
+    uint16_t* p = (uint16_t*)pv;
+    memset(p, 0, bytes);
+    const int taps = ksize * ksize, ncb = (Cin + 31) / 32;
+    for (int co = 0; co < Cout; ++co) for (int c = 0; c < Cin; ++c) for (int t = 0; t < taps; ++t)
+        p[conv_pk_index(co, c, t, taps, bn, ncb)] = w[((size_t)co * Cin + c) * taps + t];
+    return SELFTOK_OK;
+}
+int selftok_conv2d_nhwc_bf16(const void* xv, const void* pv, const void* bv, const void* rv, void* ov, int B, int H, int W, int Cin, int Cout,
+                             int Cstore, int ldo, int ksize, int stride, int upsample, int bn, hipStream_t s)
+{
+    (void)s;
+    if (!xv || !pv || !ov || B < 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 7) || Cout <= 0 || Cstore < Cout || (Cstore & 3) || ldo < Cstore || (ldo & 3) ||
+        (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1) || (upsample != 0 && upsample != 1) || (bn != 32 && bn != 128) ||
+        (upsample && stride != 1) || (stride == 2 && bn != 128))
+        return fail("conv2d_nhwc_bf16: bad argument (Cin % 8, Cstore % 4, ldo % 4, ksize 1|3, stride 1|2 (3x3 only), bn 32|128)");
+    const uint16_t *x = (const uint16_t*)xv, *pk = (const uint16_t*)pv, *bias = (const uint16_t*)bv, *res = (const uint16_t*)rv;
+    uint16_t* out = (uint16_t*)ov;
+    const int taps = ksize * ksize, ncb = (Cin + 31) / 32, Hi = H << upsample, Wi = W << upsample;
+    const int Ho = stride == 2 ? Hi / 2 : Hi, Wo = stride == 2 ? Wi / 2 : Wi, pad = (stride == 1 && ksize == 3) ? 1 : 0;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b) for (int oy = 0; oy < Ho; ++oy) for (int ox = 0; ox < Wo; ++ox) {
+        const size_t pix = ((size_t)b * Ho + oy) * Wo + ox;
+        for (int co = 0; co < Cstore; ++co) {
+            double acc = 0.0;
+            if (co < Cout) {
+                for (int t = 0; t < taps; ++t) {
+                    const int iy = oy * stride - pad + t / ksize, ix = ox * stride - pad + t % ksize;
+                    if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
+                    const uint16_t* xp = x + (((size_t)b * H + (iy >> upsample)) * W + (ix >> upsample)) * Cin;
+                    for (int c = 0; c < Cin; ++c) acc += (double)bf2f(xp[c]) * (double)bf2f(pk[conv_pk_index(co, c, t, taps, bn, ncb)]);
+                }
+                if (bias) acc += (double)bf2f(bias[co]);
+            }
+            float v = rbf((float)acc);
+            if (res) v = rbf(v + bf2f(res[pix * ldo + co]));
+            out[pix * ldo + co] = f2bf(v);
+        }
+    }
+    return SELFTOK_OK;
+}
+size_t selftok_groupnorm_nhwc_workspace_bytes(int B, int HW, int C)
+{
+    if (B <= 0 || HW <= 0 || C <= 0) return 0;
+    const size_t nblk = (size_t)(HW + 2047) / 2048;
+    return (size_t)B * nblk * (C / 4) * 2 * sizeof(double) + (size_t)B * 64 * 2 * sizeof(float) + 256;
+}
+int selftok_groupnorm_silu_nhwc_bf16(const void* xv, const void* wv, const void* bv, void* ov, void* workspace, int B, int HW, int C, int groups,
+                                     float eps, int apply_silu, hipStream_t s)
+{
+    (void)s;
+    if (!xv || !wv || !bv || !ov || !workspace || B < 0 || HW <= 0 || groups <= 0 || groups > 64 || C % groups || ((C / groups) & 3) || (C & 7) || C > 2048 || (256 % (C >> 3)))
+        return fail("groupnorm_silu_nhwc: need C % groups == 0, (C / groups) % 4 == 0, C / 8 a divisor of 256, groups <= 64");
+    const uint16_t *x = (const uint16_t*)xv, *w = (const uint16_t*)wv, *bb = (const uint16_t*)bv;
+    uint16_t* out = (uint16_t*)ov;
+    const int cpg = C / groups;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b) for (int g = 0; g < groups; ++g) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int p = 0; p < HW; ++p) for (int c = g * cpg; c < (g + 1) * cpg; ++c) { const double d = bf2f(x[((size_t)b * HW + p) * C + c]); s1 += d; s2 += d * d; }
+        const double n = (double)HW * cpg, mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0) var = 0;
+        const float meanf = (float)mean;
+        const float varf = (float)(var + (mean - (double)meanf) * (mean - (double)meanf));
+        const float rstd = 1.0f / sqrtf(varf + eps);
+        for (int p = 0; p < HW; ++p) for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const size_t i = ((size_t)b * HW + p) * C + c;
+            float y = rbf((bf2f(x[i]) - meanf) * rstd * bf2f(w[c]) + bf2f(bb[c]));
+            if (apply_silu) y = y / (1.0f + expf(-y));
+            out[i] = f2bf(y);
+        }
+    }
+    return SELFTOK_OK;
+}

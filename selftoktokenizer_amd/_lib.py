@@ -52,6 +52,11 @@ SIGNATURES = {
     "selftok_latent_process_in": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     "selftok_latent_process_out": (_i, [_vp, _vp, _l, _f, _f, _vp]),
     "selftok_clamp01_bf16": (_i, [_vp, _l, _vp]),
+    "selftok_conv2d_packed_bytes": (_sz, [_i, _i, _i, _i]),
+    "selftok_conv2d_pack_weight_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "selftok_conv2d_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
+    "selftok_groupnorm_nhwc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "selftok_groupnorm_silu_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
 }
 
 

@@ -5,6 +5,8 @@ libselftok_hip.so, and returns torch tensors.  PyTorch is only the allocator / s
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 
 from . import _lib
@@ -499,6 +501,57 @@ def groupnorm_silu(x, weight, bias, groups=32, eps=1e-6, silu_act=True):
     out = torch.empty_like(x)
     _lib.check(_lib.load().selftok_groupnorm_silu_bf16(_p(x), _p(weight), _p(bias), _p(out), B, C, H * W, groups, eps,
                                                        1 if silu_act else 0, _stream()), "selftok_groupnorm_silu_bf16")
+    return out
+
+
+class PackedConv:
+    """one convolution's weights in the opaque image selftok_conv2d_nhwc_bf16 reads (csrc/conv.hip) + its bias and geometry"""
+    __slots__ = ("packed", "bias", "cout", "cin", "ksize", "bn")
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        _need_cuda(weight, bias)
+        assert weight.dtype == torch.bfloat16 and weight.dim() == 4 and weight.shape[2] == weight.shape[3] and weight.shape[2] in (1, 3)
+        w = weight.contiguous()
+        self.cout, self.cin, self.ksize = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+        self.bn = 128 if self.cout >= 64 else 32
+        lib = _lib.load()
+        self.packed = torch.empty(lib.selftok_conv2d_packed_bytes(self.cout, self.cin, self.ksize, self.bn), dtype=torch.uint8, device=w.device)
+        _lib.check(lib.selftok_conv2d_pack_weight_bf16(_p(w), _p(self.packed), self.cout, self.cin, self.ksize, self.bn, _stream()), "selftok_conv2d_pack_weight_bf16")
+        self.bias = None if bias is None else bias.to(torch.bfloat16).contiguous()
+
+
+def conv2d_nhwc(x: torch.Tensor, pc: PackedConv, stride: int = 1, upsample: bool = False, residual: Optional[torch.Tensor] = None,
+                cstore: Optional[int] = None) -> torch.Tensor:
+    """x [B,H,W,Cin'] bf16 channels-last (Cin' = the layer's Cin rounded up to a multiple of 8, extra channels ignored) ->
+    [B,Ho,Wo,cstore] bf16: the convolution with the reference's CPU arithmetic (fp32 accumulate incl. the bias, one rounding).
+    stride 2 = Downsample (pad right/bottom + stride-2), upsample = nearest 2x applied to the input on the fly, residual [B,Ho,Wo,cstore]
+    is added with its own bf16 rounding (ResnetBlock's `x + h`)."""
+    _need_cuda(x, residual)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 4
+    B, H, W, Cin = x.shape
+    assert Cin % 8 == 0 and (Cin + 31) // 32 == (pc.cin + 31) // 32 and Cin >= pc.cin, (Cin, pc.cin)
+    cs = (pc.cout + 3) // 4 * 4 if cstore is None else cstore
+    Hi, Wi = (H * 2, W * 2) if upsample else (H, W)
+    Ho, Wo = (Hi // 2, Wi // 2) if stride == 2 else (Hi, Wi)
+    out = torch.empty(B, Ho, Wo, cs, dtype=torch.bfloat16, device=x.device)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == torch.bfloat16
+    _lib.check(_lib.load().selftok_conv2d_nhwc_bf16(_p(x), _p(pc.packed), _p(pc.bias), _p(residual), _p(out), B, H, W, Cin, pc.cout, cs, cs, pc.ksize, stride,
+                                                    1 if upsample else 0, pc.bn, _stream()), "selftok_conv2d_nhwc_bf16")
+    return out
+
+
+def groupnorm_silu_nhwc(x, weight, bias, groups=32, eps=1e-6, silu_act=True):
+    """GroupNorm [+ SiLU] on a channels-last bf16 tensor [B, ..., C]"""
+    _need_cuda(x, weight, bias)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    ws = torch.empty(lib.selftok_groupnorm_nhwc_workspace_bytes(B, HW, C), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.selftok_groupnorm_silu_nhwc_bf16(_p(x), _p(weight), _p(bias), _p(out), _p(ws), B, HW, C, groups, eps, 1 if silu_act else 0, _stream()),
+               "selftok_groupnorm_silu_nhwc_bf16")
     return out
 
 

@@ -491,6 +491,61 @@ def _(alloc):
     return "selftok_clamp01_bf16", [img.ptr, 4096, None], dict(img=img)
 
 
+# ---- channels-last bf16 convolution / GroupNorm (csrc/conv.hip) -------------------------------------------------------------------
+def _conv(B, H, W, Cin, Cout, ks=3, stride=1, up=0, bn=128, resid=False, cin_store=None, cstore=None, seed=60):
+    def fn(alloc):
+        r = rng(seed + Cin + Cout)
+        cin_s = cin_store or Cin
+        x = to_bf16(r.standard_normal((B, H, W, cin_s)))
+        w = to_bf16(r.standard_normal((Cout, Cin, ks, ks)) / np.sqrt(Cin * ks * ks))
+        bias = to_bf16(r.standard_normal(Cout))
+        cs = cstore or (Cout + 3) // 4 * 4
+        Hi, Wi = H << up, W << up
+        Ho, Wo = (Hi // 2, Wi // 2) if stride == 2 else (Hi, Wi)
+        packed = alloc(np.zeros(((Cout + bn - 1) // bn) * ((Cin + 31) // 32) * ks * ks * bn * 32, np.uint16))
+        out = alloc(np.zeros((B, Ho, Wo, cs), np.uint16))
+        res = alloc(to_bf16(r.standard_normal((B, Ho, Wo, cs)))) if resid else None
+        pre = [("selftok_conv2d_pack_weight_bf16", [alloc(w).ptr, packed.ptr, Cout, Cin, ks, bn, None])]
+        return ("selftok_conv2d_nhwc_bf16", [alloc(x).ptr, packed.ptr, alloc(bias).ptr, res.ptr if resid else None, out.ptr, B, H, W, cin_s, Cout, cs, cs, ks, stride, up, bn, None],
+                dict(out_bf16=out), pre)
+    return fn
+
+
+@case("conv2d_pack_weight")
+def _(alloc):
+    w = to_bf16(rng(61).standard_normal((40, 24, 3, 3)))
+    packed = alloc(np.zeros(2 * 1 * 9 * 32 * 32, np.uint16))
+    return "selftok_conv2d_pack_weight_bf16", [alloc(w).ptr, packed.ptr, 40, 24, 3, 32, None], dict(packed=packed)
+
+
+case("conv2d_3x3_128_128", exact=False)(_conv(2, 16, 32, 128, 128))
+case("conv2d_3x3_residual_ragged_tile", exact=False, tol=2.0 ** -5)(_conv(2, 10, 40, 64, 128, resid=True))       # tol: a 1-ulp flip of the convolution before x + h is absolute, not relative
+case("conv2d_3x3_conv_in_3_channels", exact=False)(_conv(1, 16, 32, 3, 128, cin_store=8))
+case("conv2d_3x3_latent_16_to_512", exact=False)(_conv(1, 8, 32, 16, 512))
+case("conv2d_1x1_shortcut", exact=False)(_conv(2, 12, 32, 128, 256, ks=1))
+case("conv2d_3x3_stride2_downsample", exact=False)(_conv(2, 16, 64, 128, 128, stride=2))
+case("conv2d_3x3_upsample", exact=False)(_conv(1, 8, 16, 256, 256, up=1))
+case("conv2d_3x3_narrow_out_32", exact=False)(_conv(2, 8, 32, 512, 32, bn=32))
+case("conv2d_3x3_conv_out_3", exact=False)(_conv(1, 16, 32, 128, 3, bn=32))
+
+
+def _gn_nhwc(C, silu, HW=24 * 24, B=2):
+    def fn(alloc):
+        r = rng(62 + C)
+        x = to_bf16(r.standard_normal((B, HW, C)) * 2 + 0.3)
+        w, b = to_bf16(1 + 0.2 * r.standard_normal(C)), to_bf16(0.2 * r.standard_normal(C))
+        out = alloc(np.zeros_like(x))
+        nblk = (HW + 2047) // 2048
+        ws = alloc(np.zeros(B * nblk * (C // 4) * 2 * 8 + B * 64 * 8 + 256, np.uint8))
+        return "selftok_groupnorm_silu_nhwc_bf16", [alloc(x).ptr, alloc(w).ptr, alloc(b).ptr, out.ptr, ws.ptr, B, HW, C, 32, 1e-6, silu, None], dict(out_bf16=out)
+    return fn
+
+
+for _C in (128, 256, 512):
+    case(f"groupnorm_silu_nhwc_C{_C}", exact=False)(_gn_nhwc(_C, 1))
+case("groupnorm_nhwc_C512_many_pixels", exact=False)(_gn_nhwc(512, 0, HW=70 * 70))
+
+
 # ---- runner -----------------------------------------------------------------------------------------------------------------------
 def split_planes(blk, rows, K):
     """split-activation buffer (uint16 halfs) -> (hi, lo) fp32 arrays [rows, K] of the live rows"""

@@ -382,3 +382,48 @@ def test_bf16_epilogues_match_torch_cpu(twin):
     assert twin.selftok_clamp01_bf16(ptr(iu), 4096, None) == 0
     ref = im.clone().clamp_(-1, 1).sub_(-1).div_(2)                                             # norm_ip: SelftokPipeline.py:135-137
     np.testing.assert_array_equal(iu, as_u16(ref))
+
+
+def test_nhwc_conv_and_groupnorm_match_torch_cpu_bf16(twin):
+    """the reference runs its VAE in bf16 on the CPU (oneDNN convolutions: fp32 accumulate incl. bias, one rounding): the channels-last entry
+    points against torch-CPU's own bf16 conv2d / group_norm on the same values, for every geometry the VAE uses"""
+    as_u16 = lambda t: np.ascontiguousarray(t.contiguous().view(torch.int16).numpy().view(np.uint16))
+    r = A.rng(70)
+
+    def check(name, got, ref_nchw, frac=0.005, ulps=1):
+        ref = as_u16(ref_nchw.permute(0, 2, 3, 1))
+        a, b = A.from_bf16(got), A.from_bf16(ref)                      # one bf16 ulp, or fp32-sum noise where the sum cancels to ~0
+        assert (np.abs(a - b) <= ulps * 2.0 ** -7 * np.maximum(np.abs(b), 2.0 ** -6)).all() and (got != ref).mean() < frac, (name, float(np.abs(a - b).max()), float((got != ref).mean()))
+
+    for name, (B, H, W, Cin, Cout, ks, stride, up, bn, resid) in dict(
+            plain=(2, 8, 32, 64, 128, 3, 1, 0, 128, False), resid=(1, 6, 20, 32, 64, 3, 1, 0, 128, True), one=(1, 8, 32, 64, 128, 1, 1, 0, 128, False),
+            down=(1, 8, 32, 32, 64, 3, 2, 0, 128, False), up=(1, 4, 16, 32, 64, 3, 1, 1, 128, False), narrow=(1, 8, 32, 64, 3, 3, 1, 0, 32, False)).items():
+        x = torch.from_numpy(A.f32(r.standard_normal((B, Cin, H, W)))).bfloat16()
+        w = torch.from_numpy(A.f32(r.standard_normal((Cout, Cin, ks, ks)) / np.sqrt(Cin * ks * ks))).bfloat16()
+        bias = torch.from_numpy(A.f32(r.standard_normal(Cout))).bfloat16()
+        xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+        if stride == 2:
+            ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w, bias, stride=2, padding=0)
+        else:
+            ref = F.conv2d(xin, w, bias, padding=ks // 2)
+        cs = (Cout + 3) // 4 * 4
+        res = torch.from_numpy(A.f32(r.standard_normal(ref.shape))).bfloat16() if resid else None
+        if resid:
+            ref = res + ref
+        packed = np.zeros(twin.selftok_conv2d_packed_bytes(Cout, Cin, ks, bn) // 2, np.uint16)
+        assert twin.selftok_conv2d_pack_weight_bf16(ptr(as_u16(w)), ptr(packed), Cout, Cin, ks, bn, None) == 0
+        xn, bn_, out = as_u16(x.permute(0, 2, 3, 1)), as_u16(bias), np.zeros((B, ref.shape[2], ref.shape[3], cs), np.uint16)
+        rn = None
+        if resid:
+            rn = np.zeros_like(out); rn[..., :Cout] = as_u16(res.permute(0, 2, 3, 1))
+        rc = twin.selftok_conv2d_nhwc_bf16(ptr(xn), ptr(packed), ptr(bn_), ptr(rn) if resid else None, ptr(out), B, H, W, Cin, Cout, cs, cs, ks, stride, up, bn, None)
+        assert rc == 0, twin.selftok_last_error()
+        check(name, out[..., :Cout], ref)
+        assert not out[..., Cout:].any()
+    for C in (128, 512):
+        x = torch.from_numpy(A.f32(r.standard_normal((2, C, 12, 12)) * 2 + 0.3)).bfloat16()
+        w, b = torch.from_numpy(A.f32(1 + 0.2 * r.standard_normal(C))).bfloat16(), torch.from_numpy(A.f32(0.2 * r.standard_normal(C))).bfloat16()
+        ws = np.zeros(twin.selftok_groupnorm_nhwc_workspace_bytes(2, 144, C), np.uint8)
+        out = np.zeros((2, 144, C), np.uint16)
+        assert twin.selftok_groupnorm_silu_nhwc_bf16(ptr(as_u16(x.permute(0, 2, 3, 1))), ptr(as_u16(w)), ptr(as_u16(b)), ptr(out), ptr(ws), 2, 144, C, 32, 1e-6, 1, None) == 0
+        check(f"gn{C}", out.reshape(2, 12, 12, C), F.silu(F.group_norm(x, 32, w, b, 1e-6)), frac=0.01, ulps=2)     # a 1-ulp flip of the norm through SiLU's second rounding

@@ -50,9 +50,10 @@ def test_gpu_library_matches_cpu_twin(libs, name):
         if spec["exact"]:
             assert same_bits(a, b), (k, np.argwhere(a != b)[:4])
             continue
-        if k.endswith("bf16"):                                     # GroupNorm: the statistics are summed in a different order
-            d = np.abs(a.astype(np.int32) - b.astype(np.int32))
-            assert d.max() <= 1 and (d != 0).mean() < 0.01, (k, d.max(), (d != 0).mean())
+        if k.endswith("bf16"):                                     # GroupNorm statistics / convolution sums in a different order: one
+            fa, fb = A.from_bf16(a), A.from_bf16(b)                # bf16 ulp (two through SiLU's second rounding), or fp32-sum noise where a sum cancels to ~0
+            assert (np.abs(fa - fb) <= np.maximum(2 * 2.0 ** -7 * np.maximum(np.abs(fb), 2.0 ** -6), spec["tol"])).all() and (a != b).mean() < 0.01, (k, float(np.abs(fa - fb).max()), float((a != b).mean()))
+            worst = max(worst, float((a != b).mean()))
             continue
         if a.dtype == np.uint16:                                   # a split activation: compare the values it encodes
             rows, cols = (g.get("_rows"), g.get("_cols")) if "_rows" in g else g["_blk" + k[-1]]
@@ -62,4 +63,6 @@ def test_gpu_library_matches_cpu_twin(libs, name):
         err = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) / scale
         worst = max(worst, err)
         assert err <= spec["tol"], (k, err)
-    print(f"{name}: {'bit-exact' if spec['exact'] else 'max err %.2e of scale (tol %.0e)' % (worst, spec['tol'])}")
+    what = "bit-exact" if spec["exact"] else ("%.4f %% of the bf16 outputs differ (by one ulp)" % (100 * worst) if any(k.endswith("bf16") for k in g) else
+                                             "max err %.2e of scale (tol %.0e)" % (worst, spec["tol"]))
+    print(f"{name}: {what}")
