@@ -59,7 +59,7 @@ def parse(argv=None):
     ap.add_argument("--decoder", default="diffusion", choices=["diffusion", "renderer"])
     ap.add_argument("--decode-steps", type=int, default=None, help="debug only: truncate the 50-step loop (marks the line invalid)")
     ap.add_argument("--gemm", default=None, choices=["fp32", "f16x2"], help="arithmetic of the MMDiT block Linears of the headline number")
-    ap.add_argument("--vae", default=None, choices=["parity", "fast"], help="VAE arithmetic (vae.AutoencoderKLGPU); default parity")
+    ap.add_argument("--vae", default=None, choices=["parity", "miopen", "fast"], help="VAE arithmetic (vae.AutoencoderKLGPU); default parity")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-token-check", action="store_true")
     ap.add_argument("--no-kernel-roofs", action="store_true")

@@ -806,8 +806,7 @@ int selftok_conv2d_nhwc_bf16(const void* xv, const void* pv, const void* bv, con
 size_t selftok_groupnorm_nhwc_workspace_bytes(int B, int HW, int C)
 {
     if (B <= 0 || HW <= 0 || C <= 0) return 0;
-    const size_t nblk = (size_t)(HW + 2047) / 2048;
-    return (size_t)B * nblk * (C / 4) * 2 * sizeof(double) + (size_t)B * 64 * 2 * sizeof(float) + 256;
+    return (size_t)B * 32 * (C / 4) * 2 * sizeof(double) + (size_t)B * 64 * 2 * sizeof(float) + 256;
 }
 int selftok_groupnorm_silu_nhwc_bf16(const void* xv, const void* wv, const void* bv, void* ov, void* workspace, int B, int HW, int C, int groups,
                                      float eps, int apply_silu, hipStream_t s)

@@ -294,9 +294,11 @@ __global__ __launch_bounds__(256) void conv_pack_weight_kernel(const uint16_t* _
 
 // ---- GroupNorm (+ SiLU), NHWC ---------------------------------------------------------------------------------------------------
 // pass 1: per (sample, pixel range) partial sums of x and x^2 per 4-channel quad, in fp64; a 16-byte chunk holds two quads.
-constexpr int GN_PIX_PER_BLOCK = 2048;
+// pixel ranges per sample: enough workgroups to fill the chip on the small feature maps (32 x 32: 4 per sample), at most 32
+__host__ __device__ inline int gn_nblk(int HW) { const int n = HW / 256; return n < 1 ? 1 : (n > 32 ? 32 : n); }
 __global__ __launch_bounds__(256) void gn_nhwc_partial_kernel(const uint16_t* __restrict__ x, double* __restrict__ part, int HW, int C, int nblk)
 {
+    const int GN_PIX_PER_BLOCK = (HW + nblk - 1) / nblk;
     __shared__ double red[256][4];
     const int cpp = C >> 3;                                // 16-byte chunks per pixel (C <= 2048)
     const int b = blockIdx.y, blk = blockIdx.x;
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(256) void gn_nhwc_partial_kernel(const uint16_t* __
     double s0 = 0, q0 = 0, s1 = 0, q1 = 0;
     if (slot < nslot) {
         const uint4* xp = reinterpret_cast<const uint4*>(x + (size_t)b * HW * C);
+#pragma unroll 4
         for (int p = p0 + slot; p < p1; p += nslot) {
             const uint4 v = xp[(size_t)p * cpp + chunk];
             const float e[8] = {bf2f((uint16_t)(v.x & 0xFFFF)), bf2f((uint16_t)(v.x >> 16)), bf2f((uint16_t)(v.y & 0xFFFF)), bf2f((uint16_t)(v.y >> 16)),
@@ -464,8 +467,7 @@ int selftok_conv2d_nhwc_bf16(const void* x, const void* packed, const void* bias
 size_t selftok_groupnorm_nhwc_workspace_bytes(int B, int HW, int C)
 {
     if (B <= 0 || HW <= 0 || C <= 0) return 0;
-    const size_t nblk = (size_t)(HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK;
-    return (size_t)B * nblk * (C / 4) * 2 * sizeof(double) + (size_t)B * 64 * sizeof(float2) + 256;
+    return (size_t)B * 32 * (C / 4) * 2 * sizeof(double) + (size_t)B * 64 * sizeof(float2) + 256;      // 32 = the most pixel ranges per sample
 }
 
 int selftok_groupnorm_silu_nhwc_bf16(const void* x, const void* weight, const void* bias, void* out, void* workspace, int B, int HW, int C, int groups,
@@ -477,7 +479,7 @@ int selftok_groupnorm_silu_nhwc_bf16(const void* x, const void* weight, const vo
         return SELFTOK_EINVAL;
     }
     if (B == 0) return SELFTOK_OK;
-    const int nblk = (HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK;
+    const int nblk = gn_nblk(HW);
     double* part = (double*)workspace;
     float2* stats = (float2*)((char*)workspace + (((size_t)B * nblk * (C / 4) * 2 * sizeof(double) + 255) & ~(size_t)255));
     hipLaunchKernelGGL(gn_nhwc_partial_kernel, dim3(nblk, B), dim3(256), 0, stream, (const uint16_t*)x, part, HW, C, nblk);

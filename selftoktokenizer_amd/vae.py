@@ -3,10 +3,16 @@
 The reference calls the third-party `diffusers.AutoencoderKL` (SelftokPipeline.py:162-163, 215, 288, 316);
 this module exposes the same surface (`encode(x)[0].mode()`, `decode(z)[0]`) over the same checkpoint keys
 (`<sd3_path>/vae/diffusion_pytorch_model.safetensors`) without diffusers.  Topology follows the in-repo
-architectural mirror mimogpt/models/selftok/sd3/sd3_impls.py:215-474.  Convolutions and the single-head mid
-attention run through PyTorch-ROCm (MIOpen / SDPA); GroupNorm+SiLU is our fused HIP epilogue.
+architectural mirror mimogpt/models/selftok/sd3/sd3_impls.py:215-474.
 
-Two properties of PyTorch-ROCm's bf16 convolution path matter for parity with the reference's CPU run and are handled here
+Default (`mode="parity"`): channels-last activations, every convolution through our implicit-GEMM kernel (csrc/conv.hip: fp32 accumulation
+of bf16 products with the bias inside, ONE rounding -- the reference's CPU arithmetic -- with ResnetBlock's residual add, Upsample's
+nearest 2x and Downsample's padding fused), GroupNorm+SiLU by our fp64-statistics kernel, the single-head mid attention in torch ops
+that round where the CPU flash kernel rounds (`_attn_tokens`).  No MIOpen, bit-stable by construction, 106 ms per 64 images (encode +
+decode) against 331 ms for the MIOpen route below and 185 ms for MIOpen's fastest (inaccurate) solvers.
+
+`mode="miopen"` keeps the route rounds 1-3 used to reach the same arithmetic through PyTorch-ROCm, `mode="fast"` the rounds 1-2 arithmetic.
+Two properties of PyTorch-ROCm's bf16 convolution path matter for parity with the reference's CPU run and are handled by `mode="miopen"`
 (measured: tools/probe_vae_modes.py, profiles/r3_vae_modes.txt; tests/test_parity16_gpu.py):
 
   * BIAS.  `F.conv2d(x, w, b)` on ROCm runs MIOpen's convolution (fp32 accumulate, result rounded to bf16) and then ADDS the bias as

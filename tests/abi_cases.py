@@ -535,8 +535,7 @@ def _gn_nhwc(C, silu, HW=24 * 24, B=2):
         x = to_bf16(r.standard_normal((B, HW, C)) * 2 + 0.3)
         w, b = to_bf16(1 + 0.2 * r.standard_normal(C)), to_bf16(0.2 * r.standard_normal(C))
         out = alloc(np.zeros_like(x))
-        nblk = (HW + 2047) // 2048
-        ws = alloc(np.zeros(B * nblk * (C // 4) * 2 * 8 + B * 64 * 8 + 256, np.uint8))
+        ws = alloc(np.zeros(B * 32 * (C // 4) * 2 * 8 + B * 64 * 8 + 256, np.uint8))          # selftok_groupnorm_nhwc_workspace_bytes
         return "selftok_groupnorm_silu_nhwc_bf16", [alloc(x).ptr, alloc(w).ptr, alloc(b).ptr, out.ptr, ws.ptr, B, HW, C, 32, 1e-6, silu, None], dict(out_bf16=out)
     return fn
 
