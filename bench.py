@@ -397,6 +397,21 @@ def kernel_roofs(pipe, B, K, k_table):
                     "achieved": round(3 * fl / ms / 1e9, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (f16 MFMA: 3 per fp32 product)",
                     "frac": round(3 * fl / ms / 1e9 / F16_MFMA_PEAK_TFLOPS, 4), "fp32_equivalent_TFLOPs": round(fl / ms / 1e9, 1),
                     "vendor_fp16_gemm_same_mfma_count_ms": round(ms_lib16, 4), "frac_of_vendor_fp16_gemm_rate": round(ms_lib16 / ms, 4)})
+    del a, w, a_s, packed
+    # the VAE's convolution (csrc/conv.hip) on its two heaviest decoder shapes, and the vendor bf16 GEMM of the same size beside it
+    for (Hh, C, note) in ((256, 128, "decoder up_blocks.3 resnet conv, 6 per decode + 4 per encode"), (64, 512, "decoder up_blocks.1 resnet conv")):
+        xx = torch.randn(B, Hh, Hh, C, device=dev).to(torch.bfloat16)
+        pc = ops.PackedConv(torch.randn(C, C, 3, 3, device=dev).to(torch.bfloat16) * 0.02, torch.randn(C, device=dev).to(torch.bfloat16))
+        ms = event_time_ms(lambda: ops.conv2d_nhwc(xx, pc), n=10, warm=2)
+        fl = 2.0 * B * Hh * Hh * C * C * 9
+        ag = torch.randn(B * Hh * Hh, 9 * C, device=dev).to(torch.bfloat16) if Hh <= 64 else None       # im2col-sized GEMM operand: 2.4 GB at 64 x 64 x 512
+        wg = torch.randn(C, 9 * C, device=dev).to(torch.bfloat16)
+        ms_lib = event_time_ms(lambda: F.linear(ag, wg), n=5, warm=2) if ag is not None else None
+        out.append({"kernel": "conv_nhwc_bf16_kernel<2,4,1,9,1> (implicit GEMM, fp32 accumulate incl. bias, one rounding)", "bound": "mfma(bf16), power-limited",
+                    "shape": f"[{B},{Hh},{Hh},{C}] -> {C}, 3x3 ({note})", "avg_launch_ms": round(ms, 4), "achieved": round(fl / ms / 1e9, 1), "peak": F16_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / F16_MFMA_PEAK_TFLOPS, 4),
+                    "vendor_bf16_gemm_same_flops_ms": None if ms_lib is None else round(ms_lib, 4)})
+        del xx, pc, ag, wg
     return out
 
 

@@ -66,6 +66,42 @@ __device__ __forceinline__ bf16x8 as_bf8(uint4 v)
     return c.b;
 }
 
+// epilogue: the lane holds pixel (oy0 + mt, ox) of its two tile rows; rows of the MFMA tile = output channels n0 + nt 32 + 8 rg + 4 g + e
+template <int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& P, const f32x16 (&acc)[2][NT], int b, int oy0, int ox, int n0, int g)
+{
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int oy = oy0 + mt;
+        if (oy >= P.Ho || ox >= P.Wo) continue;
+        const size_t pix = ((size_t)b * P.Ho + oy) * P.Wo + ox;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int co = n0 + nt * 32 + 8 * rg + 4 * g;
+                if (co >= P.Cs) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[mt][nt][rg * 4 + e];
+                    if (P.bias && co + e < P.Cout) v[e] += bf2f(P.bias[co + e]);
+                    v[e] = rbf(v[e]);
+                }
+                if (P.res) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(P.res + pix * P.ldo + co);
+                    v[0] = rbf(v[0] + bf2f((uint16_t)(rr.x & 0xFFFF))); v[1] = rbf(v[1] + bf2f((uint16_t)(rr.x >> 16)));
+                    v[2] = rbf(v[2] + bf2f((uint16_t)(rr.y & 0xFFFF))); v[3] = rbf(v[3] + bf2f((uint16_t)(rr.y >> 16)));
+                }
+                uint2 o;
+                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                *reinterpret_cast<uint2*>(P.out + pix * P.ldo + co) = o;
+            }
+        }
+    }
+}
+
 // two halo buffers when tile(s) + two weight slabs fit in 72 KB (two workgroups per CU), else one
 constexpr int conv_abuf(int npix, int bn) { return (npix * 80 * 2 + bn * 64 * 2 <= 73728) ? 2 : 1; }
 constexpr int conv_lds_bytes(int npix, int bn) { return conv_abuf(npix, bn) * npix * 80 + bn * 64 * 2; }
@@ -242,38 +278,134 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_nhwc_bf16_kernel(const C
 #undef SELFTOK_TAP
     }
 
-    // ---- epilogue: lane = pixel l32 of tile row (wm*2 + mt); rows of the MFMA tile = output channels ----
-    const int n0 = blockIdx.y * BN + wn * NT * 32;
+    conv_epilogue<NT>(P, acc, b, ty0 + wm * 2, tx0 + l32, blockIdx.y * BN + wn * NT * 32, g);
+}
+
+// 3 x 3, stride 1, 128 output channels per workgroup -- the shape of 95 % of the VAE's convolution work -- with ONE barrier per kernel
+// ROW (3 taps, 12 MFMAs per wave) instead of one per tap: 8 waves, 4 tile rows x 32 pixels x 128 channels per workgroup (64 x 32 per
+// wave).  LDS: one halo tile (16 KB, 80-byte pixel rows) + two weight groups of 3 slabs (2 x 24 KB) = 64 KB static, two workgroups per
+// CU.  Weight group r + 1 sits in registers while group r is multiplied (loaded a whole group = 12 MFMAs x 4 waves per SIMD earlier) and is
+// written to the other buffer right after the barrier; the next channel block's halo tile is loaded during kernel row 0 and written
+// after the barrier that ends kernel row 2 (+1 barrier per channel block: 4 instead of 9).  Same products, same order per output as
+// conv_nhwc_bf16_kernel: bit-identical results.
+__global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(const ConvParams P)
+{
+    constexpr int NTH = 512, WM = 2, TH = 4, TW = 32, HWD = 34, NPIX = 6 * 34, BN = 128;
+    constexpr int NA = (NPIX * 4 + NTH - 1) / NTH;             // 2 halo chunks per thread
+    constexpr int NBG = 3 * BN * 4 / NTH;                      // 3 weight chunks per thread and group
+    __shared__ uint4 s_a[NPIX * 5];
+    __shared__ uint4 s_b[2][3 * BN * 4];
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv % WM, wn = wv / WM;
+    const int l32 = lane & 31, g = lane >> 5;
+    const int tiles_x = (P.Wo + TW - 1) / TW, tiles_y = (P.Ho + TH - 1) / TH;
+    int tile = blockIdx.x;
+    const int tx0 = (tile % tiles_x) * TW; tile /= tiles_x;
+    const int ty0 = (tile % tiles_y) * TH;
+    const int b = tile / tiles_y;
+    const int Hi = P.H << P.up, Wi = P.W << P.up;
+    const uint16_t* __restrict__ xb = P.x + (size_t)b * P.H * P.W * P.Cin;
+    const uint16_t* __restrict__ wb = P.w + (size_t)blockIdx.y * P.ncb * 9 * BN * 32;
+    const int Cin = P.Cin, Wsrc = P.W, up = P.up, ncb = P.ncb, ngrp = P.ncb * 3;
+    const int iy0 = ty0 - 1, ix0 = tx0 - 1;
+
+    auto a_ok = [&](int cb, int i, int& off) -> bool {
+        const int q = t + NTH * i;
+        const int pp = q >> 2, c8 = (q & 3) * 8;
+        const int hy = pp / HWD, hx = pp - hy * HWD;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool ok = (q < NPIX * 4) && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi && cb * 32 + c8 < Cin;
+        const int cy = min(max(iy, 0), Hi - 1) >> up, cx = min(max(ix, 0), Wi - 1) >> up;
+        off = (cy * Wsrc + cx) * Cin + (cb * 32 + c8 < Cin ? cb * 32 + c8 : 0);
+        return ok;
+    };
+    auto load_a1 = [&](int cb, int i) -> uint4 {               // never selects on its result (see conv_nhwc_bf16_kernel)
+        int off;
+        a_ok(cb, i, off);
+        return *reinterpret_cast<const uint4*>(xb + off);
+    };
+    auto store_a1 = [&](int cb, int i, uint4 v) {
+        const int q = t + NTH * i;
+        const int pp = q >> 2, c = q & 3;
+        int off;
+        if (!a_ok(cb, i, off)) v = make_uint4(0, 0, 0, 0);
+        if (q < NPIX * 4) s_a[pp * 5 + c] = v;
+    };
+    auto load_bg = [&](int grp, int i) -> uint4 {              // group = 3 consecutive slabs of the packed image, 1536 chunks
+        return reinterpret_cast<const uint4*>(wb + (size_t)min(grp, ngrp - 1) * 3 * BN * 32)[t + NTH * i];
+    };
+    auto store_bg = [&](uint4* __restrict__ dst, int i, uint4 v) {
+        const int q = t + NTH * i, row = q >> 2, c = q & 3;     // row = slab-in-group * 128 + channel
+        dst[row * 4 + (c ^ ((row >> 2) & 3))] = v;
+    };
+
+    const int w_row = wn * 32 + l32;
+    const int w_off = w_row * 4 + (g ^ ((w_row >> 2) & 3));
+    int p_base[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int oy = ty0 + wm * 2 + mt, ox = tx0 + l32;
-        if (oy >= P.Ho || ox >= P.Wo) continue;
-        const size_t pix = ((size_t)b * P.Ho + oy) * P.Wo + ox;
+    for (int mt = 0; mt < 2; ++mt) p_base[mt] = ((wm * 2 + mt) * HWD + l32) * 5 + g;
+
+    f32x16 acc[2][1];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int co = n0 + nt * 32 + 8 * rg + 4 * g;
-                if (co >= P.Cs) continue;
-                float v[4];
+        for (int r = 0; r < 16; ++r) acc[mt][0][r] = 0.f;
+
+    uint4 ra[NA], rb[NBG];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[mt][nt][rg * 4 + e];
-                    if (P.bias && co + e < P.Cout) v[e] += bf2f(P.bias[co + e]);
-                    v[e] = rbf(v[e]);
-                }
-                if (P.res) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(P.res + pix * P.ldo + co);
-                    v[0] = rbf(v[0] + bf2f((uint16_t)(rr.x & 0xFFFF))); v[1] = rbf(v[1] + bf2f((uint16_t)(rr.x >> 16)));
-                    v[2] = rbf(v[2] + bf2f((uint16_t)(rr.y & 0xFFFF))); v[3] = rbf(v[3] + bf2f((uint16_t)(rr.y >> 16)));
-                }
-                uint2 o;
-                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                *reinterpret_cast<uint2*>(P.out + pix * P.ldo + co) = o;
+    for (int i = 0; i < NA; ++i) ra[i] = load_a1(0, i);
+#pragma unroll
+    for (int i = 0; i < NBG; ++i) rb[i] = load_bg(0, i);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) store_a1(0, i, ra[i]);
+#pragma unroll
+    for (int i = 0; i < NBG; ++i) store_bg(s_b[0], i, rb[i]);
+#pragma unroll
+    for (int i = 0; i < NBG; ++i) rb[i] = load_bg(1, i);        // rb <- group 1
+    __syncthreads();
+
+    int grp = 0;
+    for (int cb = 0; cb < ncb; ++cb) {
+        const bool more_cb = cb + 1 < ncb;
+        auto one_row = [&](auto dy_c) {
+            constexpr int dy = decltype(dy_c)::value;
+            // rb holds group grp + 1: write it to the buffer group grp - 1 was read from (everyone is past that barrier), then refill rb
+            if (grp + 1 < ngrp) {
+#pragma unroll
+                for (int i = 0; i < NBG; ++i) store_bg(s_b[(grp + 1) & 1], i, rb[i]);
             }
-        }
+#pragma unroll
+            for (int i = 0; i < NBG; ++i) rb[i] = load_bg(grp + 2, i);
+            if (dy == 0) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) ra[i] = load_a1(cb + 1, i);
+            }
+            const uint4* __restrict__ sb = s_b[grp & 1];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8 wf = as_bf8(sb[(dx * BN * 4 + w_off) ^ (2 * j)]);
+                    bf16x8 pf[2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) pf[mt] = as_bf8(s_a[p_base[mt] + (dy * HWD + dx) * 5 + 2 * j]);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, pf[mt], acc[mt][0], 0, 0, 0);
+                }
+            }
+            ++grp;
+            __syncthreads();
+            if (dy == 2 && more_cb) {                           // every wave is done with this channel block's halo tile
+#pragma unroll
+                for (int i = 0; i < NA; ++i) store_a1(cb + 1, i, ra[i]);
+                __syncthreads();
+            }
+        };
+        one_row(std::integral_constant<int, 0>{});
+        one_row(std::integral_constant<int, 1>{});
+        one_row(std::integral_constant<int, 2>{});
     }
+    conv_epilogue<1>(P, acc, b, ty0 + wm * 2, tx0 + l32, blockIdx.y * BN + wn * 32, g);
 }
 
 // w [O, Cin, ks, ks] bf16 (the checkpoint's layout) -> [nblk][ncb][taps][BN][32], zero padded
@@ -461,7 +593,17 @@ int selftok_conv2d_nhwc_bf16(const void* x, const void* packed, const void* bias
     // one's prologue / epilogue / barriers hide behind the other's matrix work.  Measured against 256 x 128 tiles of 64 x 64 per
     // wave (one workgroup per CU, half the weight traffic per pixel) and 4-wave 128 x 128 tiles: +27 % on the 128-channel layers at
     // 256 x 256, +3 ... 6 % elsewhere (profiles/r3_conv_launch_shapes.txt; the three are bit-identical).
-    return taps == 9 ? launch_conv_one<2, 4, 1, 9, 1>(P, stream) : launch_conv_one<2, 4, 1, 1, 1>(P, stream);
+    if (taps == 9) {
+        bool rows = P.ncb >= 8;      // >= 256 input channels: one barrier per kernel row, +2 ... 3 %; with 4 channel blocks its single halo buffer costs 12 %
+#ifdef SELFTOK_TUNE
+        if (const char* v = getenv("SELFTOK_CONV_VARIANT")) { if (v[0] == '2') rows = false; if (v[0] == '9') rows = true; }
+#endif
+        if (!rows) return launch_conv_one<2, 4, 1, 9, 1>(P, stream);
+        const int tiles = ((P.Wo + 31) / 32) * ((P.Ho + 3) / 4) * P.B;
+        hipLaunchKernelGGL(conv3x3_rows_kernel, dim3(tiles, (P.Cs + 127) / 128), dim3(512), 0, stream, P);
+        return check_launch("conv3x3_rows_kernel");
+    }
+    return launch_conv_one<2, 4, 1, 1, 1>(P, stream);
 }
 
 size_t selftok_groupnorm_nhwc_workspace_bytes(int B, int HW, int C)
