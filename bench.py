@@ -335,7 +335,15 @@ def latency_b1(pipe, n=3):
         once(graph)                                    # warm-up (and the capture)
         runs = [once(graph) for _ in range(n)]
         res[name] = {"encode_ms": round(float(np.median([r[0] for r in runs])), 2), "encode_plus_decode_ms": round(float(np.median([r[1] for r in runs])), 2)}
-    res["note"] = "B = 1, 256x256, 512 tokens, 50 steps, gemm mode of the headline; encode_ms is host time to the returned (asynchronous) id tensor's launch end"
+    main = pipe.model.model.gemm
+    alt = "f16x2" if main == "fp32" else "fp32"
+    if pipe.set_gemm(alt) == alt:                      # the same image on the other Linear arithmetic (eager): B = 1 is GEMM-latency-bound, not launch-bound
+        once(False)
+        runs = [once(False) for _ in range(n)]
+        res[f"eager_{alt}"] = {"encode_ms": round(float(np.median([r[0] for r in runs])), 2), "encode_plus_decode_ms": round(float(np.median([r[1] for r in runs])), 2)}
+    pipe.set_gemm(main)
+    res["note"] = ("B = 1, 256x256, 512 tokens, 50 steps; eager / hipgraph in the gemm mode of the headline, eager_<other> in the other; encode_ms is host time to the "
+                   "returned (asynchronous) id tensor's launch end")
     return res
 
 
