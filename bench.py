@@ -60,6 +60,7 @@ def parse(argv=None):
     ap.add_argument("--decode-steps", type=int, default=None, help="debug only: truncate the 50-step loop (marks the line invalid)")
     ap.add_argument("--gemm", default=None, choices=["fp32", "f16x2"], help="arithmetic of the MMDiT block Linears of the headline number")
     ap.add_argument("--vae", default=None, choices=["parity", "miopen", "fast"], help="VAE arithmetic (vae.AutoencoderKLGPU); default parity")
+    ap.add_argument("--tune-gemm", type=int, default=None, choices=[0, 1], help="fp32 Linears: hipBLASLt kernel chosen per shape family by measurement (gemm_tune.py); default: the pipeline's (on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-token-check", action="store_true")
     ap.add_argument("--no-kernel-roofs", action="store_true")
@@ -510,7 +511,8 @@ def main(argv=None):
     cfg = default_config(K, renderer=renderer)
     sd = W.synthetic_state_dict(W.expected_shapes(K, renderer=renderer), device=dev)
     vsd = W.synthetic_vae_state_dict(device=dev)
-    pipe = SelftokPipeline(cfg, None, None, device=dev, state_dict=sd, vae_state_dict=vsd, verbose=False, gemm=args.gemm, vae_mode=args.vae)
+    pipe = SelftokPipeline(cfg, None, None, device=dev, state_dict=sd, vae_state_dict=vsd, verbose=False, gemm=args.gemm, vae_mode=args.vae,
+                           tune_gemm=None if args.tune_gemm is None else bool(args.tune_gemm))
     gemm_main = pipe.model.model.gemm
 
     images = synth.synthetic_images(B, device=dev, first_index=rank * B)          # resident in HBM
@@ -587,7 +589,10 @@ def main(argv=None):
         "config": {"workload": "BASELINE configs[%d]: batch %d x 256x256 per GPU, %d-token encode + %s decode"
                                % (3 if renderer else (2 if K == 1024 else 1), B, K, "one-step renderer" if renderer else "50-step diffusion"),
                    "global_batch": world * B, "tokens": K, "decode_steps": 1 if renderer else (args.decode_steps or 50),
-                   "gemm": gemm_main, "arithmetic": arith[gemm_main], "vae": pipe.vae.mode, "parallelism": "batch-shard x%d" % world,
+                   "gemm": gemm_main, "arithmetic": arith[gemm_main], "vae": pipe.vae.mode,
+                   "fp32_linear_kernels": (None if not pipe.gemm_tune_report else {f"{n}x{k}": {"kernel": b or "hipBLASLt default", "ms_default": t0, "ms_chosen": t1}
+                                                                                       for (n, k), (b, t0, t1) in pipe.gemm_tune_report.items()}),
+                   "parallelism": "batch-shard x%d" % world,
                    "api": "pipe.encoding(images) -> id all-gather -> pipe.decoding(ids.cpu().numpy()) (noise from the CPU generator, as the reference)",
                    "weights": "hash-generated, architecture of tokenizer_512_ckpt"},
         "ranks": world, "backend": backend if world > 1 else None,

@@ -1,0 +1,125 @@
+"""Picking hipBLASLt's fp32 GEMM kernels for the MMDiT block Linears by measurement.
+
+The fp32 headline is 87 % library GEMM (PyTorch-ROCm -> hipBLASLt), and hipBLASLt's own heuristic leaves 3 - 8 % of it on the table at
+this model's shapes: [B (k+1), 1536] x {[1536, 4608], [1536, 1536], [1536, 6144], [6144, 1536]} runs at 0.84 / 0.87 / 0.92 / 0.95 of the
+fp32 matrix peak with the default choice and at 0.94 / 0.89 / 0.95 / 0.96 with the kernel PyTorch's TunableOp finds by exhaustive search
+(tools/bench_fp32_gemm_shapes.py, profiles/r3_fp32_gemm_default_vs_tuned.txt).  The exhaustive search costs ~10 s per shape and a 50-step
+decode has 50 distinct context lengths -- 204 shapes, half an hour -- so it is not run.  Instead:
+
+  * CANDIDATES = the solutions that search returned on four row counts (16 shapes);
+  * at the first decode of a batch size, every candidate (and the default) is timed on two representative row counts of each of the four
+    (N, K) families -- a probe is a TunableOp results file that maps a not-otherwise-used row count to the candidate, read back with
+    tuning disabled -- about 2 s in total;
+  * the winner of each family is written for ALL row counts of the step (TunableOp file, read back); a family whose default wins gets no
+    entry.  Nothing here can be slower than the default by more than the timing noise, and an unknown solution name (another hipBLASLt
+    build) is simply ignored by TunableOp.
+
+Side effect: torch.cuda.tunable is switched on (tuning OFF) for the process; only the listed problem keys change kernel.  The results are
+fp32 GEMMs either way: a different summation order inside the same tolerance as the default kernel's (all parity gates unchanged).
+Opt out with SELFTOK_TUNE_GEMM=0 or SelftokPipeline(..., tune_gemm=False).
+"""
+from __future__ import annotations
+
+import os
+import tempfile
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+# solutions TunableOp's exhaustive search selected on this image's hipBLASLt (100000-20250912) for the four Linear families at
+# M in {6400, 16384, 22976, 32000}; the validator lines of the generated file tie them to that build
+CANDIDATES = tuple(f"Gemm_Hipblaslt_{i}" for i in (627292, 627296, 627311, 627324, 627325, 627372, 627376, 627391, 627404, 627408, 627436))
+OP = "GemmAndBiasTunableOp_float_TN"
+_H = 1536                                                                    # weights.DIT_HIDDEN
+FAMILIES = ((3 * _H, _H), (_H, _H), (4 * _H, _H), (_H, 4 * _H))              # (N, K) of qkv, proj / out, fc1, fc2
+
+_done: Dict[Tuple[int, Tuple[int, ...]], Dict] = {}
+
+
+def _key(N: int, M: int, K: int) -> str:
+    return f"tn_{N}_{M}_{K}_ld_{K}_{K}_{N}"          # TunableOp's GemmAndBiasParams signature for F.linear(x [M,K], W [N,K], b)
+
+
+def _write(path: str, entries: Iterable[Tuple[str, str]]) -> None:
+    with open(path, "w") as f:
+        for name, val in torch.cuda.tunable.get_validators():
+            f.write(f"Validator,{name},{val}\n")
+        for key, sol in entries:
+            f.write(f"{OP},{key},{sol},0.0\n")
+
+
+def _time(fn, n: int = 6, warm: int = 2) -> float:
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def autotune_linears(row_counts: Iterable[int], device: torch.device, reps: Optional[Iterable[int]] = None, families=FAMILIES, candidates=CANDIDATES,
+                     verbose: bool = False) -> Optional[Dict]:
+    """row_counts: every M = rows of a block-Linear input the step will issue (context stream per step + image stream); reps: the row
+    counts the candidates are timed on (default: the median and the largest).  Returns {(N, K): (winner or None, ms default, ms winner)}
+    or None when TunableOp is unavailable."""
+    rows = sorted({int(m) for m in row_counts if int(m) > 0})
+    if not rows or not torch.cuda.is_available() or not hasattr(torch.cuda, "tunable"):
+        return None
+    sig = (torch.cuda.current_device(), tuple(rows))
+    if sig in _done:
+        return _done[sig]
+    tun = torch.cuda.tunable
+    try:
+        tun.enable(True)
+        tun.tuning_enable(False)
+    except Exception:                       # a PyTorch build without TunableOp: nothing to do
+        return None
+    reps = sorted({int(m) for m in reps}) if reps else sorted({rows[-1], rows[len(rows) // 2]})
+    report: Dict = {}
+    final: List[Tuple[str, str]] = []
+    with tempfile.TemporaryDirectory() as td:
+        probe_id = 0
+        for (N, K) in families:
+            w = torch.randn(N, K, device=device) * 0.02
+            bias = torch.randn(N, device=device)
+            times = {}
+            for ci, cand in enumerate((None,) + tuple(candidates)):
+                total = 0.0
+                for M in reps:
+                    Mp = M + 1 + 2 * ci if (M + 1 + 2 * ci) not in rows else M + 2 + 2 * ci      # a row count no real call uses: its key is ours alone
+                    if cand is not None:
+                        path = os.path.join(td, f"probe{probe_id}.csv")
+                        probe_id += 1
+                        _write(path, [(_key(N, Mp, K), cand)])
+                        tun.read_file(path)
+                    a = torch.randn(Mp, K, device=device)
+                    total += _time(lambda: F.linear(a, w, bias))
+                    del a
+                times[cand] = total
+            best = min(times, key=times.get)
+            if best is not None and times[best] > 0.99 * times[None]:          # below the timing noise: keep the default
+                best = None
+            report[(N, K)] = (best, round(times[None], 4), round(times[best], 4))
+            if best is not None:
+                final += [(_key(N, M, K), best) for M in rows]
+            del w, bias
+        if final:
+            path = os.path.join(td, "selftok_linears.csv")
+            _write(path, final)
+            tun.read_file(path)
+    if verbose:
+        for fam, (best, t0, t1) in report.items():
+            print(f"[gemm_tune] {fam}: default {t0:.3f} ms -> {best or 'default'} {t1:.3f} ms (two representative row counts)", flush=True)
+    _done[sig] = report
+    return report
+
+
+def step_row_counts(B: int, k_table, image_tokens: int) -> Tuple[List[int], List[int]]:
+    """(all row counts, the two the candidates are timed on) of the block-Linear inputs of a decode at batch B: context stream
+    B (k + 1) rows at each step (timed at the median), image stream B x image_tokens rows at every step"""
+    ctx = sorted(B * (int(k) + 1) for k in k_table)
+    return sorted(set(ctx) | {B * image_tokens}), [B * image_tokens, ctx[len(ctx) // 2]]

@@ -17,7 +17,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, ops, weights as W
+from . import _lib, gemm_tune, ops, weights as W
 from .encoder import QformerEncoderGPU, sinusoid_host
 from .mmdit import MMDiTGPU
 from .modsurface import ModuleSurface
@@ -150,14 +150,18 @@ class SelftokPipeline():
     def __init__(self, cfg, ckpt_path, sd3_path, datasize=256, start=1.0, cfg_scale=1, model_type='sd3',
                  dtype=torch.bfloat16, ema_decoder=False, device=None, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, verbose: bool = True, gemm: Optional[str] = None,
-                 vae_mode: Optional[str] = None):
+                 vae_mode: Optional[str] = None, tune_gemm: Optional[bool] = None):
         """cfg: parse_args_from_yaml(...) ; ckpt_path: tokenizer .pth ; sd3_path: diffusers SD3 folder (…/vae/…).
         `state_dict` / `vae_state_dict` (extensions) bypass the files, e.g. with weights.synthetic_state_dict().
         `gemm` (extension): arithmetic of the MMDiT block Linears, 'fp32' (hipBLASLt fp32) or 'f16x2' (fp32-equivalent
         split GEMM on the f16 matrix cores, csrc/gemm_split.hip); default from $SELFTOK_GEMM, else DEFAULT_GEMM.
         `vae_mode` (extension): 'parity' (default; bias inside the accumulation, deterministic GEMM algorithm) or 'fast'
-        (MIOpen's searched solvers, 1.8x faster convolutions, looser parity: see vae.AutoencoderKLGPU); default from $SELFTOK_VAE."""
+        (MIOpen's searched solvers, 1.8x faster convolutions, looser parity: see vae.AutoencoderKLGPU); default from $SELFTOK_VAE.
+        `tune_gemm` (extension): pick hipBLASLt's kernel for the fp32 block Linears by a 2-second measurement at the first decode of a
+        batch size (gemm_tune.py; switches torch.cuda.tunable on with tuning off); default from $SELFTOK_TUNE_GEMM, else on."""
         _lib.load()                                                           # fail loudly if the HIP library is missing
+        self.tune_gemm = (os.environ.get("SELFTOK_TUNE_GEMM", "1") != "0") if tune_gemm is None else bool(tune_gemm)
+        self.gemm_tune_report = None
         if device is None:
             device = "cuda"
         if not torch.cuda.is_available():
@@ -265,6 +269,12 @@ class SelftokPipeline():
         return norm_ip(recons, -1, 1)
 
     @_on_own_device
+    def _tune_linears(self, B: int, k_table, image_tokens: int) -> None:
+        """fp32 mode: choose hipBLASLt's kernels for this batch size's block Linears once (gemm_tune.py)"""
+        if self.tune_gemm and self.model.model.gemm == "fp32":
+            rows, reps = gemm_tune.step_row_counts(B, k_table, image_tokens)
+            self.gemm_tune_report = gemm_tune.autotune_linears(rows, self.device, reps=reps, verbose=self.verbose)
+
     def set_gemm(self, mode: str) -> str:
         """switch the MMDiT block Linears between 'fp32' and 'f16x2' (see MMDiTGPU.set_gemm); returns the mode in force"""
         return self.model.model.set_gemm(mode)
@@ -335,6 +345,7 @@ class SelftokPipeline():
         ehs = outs_q if k0 >= self.K - 1 else outs_q * (torch.arange(self.K, device=self.device) <= k0)[None, :, None]
         latent_dim = self.datasize // 8
         xt = noise if noise is not None else torch.randn(B, 16, latent_dim, latent_dim)
+        self._tune_linears(B * (2 if uncond_scale != 1.0 else 1), self.k_table, (latent_dim // 2) ** 2)
         pred_x0 = self._checked(lambda: self._sample(xt, ehs, max_steps, uncond_scale, use_graph, prefix_k, super_mask))
         recons = self._to_pixels(pred_x0)
         self._say('End decoding.')
@@ -346,6 +357,7 @@ class SelftokPipeline():
         """one MMDiT_Renderer pass instead of the 50-step loop (reference :296-322)"""
         self._say("Begin decoding with Renderer.")
         outs_q = self._codes(idx)
+        self._tune_linears(outs_q.shape[0], [self.K - 1], (self.datasize // 16) ** 2)
         pred_x0 = self._checked(lambda: self.model.model(y=None, encoder_hidden_states=outs_q)[0])
         recons = self._to_pixels(pred_x0)
         self._say('End decoding with Renderer.')

@@ -347,3 +347,13 @@ def test_bench_roofline_object_is_a_fraction_of_the_pipe_the_kernel_runs_on(tmp_
     assert m.measured_vq_traffic(65536, True, str(p))[0] is None and m.measured_vq_traffic(32768, True, str(tmp_path / "nope.json"))[0] is None
     r = m.vq_roofline(32768, 32768, 16, 0.0922, 0.0100, 20, t, note)
     assert r["traffic"] == 30000000 and abs(r["traffic_over_algorithmic_bytes"] - 30000000 / 4456448) < 0.01
+
+
+def test_gemm_tune_row_counts_and_file_format(tmp_path):
+    """gemm_tune: the row counts of a step and the TunableOp key / file it writes (no GPU: the timing part is exercised by every -m gpu decode)"""
+    from selftoktokenizer_amd import gemm_tune as G
+    rows, reps = G.step_row_counts(64, [511, 100, 3, 3], 256)
+    assert rows == [256, 6464, 16384, 32768] and reps == [16384, 6464]
+    assert G._key(4608, 16384, 1536) == "tn_4608_16384_1536_ld_1536_1536_4608"      # GemmAndBiasParams::Signature of F.linear([16384,1536], [4608,1536], b)
+    assert G.FAMILIES == ((4608, 1536), (1536, 1536), (6144, 1536), (1536, 6144))
+    assert G.autotune_linears([], None) is None                                       # nothing to do without rows / a GPU
