@@ -357,6 +357,7 @@ def kernel_roofs(pipe, B, K, k_table):
     dev = pipe.device
     H, NH = 1536, 24
     n = int(round(float(sum(int(k) + 1 for k in k_table)) / len(k_table)))
+    n = min((int(k) + 1 for k in k_table), key=lambda v: abs(v - n))          # a context length the step really has: its Linears then run the kernels gemm_tune installed
     out = []
     # attention: 23 of 24 blocks have both streams as queries
     cq = torch.randn(B, n, 3 * H, device=dev)
@@ -388,7 +389,7 @@ def kernel_roofs(pipe, B, K, k_table):
     b = torch.randn(3 * H, device=dev)
     fl = 2.0 * B * n * 3 * H * H
     ms = event_time_ms(lambda: F.linear(a, w, b))
-    out.append({"kernel": "hipBLASLt fp32 GEMM (PyTorch-ROCm)", "bound": "mfma(fp32)", "shape": f"[{B * n},{H}]x[{H},{3 * H}]", "avg_launch_ms": round(ms, 4),
+    out.append({"kernel": "hipBLASLt fp32 GEMM (PyTorch-ROCm; kernel per shape family picked by gemm_tune.py when it is on)", "bound": "mfma(fp32)", "shape": f"[{B * n},{H}]x[{H},{3 * H}]", "avg_launch_ms": round(ms, 4),
                 "achieved": round(fl / ms / 1e9, 1), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)})
     packed = ops.linear_f16x2_pack(w)
     # the practical ceiling of the f16 matrix cores on THIS box: the vendor's plain fp16 GEMM with the same number of MFMAs (K tripled),

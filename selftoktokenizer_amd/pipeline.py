@@ -157,7 +157,7 @@ class SelftokPipeline():
         split GEMM on the f16 matrix cores, csrc/gemm_split.hip); default from $SELFTOK_GEMM, else DEFAULT_GEMM.
         `vae_mode` (extension): 'parity' (default; bias inside the accumulation, deterministic GEMM algorithm) or 'fast'
         (MIOpen's searched solvers, 1.8x faster convolutions, looser parity: see vae.AutoencoderKLGPU); default from $SELFTOK_VAE.
-        `tune_gemm` (extension): pick hipBLASLt's kernel for the fp32 block Linears by a 2-second measurement at the first decode of a
+        `tune_gemm` (extension): pick hipBLASLt's kernel for the fp32 block Linears by a 4-second measurement at the first decode of a
         batch size (gemm_tune.py; switches torch.cuda.tunable on with tuning off); default from $SELFTOK_TUNE_GEMM, else on."""
         _lib.load()                                                           # fail loudly if the HIP library is missing
         self.tune_gemm = (os.environ.get("SELFTOK_TUNE_GEMM", "1") != "0") if tune_gemm is None else bool(tune_gemm)
