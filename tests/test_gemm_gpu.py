@@ -178,3 +178,25 @@ def test_residual_epilogue_bit_identical(B, T, N, K):
         out = ops.linear_f16x2_split_residual(xs, packed, b, N, resid, gate=gate, gate_per_sample=ps, overflow=flag)
         assert torch.equal(out, ref)
     assert int(flag.item()) == 0
+
+
+def test_gemm_tune_installs_measured_kernels_and_keeps_the_numbers():
+    """gemm_tune.autotune_linears: every family gets a report entry; whatever kernel it installs for a row count of the step, the Linear's
+    result stays an fp32 GEMM of the same accuracy against fp64 as the default kernel's (a different summation order, nothing else)."""
+    from selftoktokenizer_amd import gemm_tune as G
+    rows, reps = G.step_row_counts(8, [511, 300, 77], 256)
+    M = reps[1]
+    a = torch.randn(M, 1536, device="cuda")
+    w, b = torch.randn(4608, 1536, device="cuda") * 0.03, torch.randn(4608, device="cuda")
+    before = torch.nn.functional.linear(a, w, b)
+    rep = G.autotune_linears(rows, torch.device("cuda"), reps=reps)
+    assert rep is not None and set(rep) == set(G.FAMILIES)
+    for fam, (best, t0, t1) in rep.items():
+        assert best is None or (best in G.CANDIDATES and t1 <= t0), (fam, best, t0, t1)
+    print({f"{n}x{k}": (b_ or "default", t0, t1) for (n, k), (b_, t0, t1) in rep.items()})
+    after = torch.nn.functional.linear(a, w, b)
+    ref = (a.double() @ w.double().t() + b.double())
+    e0, e1 = float((before.double() - ref).abs().max()), float((after.double() - ref).abs().max())
+    print(f"max abs err vs fp64: default kernel {e0:.2e}, installed kernel {e1:.2e}")
+    assert e1 <= 2.0 * e0 + 1e-6
+    assert G.autotune_linears(rows, torch.device("cuda"), reps=reps) is rep          # cached per (device, row counts)
