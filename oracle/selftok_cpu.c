@@ -817,19 +817,25 @@ int selftok_groupnorm_silu_nhwc_bf16(const void* xv, const void* wv, const void*
     const uint16_t *x = (const uint16_t*)xv, *w = (const uint16_t*)wv, *bb = (const uint16_t*)bv;
     uint16_t* out = (uint16_t*)ov;
     const int cpg = C / groups;
-#pragma omp parallel for collapse(2) schedule(static)
-    for (int b = 0; b < B; ++b) for (int g = 0; g < groups; ++g) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int p = 0; p < HW; ++p) for (int c = g * cpg; c < (g + 1) * cpg; ++c) { const double d = bf2f(x[((size_t)b * HW + p) * C + c]); s1 += d; s2 += d * d; }
-        const double n = (double)HW * cpg, mean = s1 / n;
-        double var = s2 / n - mean * mean;
-        if (var < 0) var = 0;
-        const float meanf = (float)mean;
-        const float varf = (float)(var + (mean - (double)meanf) * (mean - (double)meanf));
-        const float rstd = 1.0f / sqrtf(varf + eps);
-        for (int p = 0; p < HW; ++p) for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        double s1[64] = {0}, s2[64] = {0};
+        float meanf[64], rstd[64];
+        for (int p = 0; p < HW; ++p) {                         /* one pass over the sample, pixel-major (the layout's order) */
+            const uint16_t* xp = x + ((size_t)b * HW + p) * C;
+            for (int c = 0; c < C; ++c) { const double d = bf2f(xp[c]); s1[c / cpg] += d; s2[c / cpg] += d * d; }
+        }
+        for (int g = 0; g < groups; ++g) {
+            const double n = (double)HW * cpg, mean = s1[g] / n;
+            double var = s2[g] / n - mean * mean;
+            if (var < 0) var = 0;
+            meanf[g] = (float)mean;
+            const float varf = (float)(var + (mean - (double)meanf[g]) * (mean - (double)meanf[g]));
+            rstd[g] = 1.0f / sqrtf(varf + eps);
+        }
+        for (int p = 0; p < HW; ++p) for (int c = 0; c < C; ++c) {
             const size_t i = ((size_t)b * HW + p) * C + c;
-            float y = rbf((bf2f(x[i]) - meanf) * rstd * bf2f(w[c]) + bf2f(bb[c]));
+            float y = rbf((bf2f(x[i]) - meanf[c / cpg]) * rstd[c / cpg] * bf2f(w[c]) + bf2f(bb[c]));
             if (apply_silu) y = y / (1.0f + expf(-y));
             out[i] = f2bf(y);
         }

@@ -55,10 +55,10 @@ def f32(a):
 
 
 def to_bf16(a):
-    """fp32 -> bf16 bit patterns (uint16), round to nearest even"""
-    u = f32(a).view(np.uint32).astype(np.uint64)
-    u = u + 0x7FFF + ((u >> 16) & 1)
-    return (u >> 16).astype(np.uint16)
+    """fp32 -> bf16 bit patterns (uint16), round to nearest even (torch's conversion: the same rounding, an order of magnitude faster
+    than doing it in numpy integers)"""
+    import torch
+    return np.ascontiguousarray(torch.from_numpy(np.ascontiguousarray(f32(a))).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16))
 
 
 def from_bf16(u):
