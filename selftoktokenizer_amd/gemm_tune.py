@@ -76,6 +76,8 @@ def autotune_linears(row_counts: Iterable[int], device: torch.device, reps: Opti
     try:
         tun.enable(True)
         tun.tuning_enable(False)
+        if "PYTORCH_TUNABLEOP_FILENAME" not in os.environ:          # TunableOp writes its table at exit: not into the caller's working directory
+            tun.set_filename(os.path.join(tempfile.gettempdir(), f"selftok_tunableop_{os.getpid()}.csv"))
     except Exception:                       # a PyTorch build without TunableOp: nothing to do
         return None
     reps = sorted({int(m) for m in reps}) if reps else sorted({rows[-1], rows[len(rows) // 2]})
