@@ -288,13 +288,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_nhwc_bf16_kernel(const C
 // written to the other buffer right after the barrier; the next channel block's halo tile is loaded during kernel row 0 and written
 // after the barrier that ends kernel row 2 (+1 barrier per channel block: 4 instead of 9).  Same products, same order per output as
 // conv_nhwc_bf16_kernel: bit-identical results.
-__global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(const ConvParams P)
+template <int NBUF>
+__global__ __launch_bounds__(512, NBUF == 2 ? 2 : 6) void conv3x3_rows_kernel(const ConvParams P)
 {
     constexpr int NTH = 512, WM = 2, TH = 4, TW = 32, HWD = 34, NPIX = 6 * 34, BN = 128;
     constexpr int NA = (NPIX * 4 + NTH - 1) / NTH;             // 2 halo chunks per thread
     constexpr int NBG = 3 * BN * 4 / NTH;                      // 3 weight chunks per thread and group
     __shared__ uint4 s_a[NPIX * 5];
-    __shared__ uint4 s_b[2][3 * BN * 4];
+    __shared__ uint4 s_b[NBUF][3 * BN * 4];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv % WM, wn = wv / WM;
     const int l32 = lane & 31, g = lane >> 5;
@@ -369,18 +370,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(const ConvParams P
         const bool more_cb = cb + 1 < ncb;
         auto one_row = [&](auto dy_c) {
             constexpr int dy = decltype(dy_c)::value;
-            // rb holds group grp + 1: write it to the buffer group grp - 1 was read from (everyone is past that barrier), then refill rb
-            if (grp + 1 < ngrp) {
+            if (NBUF == 2) {
+                // rb holds group grp + 1: write it to the buffer group grp - 1 was read from (everyone is past that barrier), then refill rb
+                if (grp + 1 < ngrp) {
 #pragma unroll
-                for (int i = 0; i < NBG; ++i) store_bg(s_b[(grp + 1) & 1], i, rb[i]);
+                    for (int i = 0; i < NBG; ++i) store_bg(s_b[(grp + 1) & 1], i, rb[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < NBG; ++i) rb[i] = load_bg(grp + 2, i);
             }
-#pragma unroll
-            for (int i = 0; i < NBG; ++i) rb[i] = load_bg(grp + 2, i);
             if (dy == 0) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) ra[i] = load_a1(cb + 1, i);
             }
-            const uint4* __restrict__ sb = s_b[grp & 1];
+            const uint4* __restrict__ sb = s_b[NBUF == 2 ? (grp & 1) : 0];
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
@@ -395,7 +398,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(const ConvParams P
             }
             ++grp;
             __syncthreads();
-            if (dy == 2 && more_cb) {                           // every wave is done with this channel block's halo tile
+            if (NBUF == 1) {
+                // ONE weight buffer (41 KB of LDS per workgroup -> three workgroups per CU): everyone is done reading group grp - 1 and, at
+                // dy == 2, the halo tile; refill both from registers, fetch the group after, and meet again
+                if (grp < ngrp) {
+#pragma unroll
+                    for (int i = 0; i < NBG; ++i) store_bg(s_b[0], i, rb[i]);
+                }
+                if (dy == 2 && more_cb) {
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) store_a1(cb + 1, i, ra[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < NBG; ++i) rb[i] = load_bg(grp + 1, i);
+                __syncthreads();
+            } else if (dy == 2 && more_cb) {                    // every wave is done with this channel block's halo tile
 #pragma unroll
                 for (int i = 0; i < NA; ++i) store_a1(cb + 1, i, ra[i]);
                 __syncthreads();
@@ -594,13 +611,17 @@ int selftok_conv2d_nhwc_bf16(const void* x, const void* packed, const void* bias
     // wave (one workgroup per CU, half the weight traffic per pixel) and 4-wave 128 x 128 tiles: +27 % on the 128-channel layers at
     // 256 x 256, +3 ... 6 % elsewhere (profiles/r3_conv_launch_shapes.txt; the three are bit-identical).
     if (taps == 9) {
-        bool rows = P.ncb >= 8;      // >= 256 input channels: one barrier per kernel row, +2 ... 3 %; with 4 channel blocks its single halo buffer costs 12 %
+        // 3 x 3, stride 1: one barrier pair per kernel row, ONE weight buffer -> 41 KB of LDS and 78 VGPRs, three workgroups per CU.
+        // Measured against two weight buffers (two workgroups per CU) and against one barrier per tap: +2 ... 4 % and +3 ... 7 % on every
+        // layer shape of the VAE (profiles/r3_conv_launch_shapes.txt); the three are bit-identical.
+        int variant = 8;
 #ifdef SELFTOK_TUNE
-        if (const char* v = getenv("SELFTOK_CONV_VARIANT")) { if (v[0] == '2') rows = false; if (v[0] == '9') rows = true; }
+        if (const char* v = getenv("SELFTOK_CONV_VARIANT")) variant = v[0] - '0';
 #endif
-        if (!rows) return launch_conv_one<2, 4, 1, 9, 1>(P, stream);
+        if (variant == 2) return launch_conv_one<2, 4, 1, 9, 1>(P, stream);
         const int tiles = ((P.Wo + 31) / 32) * ((P.Ho + 3) / 4) * P.B;
-        hipLaunchKernelGGL(conv3x3_rows_kernel, dim3(tiles, (P.Cs + 127) / 128), dim3(512), 0, stream, P);
+        if (variant == 9) hipLaunchKernelGGL(conv3x3_rows_kernel<2>, dim3(tiles, (P.Cs + 127) / 128), dim3(512), 0, stream, P);
+        else hipLaunchKernelGGL(conv3x3_rows_kernel<1>, dim3(tiles, (P.Cs + 127) / 128), dim3(512), 0, stream, P);
         return check_launch("conv3x3_rows_kernel");
     }
     return launch_conv_one<2, 4, 1, 1, 1>(P, stream);

@@ -8,7 +8,7 @@ architectural mirror mimogpt/models/selftok/sd3/sd3_impls.py:215-474.
 Default (`mode="parity"`): channels-last activations, every convolution through our implicit-GEMM kernel (csrc/conv.hip: fp32 accumulation
 of bf16 products with the bias inside, ONE rounding -- the reference's CPU arithmetic -- with ResnetBlock's residual add, Upsample's
 nearest 2x and Downsample's padding fused), GroupNorm+SiLU by our fp64-statistics kernel, the single-head mid attention in torch ops
-that round where the CPU flash kernel rounds (`_attn_tokens`).  No MIOpen, bit-stable by construction, 106 ms per 64 images (encode +
+that round where the CPU flash kernel rounds (`_attn_tokens`).  No MIOpen, bit-stable by construction, 103 ms per 64 images (encode +
 decode) against 331 ms for the MIOpen route below and 185 ms for MIOpen's fastest (inaccurate) solvers.
 
 `mode="miopen"` keeps the route rounds 1-3 used to reach the same arithmetic through PyTorch-ROCm, `mode="fast"` the rounds 1-2 arithmetic.

@@ -1,6 +1,10 @@
-"""Launch shapes of the implicit-GEMM convolution (csrc/conv.hip), tune build only (tools/build_tune.sh + SELFTOK_HIP_LIB):
-SELFTOK_CONV_VARIANT 0 = 8 waves, 256 px x 128 ch per workgroup (64 x 64 per wave); 1 = 4 waves, 128 px x 128 ch (64 x 64 per wave);
-2 = 8 waves, 128 px x 128 ch (64 x 32 per wave, 120 VGPRs: two workgroups per CU).  Alternating runs, median of 5."""
+"""Launch shapes of the implicit-GEMM convolution (csrc/conv.hip), tune build only (tools/build_tune.sh + SELFTOK_HIP_LIB), SELFTOK_CONV_VARIANT:
+  0  conv_nhwc_bf16_kernel<4,2,2>: 8 waves, 256 px x 128 ch per workgroup (64 x 64 per wave), one barrier per tap
+  1  conv_nhwc_bf16_kernel<2,2,2>: 4 waves, 128 px x 128 ch (64 x 64 per wave)
+  2  conv_nhwc_bf16_kernel<2,4,1>: 8 waves, 128 px x 128 ch (64 x 32 per wave, 120 VGPRs: two workgroups per CU)
+  9  conv3x3_rows_kernel<2>: as 2 with one barrier per kernel row, two weight buffers (64 KB LDS: two workgroups per CU)
+  8  conv3x3_rows_kernel<1>: one weight buffer (41 KB LDS, 78 VGPRs: three workgroups per CU) -- the product's choice
+Alternating runs, median of 3 x 5 launches; the outputs of all variants must be bit-identical."""
 import os
 import statistics
 import sys
