@@ -417,7 +417,7 @@ def kernel_roofs(pipe, B, K, k_table):
         ag = torch.randn(B * Hh * Hh, 9 * C, device=dev).to(torch.bfloat16) if Hh <= 64 else None       # im2col-sized GEMM operand: 2.4 GB at 64 x 64 x 512
         wg = torch.randn(C, 9 * C, device=dev).to(torch.bfloat16)
         ms_lib = event_time_ms(lambda: F.linear(ag, wg), n=5, warm=2) if ag is not None else None
-        out.append({"kernel": "conv_nhwc_bf16_kernel<2,4,1,9,1> (implicit GEMM, fp32 accumulate incl. bias, one rounding)", "bound": "mfma(bf16), power-limited",
+        out.append({"kernel": "conv3x3_rows_kernel<1> (implicit GEMM, fp32 accumulate incl. bias, one rounding; csrc/conv.hip)", "bound": "mfma(bf16), power-limited",
                     "shape": f"[{B},{Hh},{Hh},{C}] -> {C}, 3x3 ({note})", "avg_launch_ms": round(ms, 4), "achieved": round(fl / ms / 1e9, 1), "peak": F16_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / F16_MFMA_PEAK_TFLOPS, 4),
                     "vendor_bf16_gemm_same_flops_ms": None if ms_lib is None else round(ms_lib, 4)})
