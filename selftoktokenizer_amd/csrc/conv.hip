@@ -204,7 +204,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_nhwc_bf16_kernel(const C
     // registers).  Tap and slab parity are compile-time constants (integral_constant), so every staging register has a static name:
     // at slab s the set named by parity s & 1 holds slab s + 1 (written to LDS at the end), the other set receives slab s + 2.
     constexpr int NAH = (NA + 1) / 2;                           // chunks per half
-    uint4 ra[NAH], rb0[NB], rb1[NB];
+    // 1 x 1 convolutions have a new halo tile every slab: with one chunk per thread it is pipelined like the weights (loaded two slabs
+    // ahead into the set the slab parity names, written one slab ahead)
+    constexpr bool PIPE1 = TAPS == 1 && ABUF == 2 && NA == 1;
+    uint4 ra[NAH], ra2[NAH], rb0[NB], rb1[NB];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -218,6 +221,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_nhwc_bf16_kernel(const C
     for (int i = 0; i < NB; ++i) store_b1(s_b0, i, rb0[i]);
 #pragma unroll
     for (int i = 0; i < NB; ++i) { rb0[i] = load_b1(1, i); rb1[i] = rb0[i]; }
+#pragma unroll
+    for (int i = 0; i < NAH; ++i) { ra2[i] = ra[i]; if (PIPE1) ra[i] = load_a1(1, i); }
     __syncthreads();
 
     int slab = 0;
@@ -229,6 +234,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_nhwc_bf16_kernel(const C
             constexpr int tap = decltype(tap_c)::value, par = decltype(par_c)::value;       // par = slab & 1
 #pragma unroll
             for (int i = 0; i < NB; ++i) { if (par == 0) rb1[i] = load_b1(slab + 2, i); else rb0[i] = load_b1(slab + 2, i); }      // clamped past the end
+            if (PIPE1) {
+                if (par == 0) ra2[0] = load_a1(cb + 2, 0); else ra[0] = load_a1(cb + 2, 0);
+            }
             if (ABUF == 2 && TAPS == 9 && (tap == 0 || tap == 4)) {          // unconditional (address clamped): no select on the result
 #pragma unroll
                 for (int i = 0; i < NAH; ++i) if ((tap / 4) * NAH + i < NA) ra[i] = load_a1(cb + 1, (tap / 4) * NAH + i);
@@ -251,7 +259,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_nhwc_bf16_kernel(const C
 #pragma unroll
                 for (int i = 0; i < NAH; ++i) if ((tap / 4) * NAH + i < NA) store_a1(sa_next, cb + 1, (tap / 4) * NAH + i, ra[i]);
             }
-            if ((ABUF == 1 || TAPS == 1) && tap == TAPS - 1 && more_cb) {       // single halo buffer (stride 2) / 1x1: load and write here
+            if (PIPE1 && more_cb) store_a1(sa_next, cb + 1, 0, par == 0 ? ra[0] : ra2[0]);
+            if ((ABUF == 1 || TAPS == 1) && !PIPE1 && tap == TAPS - 1 && more_cb) {       // single halo buffer (stride 2) / wide 1x1 tiles: load and write here
                 if (ABUF == 1) __syncthreads();
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -614,14 +623,14 @@ int selftok_conv2d_nhwc_bf16(const void* x, const void* packed, const void* bias
         // 3 x 3, stride 1: one barrier pair per kernel row, ONE weight buffer -> 41 KB of LDS and 78 VGPRs, three workgroups per CU.
         // Measured against two weight buffers (two workgroups per CU) and against one barrier per tap: +2 ... 4 % and +3 ... 7 % on every
         // layer shape of the VAE (profiles/r3_conv_launch_shapes.txt); the three are bit-identical.
-        int variant = 8;
-#ifdef SELFTOK_TUNE
-        if (const char* v = getenv("SELFTOK_CONV_VARIANT")) variant = v[0] - '0';
-#endif
-        if (variant == 2) return launch_conv_one<2, 4, 1, 9, 1>(P, stream);
         const int tiles = ((P.Wo + 31) / 32) * ((P.Ho + 3) / 4) * P.B;
-        if (variant == 9) hipLaunchKernelGGL(conv3x3_rows_kernel<2>, dim3(tiles, (P.Cs + 127) / 128), dim3(512), 0, stream, P);
-        else hipLaunchKernelGGL(conv3x3_rows_kernel<1>, dim3(tiles, (P.Cs + 127) / 128), dim3(512), 0, stream, P);
+#ifdef SELFTOK_TUNE
+        if (const char* v = getenv("SELFTOK_CONV_VARIANT")) {
+            if (v[0] == '2') return launch_conv_one<2, 4, 1, 9, 1>(P, stream);
+            if (v[0] == '9') { hipLaunchKernelGGL(conv3x3_rows_kernel<2>, dim3(tiles, (P.Cs + 127) / 128), dim3(512), 0, stream, P); return check_launch("conv3x3_rows_kernel<2>"); }
+        }
+#endif
+        hipLaunchKernelGGL(conv3x3_rows_kernel<1>, dim3(tiles, (P.Cs + 127) / 128), dim3(512), 0, stream, P);
         return check_launch("conv3x3_rows_kernel");
     }
     return launch_conv_one<2, 4, 1, 1, 1>(P, stream);
