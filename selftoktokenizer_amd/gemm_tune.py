@@ -91,7 +91,8 @@ def autotune_linears(row_counts: Iterable[int], device: torch.device, reps: Opti
             # two passes over the candidates (the chip's clock drifts over the first launches of a shape): each candidate keeps its
             # faster pass
             times = {}
-            probes = {}
+            ncand = len(candidates) + 1
+            pool = {M: torch.randn(M + 2 + 2 * ncand, K, device=device) for M in reps}      # one buffer per representative row count; a probe is a row prefix
             for rnd in range(2):
                 for ci, cand in enumerate((None,) + tuple(candidates)):
                     total = 0.0
@@ -102,12 +103,10 @@ def autotune_linears(row_counts: Iterable[int], device: torch.device, reps: Opti
                             probe_id += 1
                             _write(path, [(_key(N, Mp, K), cand)])
                             tun.read_file(path)
-                        a = probes.get(Mp)
-                        if a is None:
-                            a = probes[Mp] = torch.randn(Mp, K, device=device)
+                        a = pool[M][:Mp]
                         total += _time(lambda: F.linear(a, w, bias))
                     times[cand] = min(times.get(cand, float("inf")), total)
-            probes.clear()
+            pool.clear()
             best = min(times, key=times.get)
             if best is not None and times[best] > 0.99 * times[None]:          # below the timing noise: keep the default
                 best = None
