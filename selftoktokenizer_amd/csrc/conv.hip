@@ -11,15 +11,20 @@
 //
 //   * NHWC activations ([B, H, W, C], C % 8 == 0): the contraction index (ci) is contiguous for both operands, so a 16-byte LDS read
 //     is one MFMA operand (8 bf16) with no transposition anywhere;
-//   * a workgroup (4 waves) owns TH x 32 output pixels x BN output channels.  Per block of 32 input channels it stages the input halo
+//   * a workgroup (8 waves; 4 for the narrow / stride-2 shapes) owns TH x 32 output pixels x BN output channels.  Per block of 32 input channels it stages the input halo
 //     tile ((TH-1)S+3) x (31S+3) pixels x 64 B ONCE and runs all 9 taps from it (tap = an address offset into the tile): global/L2 reads
 //     of the activations are 1/9 of the matrix-core operand reads; weights arrive as one contiguous 64 B x BN slab per (channel block,
 //     tap) from a pre-packed image.  Out-of-image pixels are zero-filled while staging (padding), the optional nearest 2x upsample
 //     of Upsample (sd3_impls.py:300-306) is an address shift while staging (the 4x larger tensor is never written);
 //   * LDS rows are 64 B (32 channels) with the 16-byte chunk index XOR-ed by (row >> 2) & 3: every ds_read_b128 of 32 consecutive
-//     pixels (or output channels) is conflict-free for any tap shift (checked exhaustively; stride-2 taps are 2-way);
-//   * register-prefetched double buffer: the next slab's global loads are issued before the current slab's 8 MFMAs per wave and
-//     written to the other LDS buffer after them -- one barrier per slab;
+//     output channels (weight slabs) is conflict-free; halo-tile rows are 80 B instead (64 B + 16 B pad): any 32 consecutive pixels hit
+//     64 distinct banks, and a tap becomes a compile-time byte offset (stride-2 taps are 2-way);
+//   * staging goes through registers with the loads issued one kernel row (or two slabs) ahead and NEVER followed by a select on the
+//     loaded value (that would park the wave on the load in the slab that issued it): out-of-range chunks load from a clamped address
+//     and are zeroed when written to LDS.  What moved the kernel was co-residency: 78 VGPRs and 41 KB of LDS (one halo tile, ONE weight
+//     buffer refilled between two barriers per kernel row) let three 8-wave workgroups share a CU, so one's prologue, epilogue and
+//     barriers hide behind the others' matrix work (conv3x3_rows_kernel<1>; the per-tap conv_nhwc_bf16_kernel serves 1x1, stride-2
+//     and narrow-output layers);
 //   * v_mfma_f32_32x32x16_bf16 with the WEIGHTS as the row operand: a lane then holds 4 consecutive output channels of one pixel per
 //     accumulator quad, i.e. 8-byte NHWC stores straight from the accumulators;
 //   * epilogue: + bias in fp32, one rounding to bf16; optional residual `x + h` (ResnetBlock.forward :262) with the reference's second
