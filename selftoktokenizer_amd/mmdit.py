@@ -245,13 +245,15 @@ class MMDiTGPU(ModuleSurface):
                          tables=tables)
 
     @torch.no_grad()
-    def gather_context(self, ctx0: torch.Tensor, visible: torch.Tensor):
+    def gather_context(self, ctx0: torch.Tensor, visible: torch.Tensor = None, index: torch.Tensor = None):
         """A visibility pattern over the context tokens that is not a prefix (the reference's `super_mask`, rectified_flow.py:226-227).
         A masked context token is a key nobody can attend to, and its own row feeds nothing but its keys / values in later blocks
         (the model returns the image stream only): dropping the masked rows is exact.  Returns the visible rows of ctx0 in token order,
         the matching rows of the 23 position tables, and the sorted visible positions -- with them the sampler's step mask
-        `arange(K) <= k` is again a PREFIX (of the visible list) and the truncated-context path applies unchanged."""
-        idx = torch.nonzero(visible.to(self.device).reshape(-1).bool())[:, 0]
+        `arange(K) <= k` is again a PREFIX (of the visible list) and the truncated-context path applies unchanged.
+        `index`: the sorted visible positions as a device tensor, instead of the mask (no `nonzero` = no host synchronisation: legal
+        inside a hipGraph capture)."""
+        idx = index if index is not None else torch.nonzero(visible.to(self.device).reshape(-1).bool())[:, 0]
         return ctx0[:, idx].contiguous(), [t[idx].contiguous() for t in self.ctx_tables], idx
 
     @torch.no_grad()

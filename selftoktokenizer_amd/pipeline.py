@@ -80,30 +80,39 @@ class _Flow(FlowSchedule):
         t_unc = torch.floor(torch.from_numpy(self.scheduled_t) * 1000).int().clamp(0, 999)
         self.t_freq_uncond = sinusoid_host(t_unc).to(device)
 
+    def resolve_super_mask(self, super_mask, K: int):
+        """[K] (or batch-uniform [B,K]) visibility pattern -> (device int64 index of the visible tokens, their positions as numpy)"""
+        sm = torch.as_tensor(super_mask).cpu()
+        if sm.dim() == 2:
+            if not bool((sm == sm[:1]).all()):
+                raise NotImplementedError("a super_mask that differs between the samples of a batch is not implemented "
+                                          "(decode the samples separately, or pass one [K] pattern)")
+            sm = sm[0]
+        if sm.numel() != K:
+            raise ValueError(f"super_mask has {sm.numel()} entries, the tokenizer has K = {K} tokens")
+        vis_pos = np.nonzero(sm.reshape(-1).bool().numpy())[0].astype(np.int64)
+        return torch.from_numpy(vis_pos).to(self.device), vis_pos
+
     @torch.no_grad()
     def p_sample_loop(self, dit: MMDiTGPU, noise: torch.Tensor, ehs: torch.Tensor, k_table: np.ndarray,
                       context_see_xt: bool = True, uncond_scale: float = 1.0, max_steps: Optional[int] = None,
-                      trace: Optional[list] = None, prefix_k: Optional[int] = None, super_mask=None) -> torch.Tensor:
+                      trace: Optional[list] = None, prefix_k: Optional[int] = None, super_mask=None, visible=None) -> torch.Tensor:
         """`prefix_k`: the reference loop's `super_mask` (rectified_flow.py:226-227, mask = mask * super_mask) for the prefix mask
         arange(K) < prefix_k -- only the first prefix_k tokens are ever visible (decode from a partial token sequence).
         `super_mask`: the same hook for ANY visibility pattern over the K tokens ([K] bool / 0-1, the same for every sample): the visible
-        tokens are gathered once (MMDiTGPU.gather_context) and the step mask is a prefix of that list."""
+        tokens are gathered once (MMDiTGPU.gather_context) and the step mask is a prefix of that list.  `visible`: the same pattern
+        already resolved by `resolve_super_mask` -- what a caller that captures this loop in a hipGraph passes (the resolution reads
+        the mask on the host and uploads an index tensor, neither of which may happen while a stream is capturing)."""
         B = noise.shape[0]
         x = noise.to(self.device).float().contiguous()
         hp, wp = x.shape[-2] // 2, x.shape[-1] // 2
         ctx0 = dit.embed_context(ehs)                                         # step independent
         tables, vis_pos = None, None
-        if super_mask is not None:
-            sm = torch.as_tensor(super_mask)
-            if sm.dim() == 2:
-                if not bool((sm == sm[:1]).all()):
-                    raise NotImplementedError("a super_mask that differs between the samples of a batch is not implemented "
-                                              "(decode the samples separately, or pass one [K] pattern)")
-                sm = sm[0]
-            if sm.numel() != ctx0.shape[1]:
-                raise ValueError(f"super_mask has {sm.numel()} entries, the tokenizer has K = {ctx0.shape[1]} tokens")
-            ctx0, tables, vis_pos = dit.gather_context(ctx0, sm)
-            vis_pos = vis_pos.cpu().numpy()
+        if visible is None and super_mask is not None:
+            visible = self.resolve_super_mask(super_mask, ctx0.shape[1])
+        if visible is not None:
+            idx_dev, vis_pos = visible                                        # device index tensor (made outside any capture), host positions
+            ctx0, tables, _ = dit.gather_context(ctx0, index=idx_dev)
         cqkv0 = dit.block0_context_qkv(ctx0, tables) if ctx0.shape[1] > 0 else None   # block 0's context QKV is step independent too
         steps = self.num_timesteps if max_steps is None else min(max_steps, self.num_timesteps)
         for i in range(steps):
@@ -155,12 +164,16 @@ class SelftokPipeline():
         `state_dict` / `vae_state_dict` (extensions) bypass the files, e.g. with weights.synthetic_state_dict().
         `gemm` (extension): arithmetic of the MMDiT block Linears, 'fp32' (hipBLASLt fp32) or 'f16x2' (fp32-equivalent
         split GEMM on the f16 matrix cores, csrc/gemm_split.hip); default from $SELFTOK_GEMM, else DEFAULT_GEMM.
-        `vae_mode` (extension): 'parity' (default; bias inside the accumulation, deterministic GEMM algorithm) or 'fast'
-        (MIOpen's searched solvers, 1.8x faster convolutions, looser parity: see vae.AutoencoderKLGPU); default from $SELFTOK_VAE.
-        `tune_gemm` (extension): pick hipBLASLt's kernel for the fp32 block Linears by a 4-second measurement at the first decode of a
-        batch size (gemm_tune.py; switches torch.cuda.tunable on with tuning off); default from $SELFTOK_TUNE_GEMM, else on."""
+        `vae_mode` (extension): 'parity' (default: every convolution / GroupNorm through csrc/conv.hip -- fp32 accumulation with the
+        bias inside, one rounding, the reference's CPU arithmetic; no MIOpen, bit-stable, batch independent), 'miopen' (the same
+        arithmetic coaxed out of MIOpen's GEMM algorithm, 3x slower) or 'fast' (MIOpen's searched solvers with a separate bias add:
+        looser parity, not bit-stable; see vae.AutoencoderKLGPU); default from $SELFTOK_VAE.
+        `tune_gemm` (extension, OPT-IN): pick hipBLASLt's kernel for the fp32 block Linears by a ~4 s measurement per batch size
+        (gemm_tune.py) -- up front through `pipe.tune_linears(batch)`, or at the first decode of a batch size.  TunableOp is enabled
+        (tuning off) only inside this pipeline's own sampler calls and the caller's torch.cuda.tunable flags are restored; on another
+        hipBLASLt build than the one the candidate kernels were found with it does nothing, loudly.  Default from $SELFTOK_TUNE_GEMM, else off."""
         _lib.load()                                                           # fail loudly if the HIP library is missing
-        self.tune_gemm = (os.environ.get("SELFTOK_TUNE_GEMM", "1") != "0") if tune_gemm is None else bool(tune_gemm)
+        self.tune_gemm = (os.environ.get("SELFTOK_TUNE_GEMM", "0") == "1") if tune_gemm is None else bool(tune_gemm)
         self.gemm_tune_report = None
         if device is None:
             device = "cuda"
@@ -190,6 +203,9 @@ class SelftokPipeline():
         cut = p.get("cut_of_k", None)
         if cut and float(cut) < 1:
             raise NotImplementedError("cut_of_k < 1 (context padding, rectified_flow.py:216-224) is not implemented; the shipped configs do not set it")
+        if bool(p.get("encoder_config", {}).get("pre_norm", False)):
+            raise NotImplementedError("encoder_config.pre_norm = True (Encoder.forward applies final_layer_norm to the image tokens, "
+                                      "models_ours.py:219-220) is not implemented; the shipped configs set it False")
         K = int(p.k)
         renderer = "Renderer" in str(p.model)
         self.diti = DiTiCont(1000, K, p.stages, p.k_per_stage)
@@ -269,11 +285,28 @@ class SelftokPipeline():
         return norm_ip(recons, -1, 1)
 
     @_on_own_device
+    def tune_linears(self, batch: int, renderer: Optional[bool] = None, guided: bool = False):
+        """(extension) measure hipBLASLt's candidate kernels for the fp32 block Linears of a decode at `batch` images now (~4 s, once
+        per batch size; gemm_tune.py) and switch `tune_gemm` on, so that this pipeline's sampler calls run under TunableOp with the
+        winners.  `guided`: a CFG decode (two MMDiT passes per step, rows of 2 x batch).  Returns the report ({(N, K): (kernel or None,
+        ms default, ms chosen)}), or None in f16x2 mode / on another hipBLASLt build."""
+        self.tune_gemm = True
+        tokens = (self.datasize // 16) ** 2
+        renderer = self.model.model.renderer if renderer is None else renderer
+        self._tune_linears(int(batch) * (2 if guided else 1), [self.K - 1] if renderer else self.k_table, tokens)
+        return self.gemm_tune_report
+
+    @_on_own_device
     def _tune_linears(self, B: int, k_table, image_tokens: int) -> None:
         """fp32 mode: choose hipBLASLt's kernels for this batch size's block Linears once (gemm_tune.py)"""
         if self.tune_gemm and self.model.model.gemm == "fp32":
             rows, reps = gemm_tune.step_row_counts(B, k_table, image_tokens)
             self.gemm_tune_report = gemm_tune.autotune_linears(rows, self.device, reps=reps, verbose=self.verbose)
+
+    def _tunable_scope(self):
+        """TunableOp on for the duration of one of OUR sampler calls when kernels were installed; the caller's flags come back after"""
+        import contextlib
+        return gemm_tune.enabled() if (self.tune_gemm and self.gemm_tune_report and self.model.model.gemm == "fp32") else contextlib.nullcontext()
 
     def set_gemm(self, mode: str) -> str:
         """switch the MMDiT block Linears between 'fp32' and 'f16x2' (see MMDiTGPU.set_gemm); returns the mode in force"""
@@ -302,14 +335,15 @@ class SelftokPipeline():
         if not use_graph:
             return self.flow.p_sample_loop(self.model.model, xt, ehs, self.k_table, context_see_xt=True,
                                            uncond_scale=uncond_scale, max_steps=max_steps, prefix_k=prefix_k, super_mask=super_mask)
-        sm_key = None if super_mask is None else np.asarray(torch.as_tensor(super_mask).cpu()).astype(bool).tobytes()
+        visible = None if super_mask is None else self.flow.resolve_super_mask(super_mask, self.K)     # host read + upload: before the capture
+        sm_key = None if visible is None else visible[1].tobytes()
         key = (tuple(xt.shape), tuple(ehs.shape), max_steps, float(uncond_scale), self.model.model.gemm, prefix_k, sm_key)
         if key not in self._graphs:
             s_noise = torch.empty(xt.shape, dtype=torch.float32, device=self.device)
             s_ehs = torch.empty_like(ehs)
             s_noise.copy_(xt); s_ehs.copy_(ehs)
             run = lambda: self.flow.p_sample_loop(self.model.model, s_noise, s_ehs, self.k_table, context_see_xt=True,
-                                                  uncond_scale=uncond_scale, max_steps=max_steps, prefix_k=prefix_k, super_mask=super_mask)
+                                                  uncond_scale=uncond_scale, max_steps=max_steps, prefix_k=prefix_k, visible=visible)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):       # warm-up outside capture (hipBLASLt / allocator warm)
@@ -346,7 +380,8 @@ class SelftokPipeline():
         latent_dim = self.datasize // 8
         xt = noise if noise is not None else torch.randn(B, 16, latent_dim, latent_dim)
         self._tune_linears(B * (2 if uncond_scale != 1.0 else 1), self.k_table, (latent_dim // 2) ** 2)
-        pred_x0 = self._checked(lambda: self._sample(xt, ehs, max_steps, uncond_scale, use_graph, prefix_k, super_mask))
+        with self._tunable_scope():
+            pred_x0 = self._checked(lambda: self._sample(xt, ehs, max_steps, uncond_scale, use_graph, prefix_k, super_mask))
         recons = self._to_pixels(pred_x0)
         self._say('End decoding.')
         return (recons, pred_x0) if return_latent else recons
@@ -358,7 +393,8 @@ class SelftokPipeline():
         self._say("Begin decoding with Renderer.")
         outs_q = self._codes(idx)
         self._tune_linears(outs_q.shape[0], [self.K - 1], (self.datasize // 16) ** 2)
-        pred_x0 = self._checked(lambda: self.model.model(y=None, encoder_hidden_states=outs_q)[0])
+        with self._tunable_scope():
+            pred_x0 = self._checked(lambda: self.model.model(y=None, encoder_hidden_states=outs_q)[0])
         recons = self._to_pixels(pred_x0)
         self._say('End decoding with Renderer.')
         return (recons, pred_x0) if return_latent else recons

@@ -27,3 +27,37 @@ def run():
     assert diff < 1e-5 and int(pipe.model.model.overflow.item()) == 0, diff
     torch.cuda.synchronize()
     print("[smoke] pipeline ok: encode -> 512 ids, 2-step decode -> pixels in [0,1]; f16x2 vs fp32 latents max diff %.1e" % diff)
+    rccl_single_rank(tokens)
+
+
+def rccl_single_rank(tokens):
+    """the path's one exchange step over RCCL with the ONE rank a smoke box has: communicator bound to the GPU, int64 -> int32 cast,
+    side stream, event join, barrier -- the same code an 8-GPU run executes, minus the xGMI transport (dist.force_single_rank)"""
+    import os
+    import socket
+    import torch.distributed as dist
+    from . import dist as D
+    if dist.is_initialized():
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    saved = {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        D.init_from_env("nccl", single_rank_group=True)
+        prev = D.force_single_rank(True)
+        try:
+            g = D.id_gatherer(tokens.shape[0], tokens.shape[1], tokens.device)
+            g.launch(tokens, timed=True)
+            out = g.wait()
+            assert g.active and g.recv.is_cuda and torch.equal(out, tokens) and out.data_ptr() != tokens.data_ptr()
+            ms = g.last_ms()
+            D.barrier()
+        finally:
+            D.force_single_rank(prev)
+            D.shutdown()
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    print("[smoke] RCCL ok: one-rank all-gather of the ids on a side stream (%.3f ms), event join, barrier" % ms)

@@ -61,8 +61,11 @@ def _step_worker(rank, world, port, total, q):
         out = g.wait()
         per_step.append({k: calls[k] - before[k] for k in calls})
         ok = ok and bool(torch.equal(out, all_ids)) and out.dtype == torch.int64
-        ok = ok and bool(torch.equal(D.all_gather_ids(all_ids[lo:hi].to(torch.int32)), all_ids.to(torch.int32)))   # cached gatherer: 1 more
-    ok = ok and all(s == {"into": 1, "list": 0, "other": 0} for s in per_step) and g.collectives == 6
+        before = dict(calls)
+        ok = ok and bool(torch.equal(D.all_gather_ids(all_ids[lo:hi].to(torch.int32)), all_ids.to(torch.int32)))
+        # the convenience call owns its own buffers and re-agrees the shard sizes every time: sizes + payload
+        ok = ok and {k: calls[k] - before[k] for k in calls} == {"into": 2, "list": 0, "other": 0}
+    ok = ok and all(s == {"into": 1, "list": 0, "other": 0} for s in per_step) and g.collectives == 3
     ok = ok and g.payload_bytes == w * g.bmax * 512 * 4
     q.put((rank, ok, per_step))
     D.shutdown()
@@ -81,6 +84,70 @@ def test_one_collective_per_step_world2_gloo():
             p.join(timeout=60)
             assert p.exitcode == 0
         assert all(ok for _, ok, _ in res), res
+
+
+def _resharding_worker(rank, world, port, totals, q):
+    """the global batch changes between calls such that ONE rank's shard keeps its size and the other's does not
+    (5 -> (3,2), 6 -> (3,3), 4 -> (2,2), 5 again).  Every rank must issue the same collectives and get the right matrix each time."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = D.init_from_env("gloo")
+    ok = True
+    for j, total in enumerate(totals):
+        lo, hi = D.shard_range(total, r, w)
+        all_ids = torch.from_numpy(synth.synthetic_token_ids(total, first_index=3 * j))
+        out = D.all_gather_ids(all_ids[lo:hi])
+        ok = ok and tuple(out.shape) == (total, 512) and bool(torch.equal(out, all_ids))
+        out2, ms = D.all_gather_ids_timed(all_ids[lo:hi])
+        ok = ok and bool(torch.equal(out2, all_ids)) and ms >= 0.0
+    q.put((rank, ok))
+    D.shutdown()
+
+
+def test_all_gather_ids_survives_a_changing_global_batch_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_resharding_worker, args=(r, 2, port, (5, 6, 4, 5, 7, 1), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+
+
+def _single_rank_worker(port, q):
+    """the forced single-rank group: every helper takes its collective path with ONE rank (what the -m gpu test does over RCCL)"""
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    assert D.init_from_env("gloo") == (0, 1, 0) and not torch.distributed.is_initialized()      # one rank: no group by default
+    D.init_from_env("gloo", single_rank_group=True)
+    ids = torch.from_numpy(synth.synthetic_token_ids(3))
+    ok = D.all_gather_ids(ids) is ids and D.backend_name() is None                              # not forced: pass-through
+    prev = D.force_single_rank(True)
+    g = D.IdGatherer(3, 512, "cpu")
+    g.launch(ids, timed=True)
+    out = g.wait()
+    ok = ok and prev is False and g.active and g.collectives == 1 and out is not ids and bool(torch.equal(out, ids))
+    ok = ok and g.payload_bytes == 3 * 512 * 4 and D.backend_name() == "gloo"
+    ok = ok and bool(torch.equal(D.all_gather_ids(ids.to(torch.int16)), ids.to(torch.int16)))
+    t = torch.arange(4.0)
+    ok = ok and bool(torch.equal(D.all_reduce_sum_(t.clone()), t)) and bool(torch.equal(D.all_gather_rows(t[:, None], [4]), t[:, None]))
+    ok = ok and bool(torch.equal(D.broadcast_(t.clone()), t)) and D.max_over_ranks(2.5, "cpu") == 2.5
+    D.barrier()
+    D.force_single_rank(False)
+    D.shutdown()
+    q.put(ok)
+
+
+def test_forced_single_rank_group_takes_the_collective_path():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_rank_worker, args=(36500 + (os.getpid() % 2000), q))
+    p.start()
+    assert q.get(timeout=120) is True
+    p.join(timeout=60)
+    assert p.exitcode == 0
 
 
 def _run(total):

@@ -180,21 +180,40 @@ def test_residual_epilogue_bit_identical(B, T, N, K):
     assert int(flag.item()) == 0
 
 
-def test_gemm_tune_installs_measured_kernels_and_keeps_the_numbers():
+def test_gemm_tune_installs_measured_kernels_and_keeps_the_numbers(capsys):
     """gemm_tune.autotune_linears: every family gets a report entry; whatever kernel it installs for a row count of the step, the Linear's
-    result stays an fp32 GEMM of the same accuracy against fp64 as the default kernel's (a different summation order, nothing else)."""
+    result stays an fp32 GEMM of the same accuracy against fp64 as the default kernel's (a different summation order, nothing else).
+    Hygiene: torch.cuda.tunable's flags are the caller's again afterwards; candidates of another
+    hipBLASLt build are not touched; a candidate name the library does not know is dropped, not raised."""
     from selftoktokenizer_amd import gemm_tune as G
+    tun = torch.cuda.tunable
+    flags0 = (tun.is_enabled(), tun.tuning_is_enabled())
     rows, reps = G.step_row_counts(8, [511, 300, 77], 256)
     M = reps[1]
     a = torch.randn(M, 1536, device="cuda")
     w, b = torch.randn(4608, 1536, device="cuda") * 0.03, torch.randn(4608, device="cuda")
     before = torch.nn.functional.linear(a, w, b)
+    # another library build: no-op, said loudly, nothing enabled
+    assert G.autotune_linears([3, 5], torch.device("cuda"), found_with={"HIPBLASLT_VERSION": "some-other-build"}) is None
+    assert "not tuning" in capsys.readouterr().out and (tun.is_enabled(), tun.tuning_is_enabled()) == flags0
+    ok, why = G.validators_match()
+    print("validators:", dict(tun.get_validators()), "match:", ok, why)
+    if not ok:                                      # a box with another hipBLASLt than the candidates' build: the no-op path is the contract
+        assert G.autotune_linears(rows, torch.device("cuda"), reps=reps) is None
+        return
+    # a solution name this library does not have is dropped (TunableOp raises inside the probing F.linear), the rest is measured
+    rep_bad = G.autotune_linears([M + 64], torch.device("cuda"), families=((4608, 1536),), candidates=("Gemm_Hipblaslt_999999999",) + G.CANDIDATES[:2])
+    assert rep_bad is not None and rep_bad[(4608, 1536)][0] in (None,) + G.CANDIDATES[:2]
     rep = G.autotune_linears(rows, torch.device("cuda"), reps=reps)
     assert rep is not None and set(rep) == set(G.FAMILIES)
     for fam, (best, t0, t1) in rep.items():
         assert best is None or (best in G.CANDIDATES and t1 <= t0), (fam, best, t0, t1)
     print({f"{n}x{k}": (b_ or "default", t0, t1) for (n, k), (b_, t0, t1) in rep.items()})
-    after = torch.nn.functional.linear(a, w, b)
+    assert (tun.is_enabled(), tun.tuning_is_enabled()) == flags0, "gemm_tune left torch.cuda.tunable's global flags changed"
+    with G.enabled() as on:
+        assert on and tun.is_enabled() and not tun.tuning_is_enabled()
+        after = torch.nn.functional.linear(a, w, b)
+    assert (tun.is_enabled(), tun.tuning_is_enabled()) == flags0
     ref = (a.double() @ w.double().t() + b.double())
     e0, e1 = float((before.double() - ref).abs().max()), float((after.double() - ref).abs().max())
     print(f"max abs err vs fp64: default kernel {e0:.2e}, installed kernel {e1:.2e}")

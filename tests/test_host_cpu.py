@@ -273,7 +273,7 @@ def test_unsupported_config_knobs_are_refused_not_ignored():
     before touching a GPU (cut_of_k < 1 cannot even run through the reference's own SelftokPipeline: p_sample_loop concatenates a
     super_mask the pipeline never passes, rectified_flow.py:216-222).  parameterization 'x0' IS implemented since round 3."""
     src = open(os.path.join(ROOT, "selftoktokenizer_amd", "pipeline.py")).read()
-    assert "cut_of_k < 1" in src and src.count("raise NotImplementedError") >= 2
+    assert "cut_of_k < 1" in src and src.count("raise NotImplementedError") >= 3 and "encoder_config.pre_norm = True" in src
     from selftoktokenizer_amd.pipeline import _Flow
     assert _Flow(50, 1.0, "cpu", "x0").parameterization == "x0" and _Flow(50, 1.0, "cpu").parameterization == "velocity"
     with pytest.raises(ValueError):
@@ -357,3 +357,9 @@ def test_gemm_tune_row_counts_and_file_format(tmp_path):
     assert G._key(4608, 16384, 1536) == "tn_4608_16384_1536_ld_1536_1536_4608"      # GemmAndBiasParams::Signature of F.linear([16384,1536], [4608,1536], b)
     assert G.FAMILIES == ((4608, 1536), (1536, 1536), (6144, 1536), (1536, 6144))
     assert G.autotune_linears([], None) is None                                       # nothing to do without rows / a GPU
+    # the candidates are solution indices of ONE library build: the module names it, and the pipeline's switch is opt-in
+    assert set(G.FOUND_WITH) == {"HIPBLASLT_VERSION", "GCN_ARCH_NAME"} and G.FOUND_WITH["GCN_ARCH_NAME"].startswith("gfx950")
+    with G.enabled() as on:                                                           # no GPU: the scope is a no-op
+        assert on is False
+    src = open(os.path.join(ROOT, "selftoktokenizer_amd", "pipeline.py")).read()
+    assert 'os.environ.get("SELFTOK_TUNE_GEMM", "0") == "1"' in src

@@ -324,16 +324,22 @@ def test_hipgraph_replay_equals_eager(pipe):
 
 def test_full_batch_size_independence(pipe):
     """BASELINE configs[1] batch (B=64): every image's tokens / latent must not depend on its batch-mates.
-    GEMM tilings differ between M=64*768 and M=8*768, so allow fp32 noise: tokens >= 99.9 % equal, latents 1e-4."""
+    The parity VAE (csrc/conv.hip + the fp64-statistics GroupNorm: no library, no solver choice, fixed summation order per output
+    element) is batch independent BY CONSTRUCTION: its latents at B = 64 and in 8 chunks of 8 must be bit-identical.  Behind it the
+    fp32 tokenizer's library GEMMs tile M = 64*768 and M = 8*768 differently, so ids may differ at fp32 noise: >= 99.9 % equal."""
     B = 64
     imgs = synth.synthetic_images(B, device="cuda")
+    assert pipe.vae.mode == "parity"
+    x0 = pipe.encode_latents(imgs)
+    x0_chunks = torch.cat([pipe.encode_latents(imgs[i:i + 8]) for i in range(0, B, 8)])
+    assert torch.equal(x0, x0_chunks), "the parity VAE's latents depend on the batch size"
+    assert torch.equal(x0[5:6], pipe.encode_latents(imgs[5:6]))
     tok_all = pipe.encoding(imgs)
     tok_chunks = torch.cat([pipe.encoding(imgs[i:i + 8]) for i in range(0, B, 8)])
     match = float((tok_all == tok_chunks).float().mean())
-    print("token match B=64 vs 8x8 through the bf16 VAE (MIOpen picks other conv algorithms per batch size):", match)
-    assert match >= 0.99
-    # the fp32 tokenizer alone (same latents): only fp32 GEMM tiling noise remains
-    x0 = pipe.encode_latents(imgs)
+    print("token match B=64 vs 8x8 from pixels (identical VAE latents; fp32 GEMM tiling noise in the tokenizer):", match)
+    assert match >= 0.999
+    # the fp32 tokenizer alone (same latents): the same fp32 GEMM tiling noise
     t_all = pipe.model.encoder(x0, d=None)[1]
     t_chunks = torch.cat([pipe.model.encoder(x0[i:i + 8], d=None)[1] for i in range(0, B, 8)])
     match32 = float((t_all == t_chunks).float().mean())
@@ -391,3 +397,8 @@ def test_sampler_options_vs_reference(pipe, gemm):
         pipe.decoding(np.repeat(g["ids"], 2, 0), noise=synth.synthetic_noise(2), max_steps=1, super_mask=np.stack([pre, ~pre]))
     with pytest.raises(ValueError):
         pipe.decoding(g["ids"], noise=noise, max_steps=1, super_mask=np.ones(100, bool))
+    # a non-prefix pattern inside a hipGraph capture (the mask is resolved on the host BEFORE the capture)
+    _, lg = pipe.decoding(g["ids"], noise=noise, max_steps=2, super_mask=g["super_mask"], return_latent=True, use_graph=True)
+    assert torch.equal(lg, la)
+    _, lg2 = pipe.decoding(ids2, noise=noise, max_steps=2, super_mask=g["super_mask"], return_latent=True, use_graph=True)    # replay
+    assert torch.equal(lg2, la)
