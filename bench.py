@@ -59,7 +59,7 @@ def parse(argv=None):
     ap.add_argument("--decoder", default="diffusion", choices=["diffusion", "renderer"])
     ap.add_argument("--decode-steps", type=int, default=None, help="debug only: truncate the 50-step loop (marks the line invalid)")
     ap.add_argument("--gemm", default=None, choices=["fp32", "f16x2"], help="arithmetic of the MMDiT block Linears of the headline number")
-    ap.add_argument("--vae", default=None, choices=["parity", "miopen", "fast"], help="VAE arithmetic (vae.AutoencoderKLGPU); default parity")
+    ap.add_argument("--vae", default=None, choices=["exact", "parity", "miopen", "fast"], help="VAE arithmetic (vae.AutoencoderKLGPU); default: the pipeline's (exact-order encoder at 256 x 256)")
     ap.add_argument("--tune-gemm", type=int, default=1, choices=[0, 1], help="fp32 Linears: hipBLASLt kernel chosen per shape family by measurement (gemm_tune.py, opt-in in the "
                     "pipeline; the bench asks for it explicitly, before the warm-up, and reports the kernels in config.fp32_linear_kernels); 0: hipBLASLt's own choice")
     ap.add_argument("--no-cpu-baseline", action="store_true")

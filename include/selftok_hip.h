@@ -248,6 +248,37 @@ size_t selftok_groupnorm_nhwc_workspace_bytes(int B, int HW, int C);
 int selftok_groupnorm_silu_nhwc_bf16(const void* x, const void* weight, const void* bias, void* out, void* workspace, int B, int HW, int C, int groups,
                                      float eps, int apply_silu, hipStream_t stream);
 
+/* ---- SD3-VAE ENCODER in the reference's exact summation orders (round 4; csrc/vae_exact.hip) ------------------------------------
+ * `vae.encode(images)[0].mode()` of the reference (SelftokPipeline.py:215; sd3/sd3_impls.py:221-377) runs in bf16 on the CPU and the
+ * token ids depend on the exact rounding of every layer.  These entries evaluate every reduction as the SAME SEQUENCE of fp32
+ * operations torch-CPU executes (oneDNN's AMX convolution, ATen's GroupNorm / SiLU / flash attention, glibc's expf) -- orders probed
+ * in the build container, restated in oracle/vae_exact.c -- so that latents and token ids from pixels equal the reference's bit for
+ * bit.  All tensors bf16 channels-last unless noted; fp32 MFMA rate (the order is prescribed, a bf16 MFMA has its own).
+ *
+ * Convolution.  x [B, H, W, ldx] (channels [0, Cin) used; ldx == Cin unless order 2), w [Cout, k, k, Cin] (the checkpoint's tensor
+ * permuted, no packing), bias [Cout], out / residual [B, Ho, Wo, Cout].  ksize 3: padding 1; stride 2 (ksize 3) = Downsample's
+ * F.pad(x, (0,1,0,1)) + stride-2 convolution.  residual: out = bf16(bf16(conv + bias) + residual).
+ * order = the chunk order of oneDNN's kernel for that layer: 0: 32-channel chunks in (kh, kw, channel-block) order; 3: channel-block
+ * major, every block's 9 taps summed privately and then added to the total (the 128- and 256-channel Downsample layers);
+ * 2: conv_in (Cin = 3): one chunk of 27 elements in (kw, kh, ic) order.  Cin % 32 == 0, Cout % 32 == 0, B*Ho*Wo % 128 == 0 (orders 0, 3). */
+int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int B, int H, int W, int ldx, int Cin, int Cout,
+                           int ksize, int stride, int order, hipStream_t stream);
+/* GroupNorm(groups, eps, affine) [+ SiLU] with ATen's statistics (Welford in 8 fp32 lanes over 16-element vectors, chunks of 16
+ * vectors, binary cascade; elements in NCHW order) and y = bf16(fma(rstd * gamma, x, fma(-rstd * gamma, mean, beta))).
+ * silu_table: 65536 bf16 entries from selftok_vx_silu_table_bf16, or NULL for no activation.  stats (may be NULL): [B, groups, 2] fp32
+ * mean, rstd.  C % 128 == 0, H*W a multiple of 1024 (4096 above 4096), power-of-two channels per group. */
+size_t selftok_vx_groupnorm_workspace_bytes(int B, int HW, int C);
+int selftok_vx_groupnorm_bf16(const void* x, const void* gamma, const void* beta, void* out, void* workspace, const void* silu_table, float* stats, int B, int HW,
+                              int C, int groups, double eps, hipStream_t stream);
+/* torch-CPU's `SiLU` on every bf16 bit pattern (it is a function of the input alone): table[bits(x)] = bits(silu(x)). */
+int selftok_vx_silu_table_bf16(void* table, hipStream_t stream);
+/* AttnBlock's scaled_dot_product_attention (sd3_impls.py:274-284), one head of C channels over T = 1024 tokens, as ATen's CPU flash
+ * kernel evaluates it: q, k, v, out [B, T, C] bf16. */
+size_t selftok_vx_attention_workspace_bytes(int B, int T, int C);
+int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void* out, void* workspace, int B, int T, int C, hipStream_t stream);
+/* glibc's expf (what `std::exp(float)` evaluates inside the flash kernel), element-wise; exposed for the parity tests. */
+int selftok_vx_expf_f32(const float* x, float* y, long n, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

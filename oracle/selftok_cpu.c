@@ -842,3 +842,77 @@ int selftok_groupnorm_silu_nhwc_bf16(const void* xv, const void* wv, const void*
     }
     return SELFTOK_OK;
 }
+
+/* ---- the exact-order VAE encoder entries (include/selftok_hip.h, round 4): the CPU twin IS oracle/vae_exact.c -------------------- */
+int vx_conv2d_nhwc(const uint16_t* xb, const uint16_t* wb, const uint16_t* bb, const uint16_t* rb, uint16_t* y, int B, int H, int W, int IC, int OC, int KH,
+                   int KW, int stride, int pad, int OH, int OW, int order);
+int vx_group_norm_nhwc(const uint16_t* x, const uint16_t* gamma, const uint16_t* beta, uint16_t* y, int B, int64_t HW, int C, int G, double eps,
+                       const uint16_t* silu, float* stats);
+int vx_attention(const uint16_t* qb, const uint16_t* kb, const uint16_t* vb, uint16_t* ob, int B, int T, int Cd);
+float vx_expf(float x);
+
+int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int B, int H, int W, int ldx, int Cin, int Cout,
+                           int ksize, int stride, int order, hipStream_t s)
+{
+    (void)s;
+    if (!x || !w || !bias || !out || B < 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (stride == 2 && ksize != 3)) return fail("vx_conv2d: bad argument");
+    if (order == 2 ? (Cin != 3 || ksize != 3 || stride != 1 || residual) : ((order != 0 && order != 3) || Cin % 32 || ldx != Cin || Cout % 32))
+        return fail("vx_conv2d: need Cin % 32 == 0, Cout % 32 == 0, order 0 / 2 / 3");
+    const int OH = stride == 2 ? H / 2 : H, OW = stride == 2 ? W / 2 : W;
+    const uint16_t* xs = (const uint16_t*)x;
+    uint16_t* tmp = NULL;
+    if (ldx != Cin) {                                   /* conv_in reads the first 3 of ldx channels */
+        tmp = (uint16_t*)malloc((size_t)B * H * W * Cin * 2);
+        for (size_t p = 0; p < (size_t)B * H * W; ++p) for (int c = 0; c < Cin; ++c) tmp[p * Cin + c] = xs[p * ldx + c];
+        xs = tmp;
+    }
+    const int rc = vx_conv2d_nhwc(xs, (const uint16_t*)w, (const uint16_t*)bias, (const uint16_t*)residual, (uint16_t*)out, B, H, W, Cin, Cout, ksize, ksize, stride,
+                                  (ksize == 3 && stride == 1) ? 1 : 0, OH, OW, order);
+    free(tmp);
+    return rc ? fail("vx_conv2d: out of memory") : SELFTOK_OK;
+}
+size_t selftok_vx_groupnorm_workspace_bytes(int B, int HW, int C)
+{
+    const int RP = HW >= 4096 ? 4096 : 1024;
+    if (B <= 0 || HW % RP || C % 128) return 0;
+    return (size_t)B * C * (HW / RP) * 8 * 8 + (size_t)2 * B * C * sizeof(float);
+}
+int selftok_vx_groupnorm_bf16(const void* x, const void* gamma, const void* beta, void* out, void* workspace, const void* silu_table, float* stats, int B, int HW,
+                              int C, int groups, double eps, hipStream_t s)
+{
+    (void)s; (void)workspace;
+    if (!x || !gamma || !beta || !out || B < 0 || groups <= 0 || C % groups) return fail("vx_groupnorm: bad argument");
+    vx_group_norm_nhwc((const uint16_t*)x, (const uint16_t*)gamma, (const uint16_t*)beta, (uint16_t*)out, B, HW, C, groups, eps, (const uint16_t*)silu_table, stats);
+    return SELFTOK_OK;
+}
+int selftok_vx_silu_table_bf16(void* table, hipStream_t s)
+{
+    (void)s;
+    if (!table) return fail("vx_silu_table: null");
+    uint16_t* t = (uint16_t*)table;
+    for (int i = 0; i < 65536; ++i) {
+        const float x = bf2f((uint16_t)i);
+        if (x != x) t[i] = (uint16_t)(i | 0x40);
+        else if (-x > 88.72284f) t[i] = f2bf(x / INFINITY);
+        else { const double xd = (double)x; t[i] = f2bf((float)(xd / (1.0 + exp(-xd)))); }
+    }
+    return SELFTOK_OK;
+}
+size_t selftok_vx_attention_workspace_bytes(int B, int T, int C)
+{
+    if (B <= 0) return 0;
+    return (size_t)B * T * T * 4 + (size_t)B * T * T * 2 + (size_t)B * T * C * 2 + (size_t)2 * B * T * 4;
+}
+int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void* out, void* workspace, int B, int T, int C, hipStream_t s)
+{
+    (void)s; (void)workspace;
+    if (!q || !k || !v || !out || B < 0 || T != 1024 || C % 128) return fail("vx_attention: one head, T == 1024, C % 128 == 0");
+    return vx_attention((const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (uint16_t*)out, B, T, C) ? fail("vx_attention") : SELFTOK_OK;
+}
+int selftok_vx_expf_f32(const float* x, float* y, long n, hipStream_t s)
+{
+    (void)s;
+    if (!x || !y || n < 0) return fail("vx_expf: bad argument");
+    for (long i = 0; i < n; ++i) y[i] = vx_expf(x[i]);
+    return SELFTOK_OK;
+}

@@ -1,0 +1,656 @@
+// The bf16 SD3-VAE ENCODER with the reference's exact summation orders (round 4).  gfx950 only.
+//
+// The reference runs `self.vae.encode(images)[0].mode()` (mimogpt/infer/SelftokPipeline.py:215; topology of the mirror
+// mimogpt/models/selftok/sd3/sd3_impls.py:221-377) in bf16 on the CPU, and its token ids depend on the exact bf16 rounding of every
+// layer.  csrc/conv.hip reproduces the PRECISION of that arithmetic (fp32 accumulation, one rounding) on the bf16 matrix cores and
+// lands within 1 bf16 ulp of it -- 15 of 8192 tokens then flip at reference near-ties.  This file reproduces the ORDER: every
+// reduction is evaluated as the same sequence of fp32 operations torch-CPU executes (oracle/vae_exact.c documents how each order was
+// established and is the bit-for-bit CPU twin of every kernel here), so the latents -- and with them the token ids from pixels --
+// are the reference's bit for bit.
+//
+//   xconv_kernel   convolution / GEMM in oneDNN's AMX order.  One TDPBF16PS takes 32 input channels: even elements are summed
+//                  sequentially in one fp32 accumulator, odd elements in another, chunk = even + odd, C += chunk.  Here a chunk is 16
+//                  v_mfma_f32_32x32x1_2b_f32: a ONE-k-step MFMA is an fma per output (the products of two bf16 values are exact, so
+//                  fma = round(acc + product), what the AMX unit does), block 0 of the instruction carries the even chain and block 1
+//                  the odd chain -- lanes 0..31 feed the low halves of the 16 packed bf16 pairs, lanes 32..63 the high halves --
+//                  and the first instruction of a chunk starts from the inline constant 0.  The fold C += (even + odd) is 16 + 16
+//                  v_add_f32 per 32 x 32 tile.  fp32 MFMA rate (157 TF/s): 16x slower than conv.hip's bf16 MFMAs, which is the
+//                  price of a prescribed order (a bf16 MFMA sums its 16 k-steps in an order of its own).
+//                  Operands come straight from global memory: a lane reads the 64 contiguous bytes of its pixel / its output
+//                  channel for the chunk (no LDS, no barrier); the next chunk's 12 x 16 bytes are in flight while this chunk's 32
+//                  MFMAs issue.  Epilogues: bf16(C + bias) [+ residual with its own rounding]; fp32 C * scale (attention scores);
+//                  a per-row rescale of C at a chunk boundary and bf16(C * rowscale) (the P V product of the flash kernel).
+//   xconv_in       conv_in: 3 input channels = ONE chunk of 27 elements in (kw, kh, ic) order; fp32 VALU FMAs, weights in LDS.
+//   xgn_*          ATen's GroupNorm: Welford over 16-element vectors in 8 fp32 lanes, chunks of 16 vectors, binary cascade,
+//                  scalar lane combination, rstd through fp64, y = bf16(fma(scale, x, bias)), then SiLU by table.
+//   xsilu_table    torch's bf16 SiLU is a function of the input alone: correctly rounded x / (1 + exp(-x)), except that
+//                  fp32 exp(-x) overflows for x < -88.72 and the quotient becomes -0.
+//   xattn_softmax  the row pass of ATen's cpu_flash_attention between the two GEMMs (kv blocks of 512, fexp_u20, 16-lane sums,
+//                  glibc expf for the rescale).
+#include "common.h"
+#include "selftok_hip.h"
+
+namespace selftok {
+
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short us8v __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float xbf2f(unsigned short u) { return __uint_as_float(((uint32_t)u) << 16); }
+__device__ __forceinline__ unsigned short xf2bf(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)0x7fc0;
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// convolution / GEMM in AMX chunk order
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct XConvArgs {
+    const unsigned short* x;      // [B][H][W][IC] bf16                      (+ z * x_bs)
+    const unsigned short* w;      // [OC][KH*KW][IC] bf16                    (+ z * w_bs)
+    const unsigned short* bias;   // [OC] bf16 or null
+    const unsigned short* res;    // [P][OC] bf16 or null                    (+ z * y_bs)
+    void* y;                      // [P][OC] bf16 (mode 0, 2) / fp32 (mode 1) (+ z * y_bs)
+    const float* rescale;         // [P] or null: C *= rescale[p] before chunk `split`   (+ z * v_bs)
+    const float* rowscale;        // [P]: mode 2, y = bf16(C * rowscale[p])              (+ z * v_bs)
+    float out_scale;              // mode 1: y = C * out_scale
+    int H, W, IC, OC, KH, KW, stride, pad, OH, OW;
+    int split, mode;
+    long x_bs, w_bs, y_bs, v_bs;
+};
+
+template <int NT, int WM, int WN, bool PARTIAL>
+__global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
+{
+    struct Ops { u32x4 a[4]; u32x4 b[NT][4]; };
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int i = lane & 31, h = lane >> 5;
+    const int z = blockIdx.z;
+    const int H = a.H, W = a.W, IC = a.IC, OC = a.OC, KH = a.KH, KW = a.KW;
+    const int KT = KH * KW, nicb = IC >> 5;
+    const long p0 = (long)blockIdx.x * (32 * WM) + wm * 32;
+    const int n0 = blockIdx.y * (32 * NT * WN) + wn * (32 * NT);
+    const unsigned short* x = a.x + (size_t)z * a.x_bs;
+    const unsigned short* w = a.w + (size_t)z * a.w_bs;
+
+    const long pa = p0 + i;
+    const int ohw = a.OH * a.OW;
+    const int b = (int)(pa / ohw);
+    const int rem = (int)(pa - (long)b * ohw);
+    const int oy = rem / a.OW, ox = rem - oy * a.OW;
+    const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+    const unsigned short* xb = x + (size_t)b * H * W * IC;
+    const uint32_t sel = h ? 0x03020c0cu : 0x01000c0cu;       // v_perm: high half kept / low half moved up = the bf16 as fp32
+    const unsigned short* wrow[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wrow[t] = w + (size_t)(n0 + t * 32 + i) * KT * IC;
+
+    float C[NT][16], S[PARTIAL ? NT : 1][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { C[t][r] = 0.f; if (PARTIAL) S[t][r] = 0.f; }
+
+    int kh = 0, kw = 0, icb = 0;
+    auto advance = [&]() {
+        if (!PARTIAL) { if (++icb == nicb) { icb = 0; if (++kw == KW) { kw = 0; ++kh; } } }
+        else { if (++kw == KW) { kw = 0; if (++kh == KH) { kh = 0; ++icb; } } }
+    };
+    auto load = [&](Ops& o) {
+        const int iy = iy0 + kh, ix = ix0 + kw;
+        const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const u32x4* ap = reinterpret_cast<const u32x4*>(xb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * IC + icb * 32);
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const u32x4 v = ap[q]; o.a[q] = ok ? v : zero; }
+        const size_t woff = (size_t)(kh * KW + kw) * IC + icb * 32;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const u32x4* bp = reinterpret_cast<const u32x4*>(wrow[t] + woff);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o.b[t][q] = bp[q];
+        }
+        advance();
+    };
+    auto compute = [&](const Ops& o) {
+        f32x32 acc[NT];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const uint32_t wa = o.a[kk >> 2][kk & 3];
+            const float fa = __uint_as_float(__builtin_amdgcn_perm(wa, wa, sel));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint32_t wb = o.b[t][kk >> 2][kk & 3];
+                const float fb = __uint_as_float(__builtin_amdgcn_perm(wb, wb, sel));
+                if (kk == 0) { const f32x32 zero = {0}; acc[t] = __builtin_amdgcn_mfma_f32_32x32x1f32(fa, fb, zero, 0, 0, 0); }
+                else acc[t] = __builtin_amdgcn_mfma_f32_32x32x1f32(fa, fb, acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float c = acc[t][r] + acc[t][16 + r];      // chunk = even chain + odd chain
+                if (PARTIAL) S[t][r] = S[t][r] + c; else C[t][r] = C[t][r] + c;
+            }
+    };
+    auto after = [&](int c) {            // order 3: an ic-block's private sum joins the total when its KH * KW taps are done
+        if (PARTIAL && (c + 1) % KT == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { C[t][r] = C[t][r] + S[t][r]; S[t][r] = 0.f; }
+        }
+    };
+    auto before = [&](int c) {           // the flash kernel's `dst *= exp(old max - new max)` between its two kv blocks
+        if (a.rescale != nullptr && c == a.split) {
+            const float* rs = a.rescale + (size_t)z * a.v_bs + p0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = rs[(r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) C[t][r] = C[t][r] * f;
+            }
+        }
+    };
+
+    const int nchunks = KT * nicb;
+    Ops o0, o1;
+    load(o0);
+    for (int c = 0; c < nchunks; c += 2) {
+        if (c + 1 < nchunks) load(o1);
+        before(c);
+        compute(o0);
+        after(c);
+        if (c + 2 < nchunks) load(o0);
+        if (c + 1 < nchunks) { before(c + 1); compute(o1); after(c + 1); }
+    }
+
+    // epilogue: lane (col = i, rows (r & 3) + 8 (r >> 2) + 4 h)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int oc = n0 + t * 32 + i;
+        const float bias = (a.mode == 0 && a.bias != nullptr) ? xbf2f(a.bias[oc]) : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long p = p0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const size_t off = (size_t)z * a.y_bs + (size_t)p * OC + oc;
+            if (a.mode == 1) {
+                reinterpret_cast<float*>(a.y)[off] = C[t][r] * a.out_scale;
+            } else if (a.mode == 2) {
+                reinterpret_cast<unsigned short*>(a.y)[off] = xf2bf(C[t][r] * a.rowscale[(size_t)z * a.v_bs + p]);
+            } else {
+                unsigned short hb = xf2bf(C[t][r] + bias);
+                if (a.res != nullptr) hb = xf2bf(xbf2f(a.res[off]) + xbf2f(hb));
+                reinterpret_cast<unsigned short*>(a.y)[off] = hb;
+            }
+        }
+    }
+}
+
+// conv_in: x [B][H][W][ldx] bf16 (channels 0..2 used), w [OC][3][3][3] bf16 ([oc][kh][kw][ic]), y [B][H][W][OC] bf16; OC == 128.
+// One thread per output pixel; the 27 products in (kw, kh, ic) order: even positions in one chain, odd in the other.
+__global__ __launch_bounds__(256) void xconv_in_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                                       const unsigned short* __restrict__ bias, unsigned short* __restrict__ y, int B, int H, int W, int ldx, int OC)
+{
+    extern __shared__ float wl[];            // [27][OC] in chain order, then bias [OC]
+    for (int e = threadIdx.x; e < 27 * OC; e += blockDim.x) {
+        const int pos = e / OC, oc = e - pos * OC;
+        const int kw = pos / 9, kh = (pos / 3) % 3, ic = pos % 3;
+        wl[e] = xbf2f(w[((size_t)oc * 9 + kh * 3 + kw) * 3 + ic]);
+    }
+    for (int e = threadIdx.x; e < OC; e += blockDim.x) wl[27 * OC + e] = xbf2f(bias[e]);
+    __syncthreads();
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long)B * H * W) return;
+    const int b = (int)(p / ((long)H * W));
+    const int rem = (int)(p - (long)b * H * W);
+    const int oy = rem / W, ox = rem - oy * W;
+    float xv[27];
+#pragma unroll
+    for (int pos = 0; pos < 27; ++pos) {
+        const int kw = pos / 9, kh = (pos / 3) % 3, ic = pos % 3;
+        const int iy = oy - 1 + kh, ix = ox - 1 + kw;
+        const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        xv[pos] = ok ? xbf2f(x[((size_t)(b * H + iy) * W + ix) * ldx + ic]) : 0.f;
+    }
+    unsigned short* yp = y + (size_t)p * OC;
+    for (int o0 = 0; o0 < OC; o0 += 8) {
+        us8v out;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int oc = o0 + e;
+            float te = 0.f, to = 0.f;
+#pragma unroll
+            for (int pos = 0; pos < 27; ++pos) {
+                const float wv = wl[pos * OC + oc];
+                if (pos & 1) to = fmaf(xv[pos], wv, to); else te = fmaf(xv[pos], wv, te);      // exact product: fma = add
+            }
+            float c = 0.f + (te + to);
+            out[e] = xf2bf(c + wl[27 * OC + oc]);
+        }
+        *reinterpret_cast<us8v*>(yp + o0) = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// GroupNorm: ATen RowwiseMomentsImpl<BFloat16> (AVX2 build), restated
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct Mom { float m1, m2; };
+
+// AddMomentsVec (one lane): (m0_add, add) joins (m0, acc)
+__device__ __forceinline__ void add_moments_vec(int m0_add, Mom add, int& m0, Mom& acc)
+{
+    const int n = m0 + m0_add;
+    const float c = n == 0 ? 0.f : (float)m0_add / (float)n;
+    const float delta = add.m1 - acc.m1;
+    const float m2_tmp = acc.m2 + add.m2;
+    const float c_delta = c * delta;
+    const float m0_delta = delta * (float)m0;
+    acc.m1 = acc.m1 + c_delta;
+    acc.m2 = fmaf(m0_delta, c_delta, m2_tmp);
+    m0 = n;
+}
+
+// Pass 1.  Workgroup = 128 threads = (lane l = tid / 16 of the 8 fp32 lanes, cq = tid % 16 -> channels cblk*128 + cq*8 .. +7) of one
+// image and one range of RP consecutive pixels.  A "chunk" is 256 consecutive pixels of a channel = 16 vectors of 16 bf16; lane l of
+// a vector's first half is pixel 16 j + l, of its second half pixel 16 j + 8 + l.  Every thread runs ATen's chunk loop + binary cascade
+// over the RP / 256 chunks of its range for its 8 channels; the range's node (level log2(RP / 256)) goes to the workspace.
+// node layout: [B][C][R][8 lanes] of Mom.
+template <int NCH>       // chunks per range: 16 (RP = 4096) or 4 (RP = 1024)
+__global__ __launch_bounds__(128) void xgn_partial_kernel(const unsigned short* __restrict__ x, Mom* __restrict__ nodes, int HW, int C, int R)
+{
+    constexpr int LV = NCH == 16 ? 5 : 3;          // levels 0 .. log2(NCH)
+    const int l = threadIdx.x >> 4, cq = threadIdx.x & 15;
+    const int r = blockIdx.x, cblk = blockIdx.y, b = blockIdx.z;
+    const int c0 = cblk * 128 + cq * 8;
+    const unsigned short* xp = x + ((size_t)b * HW + (size_t)r * NCH * 256) * C + c0;
+    Mom stk[LV][8];
+    int m0s[LV];
+#pragma unroll
+    for (int v = 0; v < LV; ++v) { m0s[v] = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) stk[v][e] = Mom{0.f, 0.f}; }
+#pragma unroll 1
+    for (int u = 0; u < NCH; ++u) {
+        Mom a[8], bb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = Mom{0.f, 0.f}; bb[e] = Mom{0.f, 0.f}; }
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const float cj = 1.0f / (float)(j + 1);
+            const us8v va = *reinterpret_cast<const us8v*>(xp + (size_t)(u * 256 + j * 16 + l) * C);
+            const us8v vb = *reinterpret_cast<const us8v*>(xp + (size_t)(u * 256 + j * 16 + 8 + l) * C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x0 = xbf2f(va[e]), x1 = xbf2f(vb[e]);
+                const float d0 = x0 - a[e].m1, d1 = x1 - bb[e].m1;
+                a[e].m1 = fmaf(d0, cj, a[e].m1); bb[e].m1 = fmaf(d1, cj, bb[e].m1);
+                const float e0 = x0 - a[e].m1, e1 = x1 - bb[e].m1;
+                a[e].m2 = fmaf(d0, e0, a[e].m2); bb[e].m2 = fmaf(d1, e1, bb[e].m2);
+            }
+        }
+        {
+            int m0 = m0s[0];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { int t0 = m0s[0]; add_moments_vec(16, a[e], t0, stk[0][e]); add_moments_vec(16, bb[e], t0, stk[0][e]); m0 = t0; }
+            m0s[0] = m0;
+        }
+        int mask = u + 1;
+#pragma unroll
+        for (int j = 1; j < LV; ++j) {
+            if ((mask & 1) != 0) break;
+            int m0 = m0s[j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { int t0 = m0s[j]; add_moments_vec(m0s[j - 1], stk[j - 1][e], t0, stk[j][e]); stk[j - 1][e] = Mom{0.f, 0.f}; m0 = t0; }
+            m0s[j] = m0; m0s[j - 1] = 0;
+            mask >>= 1;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) nodes[(((size_t)b * C + c0 + e) * R + r) * 8 + l] = stk[LV - 1][e];
+}
+
+// Pass 2.  One thread = one fp32 lane of one (image, group): continues the cascade over the group's D * R nodes (channel-major), then
+// thread 0 of the 8 combines the lanes with the scalar AddMoments (GCC's FMA contractions), rstd through fp64, and writes per-channel
+// scale = rstd * gamma, bias = fma(-scale, mean, beta).  node_count = elements per lane in one node.
+__global__ void xgn_finish_kernel(const Mom* __restrict__ nodes, const unsigned short* __restrict__ gamma, const unsigned short* __restrict__ beta,
+                                  float* __restrict__ scale, float* __restrict__ bias, float* __restrict__ stats, int BG, int C, int G, int R, int HW,
+                                  int node_count, double eps)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int grp = t >> 3, l = t & 7;
+    if (grp >= BG) return;
+    const int b = grp / G, g = grp % G, D = C / G;
+    const int Q = D * R;
+    int depth = 0;
+    while ((1 << depth) < Q) ++depth;
+    constexpr int MAXD = 9;                     // Q <= 256 nodes; every stack index below is a compile-time constant (registers, no scratch)
+    Mom stk[MAXD];
+    int m0s[MAXD];
+#pragma unroll
+    for (int v = 0; v < MAXD; ++v) { stk[v] = Mom{0.f, 0.f}; m0s[v] = 0; }
+    for (int q = 0; q < Q; ++q) {
+        const int d = q / R, r = q - d * R;
+        const Mom nd = nodes[(((size_t)b * C + g * D + d) * R + r) * 8 + l];
+        add_moments_vec(node_count, nd, m0s[0], stk[0]);
+        int mask = q + 1;
+        bool go = true;
+#pragma unroll
+        for (int j = 1; j < MAXD; ++j) {
+            go = go && j < depth && (mask & 1) == 0;
+            if (go) {
+                add_moments_vec(m0s[j - 1], stk[j - 1], m0s[j], stk[j]);
+                m0s[j - 1] = 0; stk[j - 1] = Mom{0.f, 0.f};
+                mask >>= 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 1; j < MAXD; ++j)
+        if (j < depth) add_moments_vec(m0s[j], stk[j], m0s[0], stk[0]);
+    // lane combination on lane 0 of the 8 (the values of lanes 1..7 through shuffles)
+    float m1 = 0.f, m2 = 0.f;
+    int m0 = 0;
+    const int m0_add = m0s[0];
+    for (int k = 0; k < 8; ++k) {
+        const float a1 = __shfl(stk[0].m1, (threadIdx.x & ~7) + k, WAVE), a2 = __shfl(stk[0].m2, (threadIdx.x & ~7) + k, WAVE);
+        const int n = m0 + m0_add;
+        const float c = n == 0 ? 0.f : (float)m0_add / (float)n;
+        const float delta = a1 - m1;
+        m1 = fmaf(c, delta, m1);
+        m2 = m2 + fmaf(delta * delta * c, (float)m0, a2);
+        m0 = n;
+    }
+    if (l != 0) return;
+    const float N = (float)((long)D * HW);
+    const float var = m2 / N;
+    const float rstd = (float)(1.0 / sqrt((double)fmaxf(var, 0.f) + eps));
+    if (stats != nullptr) { stats[2 * grp] = m1; stats[2 * grp + 1] = rstd; }
+    for (int d = 0; d < D; ++d) {
+        const int c = g * D + d;
+        const float sc = rstd * xbf2f(gamma[c]);
+        scale[(size_t)b * C + c] = sc;
+        bias[(size_t)b * C + c] = fmaf(-sc, m1, xbf2f(beta[c]));
+    }
+}
+
+// Pass 3.  y = table[bf16(fma(scale, x, bias))] (table == null: no activation), 8 channels per thread.
+__global__ __launch_bounds__(256) void xgn_apply_kernel(const unsigned short* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ bias,
+                                                        const unsigned short* __restrict__ table, unsigned short* __restrict__ y, long n8, int C, long HWC)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n8) return;
+    const long e0 = idx * 8;
+    const int b = (int)(e0 / HWC), c0 = (int)(e0 % C);
+    const us8v v = *reinterpret_cast<const us8v*>(x + e0);
+    const float4 s0 = *reinterpret_cast<const float4*>(scale + (size_t)b * C + c0), s1 = *reinterpret_cast<const float4*>(scale + (size_t)b * C + c0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + (size_t)b * C + c0), b1 = *reinterpret_cast<const float4*>(bias + (size_t)b * C + c0 + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, bi[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    us8v out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const unsigned short hb = xf2bf(fmaf(sc[e], xbf2f(v[e]), bi[e]));
+        out[e] = table != nullptr ? table[hb] : hb;
+    }
+    *reinterpret_cast<us8v*>(y + e0) = out;
+}
+
+// torch-CPU's SiLU on every bf16 bit pattern: x / (1 + exp(-x)) evaluated in fp32 with an exp that is exact to the last bf16 bit
+// everywhere -- except that exp(-x) overflows fp32 for -x > 88.7228 and the quotient becomes a signed zero.
+__global__ void xsilu_table_kernel(unsigned short* __restrict__ table)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 65536) return;
+    const float x = xbf2f((unsigned short)i);
+    unsigned short out;
+    if (x != x) out = (unsigned short)(i | 0x40);
+    else if (-x > 88.72284f) out = xf2bf(x / __builtin_inff());        // -0 for finite x, NaN for -inf (inf / inf)
+    else {
+        // fp64 quotient -> fp32 -> bf16: the two roundings torch's own fp32 evaluation + bf16 store amount to (checked against
+        // torch-CPU on all 65536 inputs: tests/golden/silu_bf16_table.npy)
+        const double xd = (double)x;
+        out = xf2bf((float)(xd / (1.0 + exp(-xd))));
+    }
+    table[i] = out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// attention row pass
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float xfexp_u20(float x)       // Vectorized<float>::fexp_u20 (ATen/cpu/vec/vec512/vec512_float.h)
+{
+    const float c0 = 0.00010703434948458272f, c1 = 0.30354260500649682f, c2 = -0.22433836478672356f, c3 = -0.079204240219773236f;
+    const float log2e = __uint_as_float(0x3fb8aa3bu), a = 8388608.0f, b = 8388608.0f * 127.f;
+    float src = x * log2e;
+    const float fr = src - floorf(src);
+    float res = fmaf(fr, c3, c2);
+    res = fmaf(fr, res, c1);
+    res = fmaf(fr, res, c0);
+    src = src - res;
+    const float tmp = fmaf(a, src, b);
+    int ci = (int)tmp;                     // truncation, as cvttps2dq
+    if (x < __uint_as_float(0xc2aeac50u)) ci = 0;
+    if (x > __uint_as_float(0x42b17218u)) ci = 0x7F800000;
+    return __int_as_float(ci);
+}
+
+__constant__ unsigned long long XEXP2F_T[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+    0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+    0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+// glibc's expf (sysdeps/ieee754/flt-32/e_expf.c, 32-entry table, fp64 arithmetic): what `std::exp(float)` evaluates in the flash kernel
+__device__ __forceinline__ float xexpf_glibc(float x)
+{
+    if (x != x) return x;
+    if (x > 0x1.62e42ep6f) return __builtin_inff();
+    if (x < -0x1.9fe368p6f) return 0.f;
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32, Shift = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+    const double z = InvLn2N * (double)x;
+    double kd = z + Shift;
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= Shift;
+    const double r = z - kd;
+    const unsigned long long t = XEXP2F_T[ki % 32] + (ki << 47);
+    const double s = __longlong_as_double((long long)t);
+    const double zz = fma(C0, r, C1), r2 = r * r;
+    double y = fma(C2, r, 1.0);
+    y = fma(zz, r2, y);
+    return (float)(y * s);
+}
+
+__global__ void xexpf_kernel(const float* __restrict__ x, float* __restrict__ y, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = xexpf_glibc(x[i]);
+}
+
+// s [B*T][T] fp32 scaled scores -> p [B*T][T] bf16 un-normalised probabilities (block 0 relative to its own maximum, block 1 relative
+// to the running maximum), rescale [B*T] = expf(max0 - max1), rowscale [B*T] = 1 / sum.  T = 1024: two kv blocks of 512.
+// 16 lanes per (row, block): lane = key mod 16 sums its 32 probabilities sequentially, then the 8 / 4 / 2 / 1 fold of vec_reduce_all.
+__global__ __launch_bounds__(256) void xattn_softmax_kernel(const float* __restrict__ s, unsigned short* __restrict__ p, float* __restrict__ rescale,
+                                                            float* __restrict__ rowscale, long rows, int T)
+{
+    const int sub = threadIdx.x >> 4, l = threadIdx.x & 15;          // 16 (row, block) pairs per workgroup
+    const long row = (long)blockIdx.x * 8 + (sub >> 1);
+    const int blk = sub & 1;
+    if (row >= rows) return;
+    const float* sr = s + (size_t)row * T + blk * 512;
+    float v[32];
+    float bm = -__builtin_inff();
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { v[k] = sr[16 * k + l]; bm = fmaxf(bm, v[k]); }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o, WAVE));
+    const float m0 = __shfl(bm, (threadIdx.x & 63 & ~31), WAVE);           // block 0's maximum of this row (lanes 0..15 of the 32)
+    const float m_new = blk ? fmaxf(m0, bm) : bm;
+    float acc = 0.f;
+    unsigned short* pr = p + (size_t)row * T + blk * 512;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { const float e = xfexp_u20(v[k] - m_new); acc += e; pr[16 * k + l] = xf2bf(e); }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc = acc + __shfl_xor(acc, o, WAVE);
+    const float sum0 = __shfl(acc, (threadIdx.x & 63 & ~31), WAVE);
+    if (blk == 1 && l == 0) {
+        // block 0: exp_tmp = expf(-inf - m0) = 0, sum = fma(0, 0, sum0) = sum0; block 1:
+        const float exp_tmp = xexpf_glibc(m0 - m_new);
+        const float sum = fmaf(exp_tmp, sum0, acc);
+        rescale[row] = exp_tmp;
+        rowscale[row] = 1.0f / sum;
+    }
+}
+
+// v [B][T][C] -> vt [B][C][T] (bf16): the P V product reads V as [output channel][key]
+__global__ void xtranspose_kernel(const unsigned short* __restrict__ v, unsigned short* __restrict__ vt, int T, int C)
+{
+    __shared__ unsigned short tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = v[((size_t)b * T + t0 + r) * C + c0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) vt[((size_t)b * C + c0 + r) * T + t0 + tx] = tile[tx][r];
+}
+
+static int launch_xconv(const XConvArgs& a, long P, int nz, bool partial, hipStream_t stream)
+{
+    if (a.OC % 128 == 0) {
+        dim3 grid((unsigned)(P / 64), a.OC / 128, nz);
+        if (partial) hipLaunchKernelGGL((xconv_kernel<2, 2, 2, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((xconv_kernel<2, 2, 2, false>), grid, dim3(256), 0, stream, a);
+    } else {
+        dim3 grid((unsigned)(P / 128), a.OC / 32, nz);
+        if (partial) hipLaunchKernelGGL((xconv_kernel<1, 4, 1, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((xconv_kernel<1, 4, 1, false>), grid, dim3(256), 0, stream, a);
+    }
+    return check_launch("xconv_kernel");
+}
+
+}  // namespace selftok
+
+using namespace selftok;
+
+extern "C" {
+
+int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int B, int H, int W, int ldx, int Cin, int Cout,
+                           int ksize, int stride, int order, hipStream_t stream)
+{
+    if (!x || !w || !bias || !out || B < 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (stride == 2 && ksize != 3)) {
+        set_last_error("vx_conv2d: bad argument"); return SELFTOK_EINVAL;
+    }
+    if (B == 0) return SELFTOK_OK;
+    const int OH = stride == 2 ? H / 2 : H, OW = stride == 2 ? W / 2 : W;
+    const long P = (long)B * OH * OW;
+    if (order == 2) {
+        if (Cin != 3 || ksize != 3 || stride != 1 || Cout % 8 || residual) { set_last_error("vx_conv2d: order 2 is conv_in (3 channels, 3x3)"); return SELFTOK_EINVAL; }
+        hipLaunchKernelGGL(xconv_in_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), (size_t)(28 * Cout) * sizeof(float), stream, (const unsigned short*)x,
+                           (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)out, B, H, W, ldx, Cout);
+        return check_launch("xconv_in_kernel");
+    }
+    if ((order != 0 && order != 3) || Cin % 32 || ldx != Cin || Cout % 32 || P % 128 || (stride == 2 && ((H | W) & 1))) {
+        set_last_error("vx_conv2d: need Cin % 32 == 0, Cout % 32 == 0, B*Ho*Wo % 128 == 0, order 0 / 2 / 3"); return SELFTOK_EINVAL;
+    }
+    XConvArgs a{};
+    a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.bias = (const unsigned short*)bias; a.res = (const unsigned short*)residual; a.y = out;
+    a.H = H; a.W = W; a.IC = Cin; a.OC = Cout; a.KH = a.KW = ksize; a.stride = stride; a.pad = (ksize == 3 && stride == 1) ? 1 : 0; a.OH = OH; a.OW = OW;
+    a.split = -1; a.mode = 0;
+    return launch_xconv(a, P, 1, order == 3, stream);
+}
+
+size_t selftok_vx_groupnorm_workspace_bytes(int B, int HW, int C)
+{
+    const int RP = HW >= 4096 ? 4096 : 1024;
+    if (B <= 0 || HW % RP || C % 128) return 0;
+    return (size_t)B * C * (HW / RP) * 8 * sizeof(Mom) + (size_t)2 * B * C * sizeof(float);
+}
+
+int selftok_vx_groupnorm_bf16(const void* x, const void* gamma, const void* beta, void* out, void* workspace, const void* silu_table, float* stats, int B, int HW,
+                              int C, int groups, double eps, hipStream_t stream)
+{
+    const int RP = HW >= 4096 ? 4096 : 1024;
+    if (!x || !gamma || !beta || !out || !workspace || B < 0 || groups <= 0 || C % groups || C % 128 || HW % RP || (C / groups) & ((C / groups) - 1) || ((HW / RP) & (HW / RP - 1))) {
+        set_last_error("vx_groupnorm: need C % 128 == 0, H*W a multiple of 1024 (of 4096 above 4096), power-of-two channels per group and ranges"); return SELFTOK_EINVAL;
+    }
+    if (B == 0) return SELFTOK_OK;
+    const int R = HW / RP;
+    Mom* nodes = (Mom*)workspace;
+    float* scale = (float*)((char*)workspace + (size_t)B * C * R * 8 * sizeof(Mom));
+    float* bias = scale + (size_t)B * C;
+    dim3 grid(R, C / 128, B);
+    if (RP == 4096) hipLaunchKernelGGL((xgn_partial_kernel<16>), grid, dim3(128), 0, stream, (const unsigned short*)x, nodes, HW, C, R);
+    else hipLaunchKernelGGL((xgn_partial_kernel<4>), grid, dim3(128), 0, stream, (const unsigned short*)x, nodes, HW, C, R);
+    int rc = check_launch("xgn_partial_kernel");
+    if (rc) return rc;
+    const int BG = B * groups;
+    hipLaunchKernelGGL(xgn_finish_kernel, dim3((BG * 8 + 63) / 64), dim3(64), 0, stream, nodes, (const unsigned short*)gamma, (const unsigned short*)beta, scale, bias, stats,
+                       BG, C, groups, R, HW, RP / 8, eps);
+    rc = check_launch("xgn_finish_kernel");
+    if (rc) return rc;
+    const long n8 = (long)B * HW * C / 8;
+    hipLaunchKernelGGL(xgn_apply_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, (const unsigned short*)x, scale, bias, (const unsigned short*)silu_table,
+                       (unsigned short*)out, n8, C, (long)HW * C);
+    return check_launch("xgn_apply_kernel");
+}
+
+int selftok_vx_silu_table_bf16(void* table, hipStream_t stream)
+{
+    if (!table) { set_last_error("vx_silu_table: null"); return SELFTOK_EINVAL; }
+    hipLaunchKernelGGL(xsilu_table_kernel, dim3(256), dim3(256), 0, stream, (unsigned short*)table);
+    return check_launch("xsilu_table_kernel");
+}
+
+size_t selftok_vx_attention_workspace_bytes(int B, int T, int C)
+{
+    if (B <= 0) return 0;
+    return (size_t)B * T * T * 4 + (size_t)B * T * T * 2 + (size_t)B * T * C * 2 + (size_t)2 * B * T * 4;
+}
+
+int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void* out, void* workspace, int B, int T, int C, hipStream_t stream)
+{
+    if (!q || !k || !v || !out || !workspace || B < 0 || T != 1024 || C % 128 || C > 4096) {
+        set_last_error("vx_attention: one head, T == 1024 (two kv blocks of 512, the SD3 VAE at 256 x 256), C % 128 == 0"); return SELFTOK_EINVAL;
+    }
+    if (B == 0) return SELFTOK_OK;
+    float* s = (float*)workspace;
+    unsigned short* p = (unsigned short*)((char*)workspace + (size_t)B * T * T * 4);
+    unsigned short* vt = p + (size_t)B * T * T;
+    float* rescale = (float*)(vt + (size_t)B * T * C);
+    float* rowscale = rescale + (size_t)B * T;
+    XConvArgs a{};
+    // scores: rows = queries (per image), "output channels" = keys; fp32 C * 1/sqrt(C)
+    a.x = (const unsigned short*)q; a.w = (const unsigned short*)k; a.y = s; a.H = 1; a.W = T; a.IC = C; a.OC = T; a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.OH = 1; a.OW = T;
+    a.split = -1; a.mode = 1; a.out_scale = (float)(1.0 / sqrt((double)C));
+    a.x_bs = (long)T * C; a.w_bs = (long)T * C; a.y_bs = (long)T * T; a.v_bs = T;
+    int rc = launch_xconv(a, T, B, false, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(xattn_softmax_kernel, dim3((unsigned)((long)B * T / 8)), dim3(256), 0, stream, s, p, rescale, rowscale, (long)B * T, T);
+    rc = check_launch("xattn_softmax_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(xtranspose_kernel, dim3(T / 32, C / 32, B), dim3(256), 0, stream, (const unsigned short*)v, vt, T, C);
+    rc = check_launch("xtranspose_kernel");
+    if (rc) return rc;
+    // P V: rows = queries, reduction over the 1024 keys in 32 chunks; C *= rescale before chunk 16; bf16(C * 1/sum)
+    XConvArgs g{};
+    g.x = p; g.w = vt; g.y = out; g.H = 1; g.W = T; g.IC = T; g.OC = C; g.KH = g.KW = 1; g.stride = 1; g.pad = 0; g.OH = 1; g.OW = T;
+    g.rescale = rescale; g.rowscale = rowscale; g.split = 16; g.mode = 2;
+    g.x_bs = (long)T * T; g.w_bs = (long)C * T; g.y_bs = (long)T * C; g.v_bs = T;
+    return launch_xconv(g, T, B, false, stream);
+}
+
+int selftok_vx_expf_f32(const float* x, float* y, long n, hipStream_t stream)
+{
+    if (!x || !y || n < 0) { set_last_error("vx_expf: bad argument"); return SELFTOK_EINVAL; }
+    if (n == 0) return SELFTOK_OK;
+    hipLaunchKernelGGL(xexpf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, y, n);
+    return check_launch("xexpf_kernel");
+}
+
+}  // extern "C"

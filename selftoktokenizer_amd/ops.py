@@ -601,3 +601,69 @@ def vq_encode_split_launch(z, packed_codebook, ids_dtype=torch.int64, coarse=Non
                                                   _stream()), "selftok_vq_finalize_packed")
 
     return ids.reshape(z.shape[:-1]), launch_main, launch_finalize
+
+
+# ---- the exact-order SD3-VAE encoder kernels (csrc/vae_exact.hip) -------------------------------------------------------------------
+def vx_conv2d(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, stride: int = 1, residual: Optional[torch.Tensor] = None, order: int = 0,
+              cin: Optional[int] = None) -> torch.Tensor:
+    """x [B,H,W,ldx] bf16 channels-last, w [Cout,k,k,Cin] bf16 (the checkpoint's tensor permuted), bias [Cout] bf16 -> [B,Ho,Wo,Cout] bf16 with the
+    summation order of the reference's CPU convolution (oneDNN AMX chunks; include/selftok_hip.h).  `order`: 0 / 3 / 2 (conv_in, cin = 3)."""
+    _need_cuda(x, w, bias, residual)
+    assert x.dtype == w.dtype == bias.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous() and x.dim() == 4 and w.dim() == 4
+    B, H, W, ldx = x.shape
+    Cout, k, k2, Cin = w.shape
+    assert k == k2 and (cin is None or cin == Cin)
+    Ho, Wo = (H // 2, W // 2) if stride == 2 else (H, W)
+    out = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device=x.device)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == torch.bfloat16
+    _lib.check(_lib.load().selftok_vx_conv2d_bf16(_p(x), _p(w), _p(bias), _p(residual), _p(out), B, H, W, ldx, Cin, Cout, k, stride, order, _stream()),
+               "selftok_vx_conv2d_bf16")
+    return out
+
+
+def vx_silu_table(device) -> torch.Tensor:
+    """torch-CPU's bf16 SiLU as a 65536-entry table (int16 view of bf16 bits), built on the device"""
+    t = torch.empty(65536, dtype=torch.int16, device=device)
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.load().selftok_vx_silu_table_bf16(_p(t), _stream()), "selftok_vx_silu_table_bf16")
+    return t
+
+
+def vx_groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, silu_table: Optional[torch.Tensor] = None, groups: int = 32, eps: float = 1e-6,
+                 want_stats: bool = False):
+    """GroupNorm [+ SiLU via `silu_table`] on [B, ..., C] bf16 channels-last with ATen's CPU statistics order (include/selftok_hip.h)"""
+    _need_cuda(x, gamma, beta, silu_table)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    lib = _lib.load()
+    nbytes = lib.selftok_vx_groupnorm_workspace_bytes(B, HW, C)
+    if nbytes == 0:
+        raise _lib.SelftokHipError(f"vx_groupnorm: unsupported shape B={B} HW={HW} C={C}")
+    out = torch.empty_like(x)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    stats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    _lib.check(lib.selftok_vx_groupnorm_bf16(_p(x), _p(gamma), _p(beta), _p(out), _p(ws), _p(silu_table), _p(stats), B, HW, C, groups, float(eps), _stream()),
+               "selftok_vx_groupnorm_bf16")
+    return (out, stats) if want_stats else out
+
+
+def vx_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """q, k, v [B,T,C] bf16 -> [B,T,C] bf16: one-head attention as ATen's CPU flash kernel evaluates it (T = 1024)"""
+    _need_cuda(q, k, v)
+    assert q.dtype == k.dtype == v.dtype == torch.bfloat16 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and q.shape == k.shape == v.shape
+    B, T, C = q.shape
+    lib = _lib.load()
+    out = torch.empty_like(q)
+    ws = torch.empty(lib.selftok_vx_attention_workspace_bytes(B, T, C), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.selftok_vx_attention_bf16(_p(q), _p(k), _p(v), _p(out), _p(ws), B, T, C, _stream()), "selftok_vx_attention_bf16")
+    return out
+
+
+def vx_expf(x: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().selftok_vx_expf_f32(_p(x), _p(y), x.numel(), _stream()), "selftok_vx_expf_f32")
+    return y

@@ -164,7 +164,9 @@ class SelftokPipeline():
         `state_dict` / `vae_state_dict` (extensions) bypass the files, e.g. with weights.synthetic_state_dict().
         `gemm` (extension): arithmetic of the MMDiT block Linears, 'fp32' (hipBLASLt fp32) or 'f16x2' (fp32-equivalent
         split GEMM on the f16 matrix cores, csrc/gemm_split.hip); default from $SELFTOK_GEMM, else DEFAULT_GEMM.
-        `vae_mode` (extension): 'parity' (default: every convolution / GroupNorm through csrc/conv.hip -- fp32 accumulation with the
+        `vae_mode` (extension): 'exact' (default at datasize 256: the encoder reproduces the summation ORDER of every reduction of the
+        reference's torch-CPU run, csrc/vae_exact.hip -- latents and token ids from pixels equal the reference's bit for bit; decoder as
+        'parity'), 'parity' (default otherwise: every convolution / GroupNorm through csrc/conv.hip -- fp32 accumulation with the
         bias inside, one rounding, the reference's CPU arithmetic; no MIOpen, bit-stable, batch independent), 'miopen' (the same
         arithmetic coaxed out of MIOpen's GEMM algorithm, 3x slower) or 'fast' (MIOpen's searched solvers with a separate bias add:
         looser parity, not bit-stable; see vae.AutoencoderKLGPU); default from $SELFTOK_VAE.
@@ -214,7 +216,7 @@ class SelftokPipeline():
 
         vsd = vae_state_dict if vae_state_dict is not None else W.load_vae_checkpoint(sd3_path)
         W.check_vae_state_dict(vsd)
-        self.vae = AutoencoderKLGPU(vsd, self.device, dtype, mode=vae_mode or os.environ.get("SELFTOK_VAE") or "parity")
+        self.vae = AutoencoderKLGPU(vsd, self.device, dtype, mode=vae_mode or os.environ.get("SELFTOK_VAE") or ("exact" if int(self.datasize) == 256 else "parity"))
 
         self.verbose = verbose
         self._say("Loading all...")

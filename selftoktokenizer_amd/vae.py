@@ -11,6 +11,13 @@ nearest 2x and Downsample's padding fused), GroupNorm+SiLU by our fp64-statistic
 that round where the CPU flash kernel rounds (`_attn_tokens`).  No MIOpen, bit-stable by construction, 103 ms per 64 images (encode +
 decode) against 331 ms for the MIOpen route below and 185 ms for MIOpen's fastest (inaccurate) solvers.
 
+`mode="exact"` (round 4, the pipeline's default at 256 x 256): the ENCODER additionally reproduces the ORDER of every reduction of the
+reference's torch-CPU run -- oneDNN's AMX convolution chunks, ATen's GroupNorm cascade, SiLU table, flash-attention row pass
+(csrc/vae_exact.hip; orders probed and restated in oracle/vae_exact.c) -- so the latents, and with them the token ids from pixels, are the
+reference's BIT FOR BIT (tests/test_vae_exact_gpu.py: 16 images of the reference pipeline's own run, 8192 / 8192 ids).  It runs on the fp32
+matrix cores (a prescribed order cannot use a bf16 MFMA's internal one): ~6x the `parity` encoder's time, still < 1 % of a 50-step decode.
+The decoder stays on the `parity` kernels (pixels are within 1e-3 dB either way; the 50-step fp32 sampler upstream is not bit-reproducible).
+
 `mode="miopen"` keeps the route rounds 1-3 used to reach the same arithmetic through PyTorch-ROCm, `mode="fast"` the rounds 1-2 arithmetic.
 Two properties of PyTorch-ROCm's bf16 convolution path matter for parity with the reference's CPU run and are handled by `mode="miopen"`
 (measured: tools/probe_vae_modes.py, profiles/r3_vae_modes.txt; tests/test_parity16_gpu.py):
@@ -98,7 +105,7 @@ class _Deterministic:
 
 class AutoencoderKLGPU(ModuleSurface):
     _sd_prefix = ""
-    MODES = ("parity", "miopen", "fast")
+    MODES = ("exact", "parity", "miopen", "fast")
 
     def __init__(self, vsd: Dict[str, torch.Tensor], device, dtype=torch.bfloat16, mode: str = "parity"):
         """mode 'parity' (default since the end of round 3): channels-last, every convolution through the implicit-GEMM kernel of
@@ -129,7 +136,16 @@ class AutoencoderKLGPU(ModuleSurface):
         self._tails = {}
         # native path: packed weight images of csrc/conv.hip (built on first use of mode 'parity')
         self.pc = {}
-        if mode == "parity":
+        self.xw = {}
+        if mode == "exact":
+            # the checkpoint's tensors, permuted to [Cout, k, k, Cin] (no packing): the exact-order kernels read 64 contiguous bytes per
+            # (output channel, tap, 32-channel block).  diffusers stores the attention projections as Linear [O, I] = a 1x1 convolution.
+            for k, v in self.w.items():
+                if k.startswith("encoder.") and k.endswith(".weight") and v.dim() in (2, 4):
+                    v4 = v.reshape(v.shape[0], v.shape[1], 1, 1) if v.dim() == 2 else v
+                    self.xw[k[:-len(".weight")]] = v4.permute(0, 2, 3, 1).contiguous()
+            self.silu_table = ops.vx_silu_table(device)
+        if mode in ("parity", "exact"):
             for k, v in self.w.items():
                 if k.endswith(".weight") and v.dim() == 4:
                     name = k[:-len(".weight")]
@@ -162,6 +178,51 @@ class AutoencoderKLGPU(ModuleSurface):
         h = self._n_attn("encoder.mid_block.attentions.0", h)
         h = self._n_res("encoder.mid_block.resnets.1", h)
         h = ops.conv2d_nhwc(self._n_gn("encoder.conv_norm_out", h), self.pc["encoder.conv_out"])
+        return h.permute(0, 3, 1, 2).contiguous()
+
+    # ---- exact-order encoder (mode 'exact'): every reduction in the reference's torch-CPU order -------------------------------------
+    @staticmethod
+    def _x_order(cin: int, stride: int) -> int:
+        """the chunk order oneDNN's AMX convolution kernel uses for this layer of the encoder at 256 x 256 (probed per layer shape,
+        tools/probe_cpu_bf16/; include/selftok_hip.h): conv_in is one 27-element chunk; the 128- and 256-channel Downsample layers run
+        channel-block major with private partial sums; everything else (kh, kw, channel-block)"""
+        if cin < 32:
+            return 2
+        return 3 if (stride == 2 and cin in (128, 256)) else 0
+
+    def _x_conv(self, name, x, stride=1, residual=None):
+        w = self.xw[name]
+        return ops.vx_conv2d(x, w, self.w[name + ".bias"], stride=stride, residual=residual, order=self._x_order(w.shape[3], stride))
+
+    def _x_gn(self, name, x, act=True):
+        return ops.vx_groupnorm(x, self.w[name + ".weight"], self.w[name + ".bias"], silu_table=self.silu_table if act else None, groups=32, eps=1e-6)
+
+    def _x_res(self, p, x):
+        h = self._x_conv(p + ".conv1", self._x_gn(p + ".norm1", x))
+        sc = self._x_conv(p + ".conv_shortcut", x) if (p + ".conv_shortcut") in self.xw else x
+        return self._x_conv(p + ".conv2", self._x_gn(p + ".norm2", h), residual=sc)
+
+    def _x_encode_moments(self, img):
+        if tuple(img.shape[-2:]) != (256, 256):
+            raise NotImplementedError("vae_mode='exact' reproduces oneDNN's summation orders as probed for the encoder's layer shapes at 256 x 256; "
+                                      "use vae_mode='parity' for other resolutions")
+        x = img.to(self.device, self.dtype).permute(0, 2, 3, 1)
+        h = F.pad(x, (0, 8 - x.shape[-1])).contiguous()                                # 3 -> 8 channels: 16-byte pixels
+        h = self._x_conv("encoder.conv_in", h)
+        for lvl in range(4):
+            for j in range(2):
+                h = self._x_res(f"encoder.down_blocks.{lvl}.resnets.{j}", h)
+            if lvl != 3:
+                h = self._x_conv(f"encoder.down_blocks.{lvl}.downsamplers.0.conv", h, stride=2)
+        h = self._x_res("encoder.mid_block.resnets.0", h)
+        p = "encoder.mid_block.attentions.0"
+        B, H, W, C = h.shape
+        n = self._x_gn(p + ".group_norm", h, act=False)
+        q, k, v = (self._x_conv(p + s, n).reshape(B, H * W, C) for s in (".to_q", ".to_k", ".to_v"))
+        a = ops.vx_attention(q, k, v).reshape(B, H, W, C)
+        h = self._x_conv(p + ".to_out.0", a, residual=h)
+        h = self._x_res("encoder.mid_block.resnets.1", h)
+        h = self._x_conv("encoder.conv_out", self._x_gn("encoder.conv_norm_out", h))
         return h.permute(0, 3, 1, 2).contiguous()
 
     def _n_decode(self, z):
@@ -255,6 +316,8 @@ class AutoencoderKLGPU(ModuleSurface):
 
     @torch.no_grad()
     def encode_moments(self, img: torch.Tensor) -> torch.Tensor:
+        if self.mode == "exact":
+            return self._x_encode_moments(img)
         if self.mode == "parity":
             return self._n_encode_moments(img)
         with self._flags():
@@ -278,7 +341,7 @@ class AutoencoderKLGPU(ModuleSurface):
 
     @torch.no_grad()
     def decode(self, z, return_dict=False):
-        if self.mode == "parity":
+        if self.mode in ("parity", "exact"):
             return (self._n_decode(z),)
         with self._flags():
             return self._decode(z)

@@ -166,7 +166,7 @@ def test_vae_vs_mirror():
     lat = synth.synthetic_latents(1).to(torch.bfloat16)
     ref, ref2 = torch.from_numpy(g["mean"]), torch.from_numpy(g["rec"])
     res = {}
-    for mode in ("parity", "miopen", "fast"):
+    for mode in ("exact", "parity", "miopen", "fast"):
         vae = AutoencoderKLGPU(W.synthetic_vae_state_dict(), torch.device("cuda"), mode=mode)
         mean = vae.encode(img.cuda())[0].mode().float().cpu()
         rec = vae.decode(lat.cuda())[0].float().cpu()
@@ -177,6 +177,8 @@ def test_vae_vs_mirror():
               f"decoder PSNR vs mirror (range 2) {10 * np.log10(4.0 / max(res[mode][3] ** 2, 1e-12)):.2f} dB")
         if mode != "fast":         # bit-stable: a second call returns the same bits
             assert torch.equal(vae.encode(img.cuda())[0].mode().float().cpu(), mean)
+    assert res["exact"][0] == 0.0, "the exact-order encoder must reproduce the mirror's latent mean bit for bit"
+    assert res["exact"][2:] == res["parity"][2:]                       # same decoder kernels
     e1, r1, e2, r2 = res["parity"]
     assert e1 <= 0.0313 and r1 < 0.0078            # encoder: <= 2 ulps at |x| in [2, 4) anywhere, rms below one ulp at |x| ~ 1
     assert e2 <= 0.0625 and r2 < 0.0117            # decoder output (|rec| up to 3.3: 4 ulps anywhere, rms below 3/4 ulp at |x| in [2, 4))
