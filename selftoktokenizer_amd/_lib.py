@@ -57,7 +57,7 @@ SIGNATURES = {
     "selftok_conv2d_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
     "selftok_groupnorm_nhwc_workspace_bytes": (_sz, [_i, _i, _i]),
     "selftok_groupnorm_silu_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
-    "selftok_vx_conv2d_bf16": (_i, [_vp] * 5 + [_i] * 10 + [_vp]),
+    "selftok_vx_conv2d_bf16": (_i, [_vp] * 5 + [_i] * 9 + [_vp]),
     "selftok_vx_groupnorm_workspace_bytes": (_sz, [_i, _i, _i]),
     "selftok_vx_groupnorm_bf16": (_i, [_vp] * 7 + [_i, _i, _i, _i, C.c_double, _vp]),
     "selftok_vx_silu_table_bf16": (_i, [_vp, _vp]),
