@@ -80,7 +80,7 @@ def test_barrier_reductions_and_row_gather_over_rccl(rccl_single_rank):
 
 def test_codebook_training_step_over_rccl(rccl_single_rank):
     """f4: the data-parallel code-book update issues its id gather and both all-reduces on the RCCL group; with one rank the state
-    must equal the un-distributed step bit for bit"""
+    must equal the un-distributed step (bit for bit where the arithmetic is order independent)"""
     from selftoktokenizer_amd.vq_train import CodebookEMA, l2norm
     C, K, B = 2048, 32, 16
     embed0 = l2norm(synth.hash_normalish(0xE0, (C, 16))).cuda()
@@ -94,6 +94,8 @@ def test_codebook_training_step_over_rccl(rccl_single_rank):
     finally:
         D.force_single_rank(prev)
     assert torch.equal(ids1, ids2) and torch.equal(q1, q2)
-    for name in ("embed", "embed_avg", "cluster_size", "timestep_p_over_c"):
+    for name in ("cluster_size", "timestep_p_over_c"):                            # integer-valued sums: exact whatever the order
         assert torch.equal(getattr(with_group, name), getattr(alone, name)), name
+    for name in ("embed", "embed_avg"):                                           # fp32 scatter-adds (atomics): order noise between two runs
+        torch.testing.assert_close(getattr(with_group, name), getattr(alone, name), rtol=0, atol=2e-6)
     assert np.isfinite(float(with_group.delta_embed))
