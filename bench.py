@@ -136,20 +136,30 @@ def cpu_baseline(sd_gpu, vsd_gpu, cfg, K):
         t0 = time.perf_counter()
         OM.pipeline_encode(sd, vsd, synth.synthetic_images(8), enc_tables)
         t_enc8 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        OM.pipeline_encode(sd, vsd, synth.synthetic_images(64), enc_tables)            # BASELINE configs[1]'s batch, encode only
+        t_enc64 = time.perf_counter() - t0
         cb = sd["encoder.quantizer._codebook.embed"][0].numpy()
-        vq = {}
+        vq, vq_mt = {}, {}
         for n in (512, 32768):
             z = synth.synthetic_vq_rows(n, seed=0xBE0C).numpy()
             t0 = time.perf_counter()
             clib.vq_encode(z, cb)
             vq[f"N{n}_rows_per_s"] = round(n / (time.perf_counter() - t0), 1)
+        for n in (32768, 65536, 131072):                                               # N = B K of configs[1], [2], [3]: all host threads over row chunks
+            z = synth.synthetic_vq_rows(n, seed=0xBE0C).numpy()
+            t0 = time.perf_counter()
+            clib.vq_encode_mt(z, cb)
+            vq_mt[f"N{n}_rows_per_s"] = round(n / (time.perf_counter() - t0), 1)
     total = t_enc + 25.0 * t_2 + t_vd
     return {"value": round(1.0 / total, 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"B=1 256x256 K={K}: full encode {t_enc:.2f}s + 2 of 50 decode steps {t_2:.2f}s (x25 extrapolated) "
                       f"+ VAE decode {t_vd:.2f}s on {torch.get_num_threads()} host threads; oracle/ = lean restatement "
                       "(no redundant encoder passes / table recomputes of the reference)",
-            "encode_images_per_s": {"B1": round(1.0 / t_enc, 3), "B8": round(8.0 / t_enc8, 3)},
-            "vq_lookup_scalar_C_1_thread": vq}
+            "encode_images_per_s": {"B1": round(1.0 / t_enc, 3), "B8": round(8.0 / t_enc8, 3), "B64": round(64.0 / t_enc64, 3)},
+            "vq_lookup_scalar_C_1_thread": vq, "vq_lookup_scalar_C_all_threads": vq_mt,
+            "kinds": "every figure here is the build's own CPU restatement (oracle/: torch-CPU GEMMs / convolutions + oracle/libselftok_oracle.so for the "
+                     "VQ lookup) on this box's host cores -- 'port'; the reference itself was timed only in the build container (cpu_baseline_reference_survey)"}
 
 
 REFERENCE_SURVEY_BASELINE = {
@@ -223,17 +233,19 @@ def measured_vq_traffic(n_vq: int, coarse: bool, path=None):
 
 def vq_roofline(n_vq, C, Dm, main_ms, fin_ms, launches, traffic, traffic_note, fp32_main_ms=None, fp32_fin_ms=None, ids_bytes=8):
     """the `roofline` object of the JSON line, from measured kernel times.  Dominant kernel = vq_f16_kernel (the coarse pass: 3
-    v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 block of the score matrix): achieved = the f16-MFMA FLOPs it EXECUTES per launch
-    (3 x 2NCD) / its average launch duration, peak = the dense f16 matrix peak.  The fp32-equivalent rate of the reference's score
-    matrix is reported separately and never as `frac`."""
+    v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 block of the score matrix).  `achieved` / `frac` (= `frac_algorithmic`): the ALGORITHMIC
+    FLOPs per launch (2NCD, SURVEY 8d) / its average launch duration against the dense f16 matrix peak, as the contract defines them;
+    `achieved_executed` / `frac_executed`: the f16-MFMA FLOPs the kernel issues (3 x 2NCD) over the same time = pipe utilisation."""
     flops = 2.0 * n_vq * C * Dm                                   # the reference's fp32 score matrix (SURVEY 8d)
     executed = 3.0 * flops                                        # f16 MFMA FLOPs the coarse kernel issues (hi*hi + hi*lo + lo*hi)
     alg_bytes = 4.0 * n_vq * Dm + 4.0 * C * Dm + float(ids_bytes) * n_vq   # z + codebook (once) + ids
-    ach = executed / (main_ms * 1e-3) / 1e12
+    ach_exec = executed / (main_ms * 1e-3) / 1e12
+    ach = flops / (main_ms * 1e-3) / 1e12
     both = main_ms + fin_ms
     roof = {"kernel": "vq_f16_kernel<RT> (f16 coarse pass of the cosine argmax; vq_finalize_f16_kernel re-scores the candidates in canonical fp32: "
                       "ids and top-1 score bits equal the fp32 kernels')",
             "bound": "mfma", "achieved": round(ach, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F16_MFMA_PEAK_TFLOPS, 4),
+            "frac_algorithmic": round(ach / F16_MFMA_PEAK_TFLOPS, 4), "achieved_executed": round(ach_exec, 2), "frac_executed": round(ach_exec / F16_MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic, "traffic_note": traffic_note,
             "traffic_over_algorithmic_bytes": (round(traffic / alg_bytes, 2) if traffic else None),
             "avg_launch_ms": round(main_ms, 4), "finalize_kernel_ms": round(fin_ms, 4), "both_launches_ms": round(both, 4), "launches": launches,
@@ -244,8 +256,9 @@ def vq_roofline(n_vq, C, Dm, main_ms, fin_ms, launches, traffic, traffic_note, f
                                         "the f16 matrix cores) -- kept for comparison with the fp32 kernel below"},
             "hbm": {"achieved_GBs": round(alg_bytes / (both * 1e-3) / 1e9, 2), "frac_of_8TBs": round(alg_bytes / (both * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                     "note": "algorithmic bytes / both launches: ~7.7 kFLOP per byte at D = 16, the path is matrix bound by three orders of magnitude"},
-            "note": "frac = 3 * 2NCD / avg_launch_ms / 2500 TFLOP/s (N*C*D = %d x %d x %d); recompute from profiles/*kernel_stats.csv: the "
-                    "vq_f16_kernel row's average duration" % (n_vq, C, Dm)}
+            "note": "frac = frac_algorithmic = 2NCD (SURVEY 8d: the reference's fp32 score matrix) / avg_launch_ms / 2500 TFLOP/s, the f16 matrix peak the "
+                    "kernel runs on; frac_executed = the f16 MFMA FLOPs it issues (3 per product: hi*hi + hi*lo + lo*hi, what keeps ids bit-exact) / the same "
+                    "time and peak = pipe utilisation (N*C*D = %d x %d x %d); recompute from profiles/*kernel_stats.csv: the vq_f16_kernel row's average duration" % (n_vq, C, Dm)}
     if fp32_main_ms:
         a32 = flops / (fp32_main_ms * 1e-3) / 1e12
         roof["fp32_mfma_kernel"] = {"kernel": "vq_mfma_kernel<RT> (round-1 kernel: exact fp32 products on v_mfma_f32_32x32x2_f32; same ids, bit for bit)",
@@ -281,6 +294,7 @@ def parity_16(pipe):
     dz = (zn - zr).norm(dim=-1).reshape(B, -1).numpy()              # |delta of the unit feature| per token: a score moves by at most this
     mo = g["tokens_oracle"].astype(np.int64) != ref
     out = {"images": B, "reference": "mimogpt.infer.SelftokPipeline on CPU (fp32 tokenizer, bf16 SDVAE mirror), tests/golden/pipeline_b16.npz",
+           "vae_mode": pipe.vae.mode, "vae_latents_bit_equal_to_reference": bool(torch.equal(x0.cpu(), torch.from_numpy(g["x0_bf16"]).view(torch.bfloat16).float())),
            "ids_match_vs_reference": round(float(1.0 - mism.mean()), 6), "flips": int(mism.sum()), "tokens": int(mism.size),
            "flip_gaps_reference_top1_minus_top2": [round(float(v), 8) for v in np.sort(g["gap"][mism])],
            "flips_to_the_reference_runner_up": int((ids[mism] == g["id2"].astype(np.int64)[mism]).sum()),
@@ -309,7 +323,7 @@ def parity_16(pipe):
                        "same_decoder_delta_mean_max": [round(float(d_same.mean()), 7), round(float(d_same.max()), 7)],
                        "second_cpu_implementation_vs_reference_delta_mean_max": [round(float(d_or.mean()), 6), round(float(d_or.max()), 6)],
                        "final_latent_maxdiff_vs_reference": round(float((lat - lat_ref).abs().max()), 8),
-                       "note": "end to end = our latents through our bf16 VAE decoder (MIOpen) vs the reference's pixels; same decoder = the reference's "
+                       "note": "end to end = our latents through our bf16 VAE decoder (csrc/conv.hip + the exact-order attention block) vs the reference's pixels; same decoder = the reference's "
                                "final latents and ours through ONE call of our decoder (north star: 1e-3 dB); second cpu implementation = the CPU bf16 VAE with "
                                "diffusers' Linear attention projections on the reference's latents vs the reference's pixels: the spread between two CPU "
                                "implementations of the same bf16 network"}
@@ -423,14 +437,25 @@ def kernel_roofs(pipe, B, K, k_table):
                     "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / F16_MFMA_PEAK_TFLOPS, 4),
                     "vendor_bf16_gemm_same_flops_ms": None if ms_lib is None else round(ms_lib, 4)})
         del xx, pc, ag, wg
+    # the exact-order VAE encoder's convolution (csrc/vae_exact.hip): oneDNN's AMX chunk order on the fp32 matrix cores
+    xx = torch.randn(B, 128, 128, 256, device=dev).to(torch.bfloat16)
+    ww = (torch.randn(256, 3, 3, 256, device=dev) * 0.02).to(torch.bfloat16)
+    bb = torch.randn(256, device=dev).to(torch.bfloat16)
+    ms = event_time_ms(lambda: ops.vx_conv2d(xx, ww, bb), n=5, warm=2)
+    fl = 2.0 * B * 128 * 128 * 256 * 256 * 9
+    out.append({"kernel": "xconv_kernel<2,2,2,false> (exact-order convolution: even / odd fp32 chains per 32-channel chunk on v_mfma_f32_32x32x1_2b_f32, csrc/vae_exact.hip)",
+                "bound": "mfma(fp32)", "shape": f"[{B},128,128,256] -> 256, 3x3 (encoder down_blocks.1 resnet conv, 3 per encode)", "avg_launch_ms": round(ms, 4),
+                "achieved": round(fl / ms / 1e9, 1), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)})
+    del xx, ww, bb
     return out
 
 
-def token_match(pipe, images, tokens_gpu, sd_gpu, vsd_gpu, K, n_check=4):
+def token_match(pipe, images, tokens_gpu, sd_gpu, vsd_gpu, K, n_check=2):
     """token-id exact match of the timed batch (rank 0's shard) against the CPU oracle:
        kernel_boundary : the HIP VQ kernel vs the C oracle on the SAME features, every row of the batch (must be 1.0);
        e2e_same_latents: GPU encoder+VQ vs oracle encoder+VQ from the same fp32 latents (fp32 GEMM library differences only);
-       e2e_vs_oracle   : from pixels, i.e. incl. the bf16 VAE (MIOpen vs CPU convolutions), first n_check images."""
+       e2e_vs_oracle   : from pixels, i.e. incl. the bf16 VAE (the CPU checker's VAE = oracle/vae_exact.c = the reference's run bit for
+                         bit; 1.0 in the default `exact` VAE mode up to fp32 GEMM noise in the tokenizer), first n_check images."""
     import numpy as np
     import torch
     from oracle import clib, model as OM
@@ -448,7 +473,11 @@ def token_match(pipe, images, tokens_gpu, sd_gpu, vsd_gpu, K, n_check=4):
         tables = OM.encoder_tables(sd, K)
         z_o = OM.encoder_features(sd, x0[:n_check].cpu(), tables)
         ids_same = OM.vq_ids(sd, z_o).numpy()
-        x0_e2e = OM.process_in(OM.vae_encode_mean(vsd, images[:n_check].cpu().to(torch.bfloat16))).to(torch.float32)
+        # the VAE of the CPU checker: oracle/vae_exact.c, the bit-for-bit restatement of the reference's torch-CPU run (host independent --
+        # torch's own bf16 convolution sums in another order on a host without AMX); ~10 s per image on 8 cores
+        from oracle import vae_exact as VX
+        mom = VX.encode_moments(VX.pack_weights(vsd), VX.bf16_bits(images[:n_check].cpu().to(torch.bfloat16).permute(0, 2, 3, 1)))
+        x0_e2e = OM.process_in(VX.bits_to_torch(mom[..., :16]).permute(0, 3, 1, 2).contiguous()).to(torch.float32)
         z_e2e = OM.encoder_features(sd, x0_e2e, tables)                       # = OM.pipeline_encode, keeping the features for the gaps
         ids_e2e = OM.vq_ids(sd, z_e2e).numpy()
 
@@ -463,7 +492,8 @@ def token_match(pipe, images, tokens_gpu, sd_gpu, vsd_gpu, K, n_check=4):
             "e2e_same_latents": round(float((ids_same == ids_gpu[:n_check]).mean()), 6), "mismatch_gaps_same_latents": gaps(ids_same, z_o),
             "e2e_vs_oracle": round(float((ids_e2e == ids_gpu[:n_check]).mean()), 6), "mismatch_gaps_e2e": gaps(ids_e2e, z_e2e), "images_checked": n_check,
             "note": "gap = oracle top-1 minus top-2 cosine score of each mismatching token (a flip needs an upstream difference larger than the gap); "
-                    "e2e_vs_oracle additionally carries the bf16 VAE encoder (MIOpen vs the CPU's oneDNN convolutions; the oracle's VAE is bit-identical to the reference's)"}
+                    "e2e_vs_oracle additionally carries the bf16 VAE encoder (vae mode '%s' vs oracle/vae_exact.c, the bit-for-bit restatement of the "
+                    "reference's torch-CPU run)" % pipe.vae.mode}
 
 
 def main(argv=None):

@@ -16,9 +16,11 @@
 //                  and the first instruction of a chunk starts from the inline constant 0.  The fold C += (even + odd) is 16 + 16
 //                  v_add_f32 per 32 x 32 tile.  fp32 MFMA rate (157 TF/s): 16x slower than conv.hip's bf16 MFMAs, which is the
 //                  price of a prescribed order (a bf16 MFMA sums its 16 k-steps in an order of its own).
-//                  Operands come straight from global memory: a lane reads the 64 contiguous bytes of its pixel / its output
-//                  channel for the chunk (no LDS, no barrier); the next chunk's 12 x 16 bytes are in flight while this chunk's 32
-//                  MFMAs issue.  Epilogues: bf16(C + bias) [+ residual with its own rounding]; fp32 C * scale (attention scores);
+//                  Staging: the workgroup (4 waves: 64 pixels x 128 channels) copies the chunk's 64 bytes of each of its 192 rows to
+//                  LDS with coalesced 16-byte loads (one full row per 4 threads), double buffered, one barrier per chunk, the next
+//                  chunk in flight during this chunk's 32 MFMAs per wave; lanes read their row's four 16-byte pieces back with
+//                  ds_read_b128 (XOR-swizzled: rows are 16 banks apart).  A first version had every lane read its own row from
+//                  global memory: 8x the cache-line accesses, 0.595 of the fp32 matrix peak (profiles/r4_vae_exact_bench_first.txt).  Epilogues: bf16(C + bias) [+ residual with its own rounding]; fp32 C * scale (attention scores);
 //                  a per-row rescale of C at a chunk boundary and bf16(C * rowscale) (the P V product of the flash kernel).
 //   xconv_in       conv_in: 3 input channels = ONE chunk of 27 elements in (kw, kh, ic) order; fp32 VALU FMAs, weights in LDS.
 //   xgn_*          ATen's GroupNorm: Welford over 16-element vectors in 8 fp32 lanes, chunks of 16 vectors, binary cascade,
@@ -65,29 +67,52 @@ struct XConvArgs {
 template <int NT, int WM, int WN, bool PARTIAL>
 __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
 {
-    struct Ops { u32x4 a[4]; u32x4 b[NT][4]; };
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // workgroup tile: RA = 32 WM pixel rows x RB = 32 NT WN output channels; one chunk = 64 bytes (32 bf16 channels) of every row
+    constexpr int RA = 32 * WM, RB = 32 * NT * WN;
+    constexpr int NPA = (RA * 4 + 255) / 256, NPB = (RB * 4 + 255) / 256;          // 16-byte pieces per thread
+    __shared__ u32x4 lds[2][(RA + RB) * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int i = lane & 31, h = lane >> 5;
     const int z = blockIdx.z;
     const int H = a.H, W = a.W, IC = a.IC, OC = a.OC, KH = a.KH, KW = a.KW;
     const int KT = KH * KW, nicb = IC >> 5;
-    const long p0 = (long)blockIdx.x * (32 * WM) + wm * 32;
-    const int n0 = blockIdx.y * (32 * NT * WN) + wn * (32 * NT);
+    const long pwg = (long)blockIdx.x * RA;
+    const int nwg = blockIdx.y * RB;
+    const long p0 = pwg + wm * 32;
+    const int n0 = nwg + wn * (32 * NT);
     const unsigned short* x = a.x + (size_t)z * a.x_bs;
     const unsigned short* w = a.w + (size_t)z * a.w_bs;
-
-    const long pa = p0 + i;
-    const int ohw = a.OH * a.OW;
-    const int b = (int)(pa / ohw);
-    const int rem = (int)(pa - (long)b * ohw);
-    const int oy = rem / a.OW, ox = rem - oy * a.OW;
-    const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-    const unsigned short* xb = x + (size_t)b * H * W * IC;
     const uint32_t sel = h ? 0x03020c0cu : 0x01000c0cu;       // v_perm: high half kept / low half moved up = the bf16 as fp32
-    const unsigned short* wrow[NT];
+
+    // what this thread stages: piece (row, q) -> lds[(row * 4 + (q ^ ((row >> 2) & 3)))]: the XOR spreads the rows of a 16-lane read
+    // group over all 64 banks (rows are 64 bytes = 16 banks apart)
+    const unsigned short* arow[NPA];
+    int aiy0[NPA], aix0[NPA], aslot[NPA];
+    bool aon[NPA];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wrow[t] = w + (size_t)(n0 + t * 32 + i) * KT * IC;
+    for (int j = 0; j < NPA; ++j) {
+        const int idx = tid + 256 * j, row = idx >> 2, q = idx & 3;
+        aon[j] = idx < RA * 4;
+        const long pa = pwg + (aon[j] ? row : 0);
+        const int ohw = a.OH * a.OW;
+        const int b = (int)(pa / ohw);
+        const int rem = (int)(pa - (long)b * ohw);
+        const int oy = rem / a.OW, ox = rem - oy * a.OW;
+        aiy0[j] = oy * a.stride - a.pad; aix0[j] = ox * a.stride - a.pad;
+        arow[j] = x + (size_t)b * H * W * IC + q * 8;
+        aslot[j] = row * 4 + (q ^ ((row >> 2) & 3));
+    }
+    const unsigned short* brow[NPB];
+    int bslot[NPB];
+    bool bon[NPB];
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+        const int idx = tid + 256 * j, row = idx >> 2, q = idx & 3;
+        bon[j] = idx < RB * 4;
+        brow[j] = w + (size_t)(nwg + (bon[j] ? row : 0)) * KT * IC + q * 8;
+        bslot[j] = (RA + row) * 4 + (q ^ ((row >> 2) & 3));
+    }
 
     float C[NT][16], S[PARTIAL ? NT : 1][16];
 #pragma unroll
@@ -96,38 +121,49 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
         for (int r = 0; r < 16; ++r) { C[t][r] = 0.f; if (PARTIAL) S[t][r] = 0.f; }
 
     int kh = 0, kw = 0, icb = 0;
-    auto advance = [&]() {
+    u32x4 sa[NPA], sb[NPB];
+    auto fetch = [&]() {                 // global -> registers for the chunk (kh, kw, icb), then step to the next chunk
+#pragma unroll
+        for (int j = 0; j < NPA; ++j) {
+            const int iy = aiy0[j] + kh, ix = aix0[j] + kw;
+            const bool ok = aon[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            const u32x4 v = *reinterpret_cast<const u32x4*>(arow[j] + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * IC + icb * 32);
+            sa[j] = ok ? v : zero;
+        }
+        const size_t woff = (size_t)(kh * KW + kw) * IC + icb * 32;
+#pragma unroll
+        for (int j = 0; j < NPB; ++j) sb[j] = *reinterpret_cast<const u32x4*>(brow[j] + woff);
         if (!PARTIAL) { if (++icb == nicb) { icb = 0; if (++kw == KW) { kw = 0; ++kh; } } }
         else { if (++kw == KW) { kw = 0; if (++kh == KH) { kh = 0; ++icb; } } }
     };
-    auto load = [&](Ops& o) {
-        const int iy = iy0 + kh, ix = ix0 + kw;
-        const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        const u32x4* ap = reinterpret_cast<const u32x4*>(xb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * IC + icb * 32);
-        const u32x4 zero = {0u, 0u, 0u, 0u};
+    auto stage = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const u32x4 v = ap[q]; o.a[q] = ok ? v : zero; }
-        const size_t woff = (size_t)(kh * KW + kw) * IC + icb * 32;
+        for (int j = 0; j < NPA; ++j) if (aon[j]) lds[buf][aslot[j]] = sa[j];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const u32x4* bp = reinterpret_cast<const u32x4*>(wrow[t] + woff);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o.b[t][q] = bp[q];
-        }
-        advance();
+        for (int j = 0; j < NPB; ++j) if (bon[j]) lds[buf][bslot[j]] = sb[j];
     };
-    auto compute = [&](const Ops& o) {
+    const int ra = wm * 32 + i, swa = (ra >> 2) & 3;
+    int rb[NT], swb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { rb[t] = RA + wn * (32 * NT) + t * 32 + i; swb[t] = ((rb[t] - RA) >> 2) & 3; }
+    auto compute = [&](int buf) {
         f32x32 acc[NT];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const uint32_t wa = o.a[kk >> 2][kk & 3];
-            const float fa = __uint_as_float(__builtin_amdgcn_perm(wa, wa, sel));
+        for (int q = 0; q < 4; ++q) {
+            const u32x4 va = lds[buf][ra * 4 + (q ^ swa)];
+            u32x4 vb[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const uint32_t wb = o.b[t][kk >> 2][kk & 3];
-                const float fb = __uint_as_float(__builtin_amdgcn_perm(wb, wb, sel));
-                if (kk == 0) { const f32x32 zero = {0}; acc[t] = __builtin_amdgcn_mfma_f32_32x32x1f32(fa, fb, zero, 0, 0, 0); }
-                else acc[t] = __builtin_amdgcn_mfma_f32_32x32x1f32(fa, fb, acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) vb[t] = lds[buf][rb[t] * 4 + (q ^ swb[t])];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float fa = __uint_as_float(__builtin_amdgcn_perm(va[e], va[e], sel));
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float fb = __uint_as_float(__builtin_amdgcn_perm(vb[t][e], vb[t][e], sel));
+                    if (q == 0 && e == 0) { const f32x32 zero = {0}; acc[t] = __builtin_amdgcn_mfma_f32_32x32x1f32(fa, fb, zero, 0, 0, 0); }
+                    else acc[t] = __builtin_amdgcn_mfma_f32_32x32x1f32(fa, fb, acc[t], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -138,16 +174,15 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
                 if (PARTIAL) S[t][r] = S[t][r] + c; else C[t][r] = C[t][r] + c;
             }
     };
-    auto after = [&](int c) {            // order 3: an ic-block's private sum joins the total when its KH * KW taps are done
-        if (PARTIAL && (c + 1) % KT == 0) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { C[t][r] = C[t][r] + S[t][r]; S[t][r] = 0.f; }
-        }
-    };
-    auto before = [&](int c) {           // the flash kernel's `dst *= exp(old max - new max)` between its two kv blocks
-        if (a.rescale != nullptr && c == a.split) {
+
+    const int nchunks = KT * nicb;
+    fetch();
+    stage(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        if (more) fetch();                                       // the next chunk's 12 KB are in flight during this chunk's MFMAs
+        if (a.rescale != nullptr && c == a.split) {              // the flash kernel's `dst *= exp(old max - new max)` between its two kv blocks
             const float* rs = a.rescale + (size_t)z * a.v_bs + p0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -156,18 +191,15 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
                 for (int t = 0; t < NT; ++t) C[t][r] = C[t][r] * f;
             }
         }
-    };
-
-    const int nchunks = KT * nicb;
-    Ops o0, o1;
-    load(o0);
-    for (int c = 0; c < nchunks; c += 2) {
-        if (c + 1 < nchunks) load(o1);
-        before(c);
-        compute(o0);
-        after(c);
-        if (c + 2 < nchunks) load(o0);
-        if (c + 1 < nchunks) { before(c + 1); compute(o1); after(c + 1); }
+        compute(c & 1);
+        if (PARTIAL && (c + 1) % KT == 0) {                      // order 3: an ic-block's private sum joins the total when its taps are done
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { C[t][r] = C[t][r] + S[t][r]; S[t][r] = 0.f; }
+        }
+        if (more) stage((c + 1) & 1);
+        __syncthreads();
     }
 
     // epilogue: lane (col = i, rows (r & 3) + 8 (r >> 2) + 4 h)

@@ -7,8 +7,9 @@ architectural mirror mimogpt/models/selftok/sd3/sd3_impls.py:215-474.
 
 Default (`mode="parity"`): channels-last activations, every convolution through our implicit-GEMM kernel (csrc/conv.hip: fp32 accumulation
 of bf16 products with the bias inside, ONE rounding -- the reference's CPU arithmetic -- with ResnetBlock's residual add, Upsample's
-nearest 2x and Downsample's padding fused), GroupNorm+SiLU by our fp64-statistics kernel, the single-head mid attention in torch ops
-that round where the CPU flash kernel rounds (`_attn_tokens`).  No MIOpen, bit-stable by construction, 103 ms per 64 images (encode +
+nearest 2x and Downsample's padding fused), GroupNorm+SiLU by our fp64-statistics kernel, the single-head mid attention (round 4) by the
+exact-order kernels of csrc/vae_exact.hip -- no torch arithmetic is left in the VAE at 256 x 256 (`_attn_tokens`, the torch-op formulation
+that rounds where the CPU flash kernel rounds, remains for other token counts and the 'miopen' / 'fast' modes).  No MIOpen, bit-stable by construction, 103 ms per 64 images (encode +
 decode) against 331 ms for the MIOpen route below and 185 ms for MIOpen's fastest (inaccurate) solvers.
 
 `mode="exact"` (round 4, the pipeline's default at 256 x 256): the ENCODER additionally reproduces the ORDER of every reduction of the
@@ -137,11 +138,13 @@ class AutoencoderKLGPU(ModuleSurface):
         # native path: packed weight images of csrc/conv.hip (built on first use of mode 'parity')
         self.pc = {}
         self.xw = {}
-        if mode == "exact":
+        if mode in ("exact", "parity"):
             # the checkpoint's tensors, permuted to [Cout, k, k, Cin] (no packing): the exact-order kernels read 64 contiguous bytes per
             # (output channel, tap, 32-channel block).  diffusers stores the attention projections as Linear [O, I] = a 1x1 convolution.
+            # 'exact': the whole encoder; both modes: the mid-block attention of encoder AND decoder (AttnBlock, sd3_impls.py:274-284)
+            # runs on these kernels -- GroupNorm, q / k / v / out projections and the flash-kernel row pass in the reference's order
             for k, v in self.w.items():
-                if k.startswith("encoder.") and k.endswith(".weight") and v.dim() in (2, 4):
+                if k.endswith(".weight") and v.dim() in (2, 4) and (".attentions." in k or (mode == "exact" and k.startswith("encoder."))):
                     v4 = v.reshape(v.shape[0], v.shape[1], 1, 1) if v.dim() == 2 else v
                     self.xw[k[:-len(".weight")]] = v4.permute(0, 2, 3, 1).contiguous()
             self.silu_table = ops.vx_silu_table(device)
@@ -161,9 +164,17 @@ class AutoencoderKLGPU(ModuleSurface):
         return ops.conv2d_nhwc(self._n_gn(p + ".norm2", h), self.pc[p + ".conv2"], residual=sc)          # x + h: second rounding in the epilogue
 
     def _n_attn(self, p, x):
+        """AttnBlock on channels-last tokens, every step a HIP kernel in the reference's CPU order (csrc/vae_exact.hip): GroupNorm with
+        ATen's statistics, the four projections as 1x1 convolutions in oneDNN's chunk order, the attention as ATen's flash kernel
+        evaluates it (T = 1024 tokens: the VAE at 256 x 256).  Other token counts keep the torch-op formulation of `_attn_tokens`."""
         B, H, W, C = x.shape
-        h = self._n_gn(p + ".group_norm", x, act=False).reshape(B, H * W, C)
-        return x + self._attn_tokens(p, h).reshape(B, H, W, C)
+        if H * W != 1024 or not self.xw:
+            h = self._n_gn(p + ".group_norm", x, act=False).reshape(B, H * W, C)
+            return x + self._attn_tokens(p, h).reshape(B, H, W, C)
+        n = self._x_gn(p + ".group_norm", x, act=False)
+        q, k, v = (self._x_conv(p + s, n).reshape(B, H * W, C) for s in (".to_q", ".to_k", ".to_v"))
+        a = ops.vx_attention(q, k, v).reshape(B, H, W, C)
+        return self._x_conv(p + ".to_out.0", a, residual=x)
 
     def _n_encode_moments(self, img):
         x = img.to(self.device, self.dtype).permute(0, 2, 3, 1)
@@ -215,12 +226,7 @@ class AutoencoderKLGPU(ModuleSurface):
             if lvl != 3:
                 h = self._x_conv(f"encoder.down_blocks.{lvl}.downsamplers.0.conv", h, stride=2)
         h = self._x_res("encoder.mid_block.resnets.0", h)
-        p = "encoder.mid_block.attentions.0"
-        B, H, W, C = h.shape
-        n = self._x_gn(p + ".group_norm", h, act=False)
-        q, k, v = (self._x_conv(p + s, n).reshape(B, H * W, C) for s in (".to_q", ".to_k", ".to_v"))
-        a = ops.vx_attention(q, k, v).reshape(B, H, W, C)
-        h = self._x_conv(p + ".to_out.0", a, residual=h)
+        h = self._n_attn("encoder.mid_block.attentions.0", h)
         h = self._x_res("encoder.mid_block.resnets.1", h)
         h = self._x_conv("encoder.conv_out", self._x_gn("encoder.conv_norm_out", h))
         return h.permute(0, 3, 1, 2).contiguous()
