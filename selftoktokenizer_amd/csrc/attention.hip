@@ -258,8 +258,8 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams P)
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void attn_lds_dma16(const void* base, unsigned voff, unsigned lds)
 {
-    // M0 = LDS byte address of the 1-KiB piece (hipcc never keeps a value in M0 across statements)
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory");
+    // M0 = LDS byte address of the 1-KiB piece; declared as clobbered so that no compiler version keeps a value of its own in M0 across this
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory", "m0");
 }
 
 __global__ __launch_bounds__(256) void attn64_dma_kernel(AttnParams P)

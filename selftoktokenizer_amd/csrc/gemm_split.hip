@@ -355,7 +355,7 @@ constexpr int P_LDS_BYTES = PW_BASE + PW_STAGES * W_BYTES;   // 163840
 // Inline asm because hipcc will not select the SGPR-base form for the builtin (it rebuilds a 64-bit VGPR address per piece).
 __device__ __forceinline__ void lds_dma16(const void* base, unsigned voff, unsigned lds)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory");   // M0 is reserved: hipcc never keeps a value in it across statements
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory", "m0");   // M0 declared as clobbered
 }
 
 // fused residual epilogue (RES): out = resid + gate * (A W^T + bias), gate element (row, col) at gate + (row / T) gsb + (row % T) gst + col
