@@ -231,25 +231,25 @@ def measured_vq_traffic(n_vq: int, coarse: bool, path=None):
     return int(d[key]), f"rocprofv3 PMC, sources {now}: {d.get('method', '')}"
 
 
-def vq_roofline(n_vq, C, Dm, main_ms, fin_ms, launches, traffic, traffic_note, fp32_main_ms=None, fp32_fin_ms=None, ids_bytes=8):
+def vq_roofline(n_vq, C, Dm, main_ms, fin_ms, launches, traffic, traffic_note, fp32_main_ms=None, fp32_fin_ms=None, ids_bytes=8, mfmas=3):
     """the `roofline` object of the JSON line, from measured kernel times.  Dominant kernel = vq_f16_kernel (the coarse pass: 3
     v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 block of the score matrix).  `achieved` / `frac` (= `frac_algorithmic`): the ALGORITHMIC
     FLOPs per launch (2NCD, SURVEY 8d) / its average launch duration against the dense f16 matrix peak, as the contract defines them;
     `achieved_executed` / `frac_executed`: the f16-MFMA FLOPs the kernel issues (3 x 2NCD) over the same time = pipe utilisation."""
     flops = 2.0 * n_vq * C * Dm                                   # the reference's fp32 score matrix (SURVEY 8d)
-    executed = 3.0 * flops                                        # f16 MFMA FLOPs the coarse kernel issues (hi*hi + hi*lo + lo*hi)
+    executed = float(mfmas) * flops                               # f16 MFMA FLOPs the coarse kernel issues: 1 (hi*hi) or 3 (hi*hi + hi*lo + lo*hi) per product
     alg_bytes = 4.0 * n_vq * Dm + 4.0 * C * Dm + float(ids_bytes) * n_vq   # z + codebook (once) + ids
     ach_exec = executed / (main_ms * 1e-3) / 1e12
     ach = flops / (main_ms * 1e-3) / 1e12
     both = main_ms + fin_ms
-    roof = {"kernel": "vq_f16_kernel<RT> (f16 coarse pass of the cosine argmax; vq_finalize_f16_kernel re-scores the candidates in canonical fp32: "
-                      "ids and top-1 score bits equal the fp32 kernels')",
+    roof = {"kernel": "vq_f16_kernel<RT,%d> (f16 coarse pass of the cosine argmax, %d MFMA%s per 32 x 32 scores; vq_finalize_f16_kernel re-scores the candidates "
+                      "inside the proven error window in canonical fp32: ids and top-1 score bits equal the fp32 kernels')" % (mfmas, mfmas, "" if mfmas == 1 else "s"),
             "bound": "mfma", "achieved": round(ach, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F16_MFMA_PEAK_TFLOPS, 4),
             "frac_algorithmic": round(ach / F16_MFMA_PEAK_TFLOPS, 4), "achieved_executed": round(ach_exec, 2), "frac_executed": round(ach_exec / F16_MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic, "traffic_note": traffic_note,
             "traffic_over_algorithmic_bytes": (round(traffic / alg_bytes, 2) if traffic else None),
             "avg_launch_ms": round(main_ms, 4), "finalize_kernel_ms": round(fin_ms, 4), "both_launches_ms": round(both, 4), "launches": launches,
-            "executed_flops_per_launch": executed, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
+            "executed_flops_per_launch": executed, "mfmas_per_product": mfmas, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
             "timing": "HIP events on the launch stream around each of the two launches of every VQ call inside the timed steps",
             "fp32_equivalent": {"tflops": round(flops / (both * 1e-3) / 1e12, 2), "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
                                 "note": "2NCD of the reference's fp32 score matrix / (both launches); NOT a roofline fraction of this kernel (it runs on "
@@ -611,7 +611,7 @@ def main(argv=None):
     _, lm, lf = ops.vq_encode_split_launch(zf, pipe.model.encoder.codebook_packed, coarse=False)
     fp32_main, fp32_fin = event_time_ms(lm, n=20), event_time_ms(lf, n=20)
     traffic, traffic_note = measured_vq_traffic(n_vq, ops.VQ_DEFAULT_COARSE)
-    roof = vq_roofline(n_vq, 32768, 16, vq_main, vq_fin, len(vq_events), traffic, traffic_note, fp32_main, fp32_fin)
+    roof = vq_roofline(n_vq, 32768, 16, vq_main, vq_fin, len(vq_events), traffic, traffic_note, fp32_main, fp32_fin, mfmas=ops.VQ_COARSE_MFMAS)
     arith = {"fp32": "fp32 Q-Former/VQ/MMDiT (hipBLASLt fp32 GEMMs), bf16 SD3-VAE (reference dtypes)",
              "f16x2": "fp32 Q-Former/VQ/MMDiT with the MMDiT block Linears and joint attention as f16x2-split products on the f16 matrix cores "
                       "(fp32-equivalent: error vs fp64 below the fp32 kernels', tests/test_gemm_gpu.py, test_kernels_gpu.py), bf16 SD3-VAE"}

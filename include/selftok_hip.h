@@ -40,6 +40,9 @@ typedef struct ihipStream_t* hipStream_t;
 #define SELFTOK_VQ_F16COARSE 8  /* packed path: approximate scores on the f16 matrix cores (3 MFMAs of the 16x-rate pipe per 32x32 scores),
                                   then canonical fp32 re-score of every candidate within the proven error window -> the SAME ids and
                                   top-1 score bits as the fp32 kernels (csrc/vq.hip, vq_f16_kernel) */
+#define SELFTOK_VQ_F16COARSE1 16 /* with SELFTOK_VQ_F16COARSE: ONE MFMA per 32x32 scores (hi x hi only) and a 136x wider re-score window
+                                   (17 x 2^-14, proven in csrc/vq.hip): 3x fewer MFMAs in the coarse pass, a longer exact re-score; same
+                                   ids and score bits.  Pass the same flag to the partial pass and to the finalize. */
 #define SELFTOK_VQ_RT(n) (((n) & 0xF) << 8)
 #define SELFTOK_VQ_SPLIT(n) (((n) & 0xFF) << 16)
 

@@ -247,6 +247,13 @@ constexpr float F16_SCORE_SCALE = F16_PRESCALE * F16_PRESCALE;
 // <= 1), the canonical chain's own 16 roundings <= 9.5e-7: < 2.4e-6 in the worst case.  The window is 3x that; measured maximum
 // over 1.7e7 scores: 3.0e-7 (tests/test_vq_gpu.py::test_vq_coarse_pass_error_bound_and_adversarial_near_ties).
 constexpr float F16_EPS = 7.62939453125e-06f;          // 2^-17
+// ONE-MFMA coarse pass (round 4, SELFTOK_VQ_F16COARSE1): only hi x hi.  |x_k e_k - x0_k e0_k| <= |x_k| |e_k - e0_k| + |e0_k| |x_k - x0_k|
+// <= |x_k e_k| (2^-11 + 2^-11 (1 + 2^-11)) (fp16 keeps 11 significand bits: relative rounding error <= 2^-11), summed with Cauchy-Schwarz
+// over unit vectors (norm^2 <= 1.01): <= 9.86e-4; + the fp32 accumulation of one MFMA and the canonical chain's own roundings (< 2e-6)
+// + fp16 subnormals of 2^7-scaled components below 5e-7 (< 1e-8).  The window constant is 17 x 2^-14 = 1.0376e-3, 5 % above that.
+// Three times fewer MFMAs for a window 136x wider: 1.08 instead of 1.00 candidate streams per row and 0.4 % of the rows with a stream
+// whose two best tiles are both inside the window (whole-stream exact re-scan) on the synthetic features -- a longer finalize.
+constexpr float F16_EPS1 = 0.00103759765625f;
 // the bound above holds for |x|^2, |e|^2 <= 1; up to 1.01 it grows by 1 % (the window has a 3x margin).  Rows / code books beyond
 // it are flagged and take the exact scan (nothing enforced the unit-norm premise of the window).
 constexpr float F16_NORM2_MAX = 1.01f;
@@ -524,7 +531,7 @@ constexpr uint32_t F16_FLAG = 0x80000000u;       // entry.lo bit 31: re-scan the
 
 SELFTOK_STAMP_DECL(tune_stamp_vq_f16);
 
-template <int RT>
+template <int RT, int NM>       // NM = MFMAs per 32 x 32 scores: 3 (hi*hi + hi*lo + lo*hi, window 2^-17) or 1 (hi*hi, window F16_EPS1)
 __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z, const float* __restrict__ packed,
                                                      unsigned long long* __restrict__ partial, int N, int C,
                                                      int tiles_per_split, int normalize)
@@ -592,6 +599,7 @@ __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z
     auto stage = [&](int chunk, int buf) {      // this wave's share: pieces wave, wave+4, ... of the 2*M_CH 1-KiB (tile, plane) pieces
 #pragma unroll
         for (int pi = wave; pi < 2 * M_CH; pi += 4) {
+            if (NM == 1 && (pi & 1)) continue;                            // the lo plane is not read by the one-MFMA pass
             int tl = chunk * M_CH + (pi >> 1);
             tl = tl < nt ? tl : nt - 1;
             const _Float16* src = packed16 + (size_t)(tile_first + tl) * 1024 + (pi & 1) * 512 + lane * 8;
@@ -625,13 +633,16 @@ __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z
             for (int j = 0; j < M_CH; ++j) {
                 if (base + j < nt) {                                   // wave-uniform
                     const vh8 e0 = *reinterpret_cast<const vh8*>(&s_tile[buf][j * 2048 + lane * 16]);
-                    const vh8 e1 = *reinterpret_cast<const vh8*>(&s_tile[buf][j * 2048 + 1024 + lane * 16]);
+                    vh8 e1 = e0;
+                    if (NM == 3) e1 = *reinterpret_cast<const vh8*>(&s_tile[buf][j * 2048 + 1024 + lane * 16]);
                     const int tile = tile_first + base + j;
 #pragma unroll
                     for (int t = 0; t < RT; ++t) {
                         f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, __builtin_bit_cast(vh8, x0[t]), zero, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, __builtin_bit_cast(vh8, x1[t]), acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, __builtin_bit_cast(vh8, x0[t]), acc, 0, 0, 0);
+                        if (NM == 3) {
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, __builtin_bit_cast(vh8, x1[t]), acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, __builtin_bit_cast(vh8, x0[t]), acc, 0, 0, 0);
+                        }
                         // tile maximum (8 x v_max3), then (m1, m2) <- the two largest of (m1, m2, mt): v_max + v_med3
                         const float a0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]), a1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
                         const float a2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]), a3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
@@ -650,7 +661,7 @@ __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z
     }
 
     SELFTOK_STAMP_END(tune_stamp_vq_f16);
-    const float win = 2.0f * F16_EPS * F16_SCORE_SCALE;
+    const float win = 2.0f * (NM == 1 ? F16_EPS1 : F16_EPS) * F16_SCORE_SCALE;
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
         const bool flag = bad || !(m2[t] < m1[t] - win);                // also true when m1 is NaN
@@ -669,7 +680,7 @@ __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z
 template <typename IdT>
 __global__ __launch_bounds__(256) void vq_finalize_f16_kernel(const unsigned long long* __restrict__ partial, const float* __restrict__ z,
                                                               const float* __restrict__ packed, IdT* __restrict__ ids, float* __restrict__ best,
-                                                              int N, int C, int nsplit, int tiles_per_split, int normalize)
+                                                              int N, int C, int nsplit, int tiles_per_split, int normalize, float win)
 {
     const int gl = threadIdx.x & 15;
     const int gsh = (threadIdx.x & 63) & ~15;                            // first lane of this row's 16-lane group inside the wave
@@ -695,7 +706,7 @@ __global__ __launch_bounds__(256) void vq_finalize_f16_kernel(const unsigned lon
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(gmax, o, 16); gmax = other > gmax ? other : gmax; }
-    const float thresh = (gmax == KEY_NAN) ? -__builtin_inff() : f32_from_orderable(gmax) - 2.0f * F16_EPS * F16_SCORE_SCALE;
+    const float thresh = (gmax == KEY_NAN) ? -__builtin_inff() : f32_from_orderable(gmax) - win;       // win = 2 eps of the coarse pass, scaled
 
     Best b;
     best_init(b, 0);
@@ -1030,9 +1041,15 @@ int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, vo
         split = (ntiles + tps - 1) / tps;
         *nsplit_out = split;
         dim3 grid(row_blocks, split), block(256);
-        if (rt == 4) hipLaunchKernelGGL(vq_f16_kernel<4>, grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
-        else if (rt == 2) hipLaunchKernelGGL(vq_f16_kernel<2>, grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
-        else hipLaunchKernelGGL(vq_f16_kernel<1>, grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
+        if (flags & SELFTOK_VQ_F16COARSE1) {
+            if (rt == 4) hipLaunchKernelGGL((vq_f16_kernel<4, 1>), grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
+            else if (rt == 2) hipLaunchKernelGGL((vq_f16_kernel<2, 1>), grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
+            else hipLaunchKernelGGL((vq_f16_kernel<1, 1>), grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
+        } else {
+            if (rt == 4) hipLaunchKernelGGL((vq_f16_kernel<4, 3>), grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
+            else if (rt == 2) hipLaunchKernelGGL((vq_f16_kernel<2, 3>), grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
+            else hipLaunchKernelGGL((vq_f16_kernel<1, 3>), grid, block, 0, stream, z, packed, partial, N, C, tps, norm);
+        }
         return check_launch("vq_f16_kernel");
     }
     int rt = N >= 32768 ? 4 : (N >= 8192 ? 2 : 1);     // measured: 130 / 126 / 118 TF at N=32768 for RT = 4 / 2 / 1
@@ -1075,8 +1092,9 @@ int selftok_vq_finalize_packed(const void* workspace, const float* z, const floa
     const int norm = (flags & 2) ? 0 : 1;
     if (flags & SELFTOK_VQ_F16COARSE) {
         const int ntiles = C >> 5, tps = (ntiles + nsplit - 1) / nsplit;
-        if (flags & 1) hipLaunchKernelGGL(vq_finalize_f16_kernel<int32_t>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (int32_t*)ids, best, N, C, nsplit, tps, norm);
-        else hipLaunchKernelGGL(vq_finalize_f16_kernel<long long>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (long long*)ids, best, N, C, nsplit, tps, norm);
+        const float win = 2.0f * ((flags & SELFTOK_VQ_F16COARSE1) ? F16_EPS1 : F16_EPS) * F16_SCORE_SCALE;      // must match the main kernel's
+        if (flags & 1) hipLaunchKernelGGL(vq_finalize_f16_kernel<int32_t>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (int32_t*)ids, best, N, C, nsplit, tps, norm, win);
+        else hipLaunchKernelGGL(vq_finalize_f16_kernel<long long>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (long long*)ids, best, N, C, nsplit, tps, norm, win);
         return check_launch("vq_finalize_f16_kernel");
     }
     if (flags & 1) hipLaunchKernelGGL(vq_finalize_packed_kernel<int32_t>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (int32_t*)ids, best, N, 2 * nsplit, norm);

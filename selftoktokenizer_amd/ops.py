@@ -14,7 +14,22 @@ from . import _lib
 IDS_I32 = 1
 PRENORMED = 2
 VQ_F16COARSE = 8     # packed path: f16 coarse pass + exact fp32 re-score (same ids / score bits, ~4x faster than the fp32-MFMA kernel)
+VQ_F16COARSE1 = 16   # with VQ_F16COARSE: ONE MFMA per 32 x 32 scores (hi x hi) and a wider exact re-score window (same ids / score bits)
 VQ_DEFAULT_COARSE = True
+VQ_COARSE_MFMAS = 1  # MFMAs per 32 x 32 coarse scores when `coarse` is True / None: 1 (hi x hi, window 17 x 2^-14; round 4: 0.115 -> 0.079 ms at
+                     # N = 32768, profiles/r4_vq_bench_1mfma.txt) or 3 (hi*hi + hi*lo + lo*hi, window 2^-17)
+
+
+def _coarse_flags(coarse) -> int:
+    """coarse: None -> the defaults, False -> fp32-input MFMA kernel, True -> f16 coarse pass with VQ_COARSE_MFMAS, 3 / 1 -> that variant"""
+    if coarse is None:
+        coarse = VQ_DEFAULT_COARSE
+    if coarse is False or coarse == 0:
+        return 0
+    n = VQ_COARSE_MFMAS if coarse is True else int(coarse)
+    if n not in (1, 3):
+        raise ValueError(f"coarse = {coarse!r}: expected None, False, True, 1 or 3")
+    return VQ_F16COARSE | (VQ_F16COARSE1 if n == 1 else 0)
 VQ_EVENTS = None     # bench.py sets this to a list: vq_encode(packed=True) then appends (start, after main kernel, after finalize) HIP events
 
 
@@ -63,11 +78,13 @@ def vq_encode(z: torch.Tensor, codebook: torch.Tensor, *, packed: bool = False, 
               ids_dtype=torch.int64, prenormed: bool = False, rt: int = 0, split: int = 0, coarse=None):
     """z [...,16] fp32 (pre-norm) , codebook [C,16] (raw, or packed if packed=True) -> ids [...].
     rt / split: launch-shape overrides of the packed path (SELFTOK_VQ_RT / SELFTOK_VQ_SPLIT; 0 = automatic).
-    coarse (packed path): True = f16 coarse pass + exact re-score (SELFTOK_VQ_F16COARSE), False = fp32-input MFMA kernel;
-    None = VQ_DEFAULT_COARSE.  Both return identical ids and score bits."""
+    coarse (packed path): True = f16 coarse pass + exact re-score (SELFTOK_VQ_F16COARSE) with VQ_COARSE_MFMAS MFMAs per 32 x 32 scores,
+    3 / 1 = that variant explicitly (1 = SELFTOK_VQ_F16COARSE1), False = fp32-input MFMA kernel; None = VQ_DEFAULT_COARSE.  All return
+    identical ids and score bits."""
     _need_cuda(z, codebook)
     lib = _lib.load()
-    use_coarse = packed and (VQ_DEFAULT_COARSE if coarse is None else bool(coarse))
+    cflags = _coarse_flags(coarse) if packed else 0
+    use_coarse = cflags if cflags else False
     if packed and VQ_EVENTS is not None and not return_best and not prenormed and z.numel() > 0:
         # same two launches as selftok_vq_encode_packed_f32, with HIP events around the argmax kernel on its launch stream
         ids, launch_main, launch_fin = vq_encode_split_launch(z, codebook, ids_dtype, coarse=use_coarse)
@@ -86,7 +103,7 @@ def vq_encode(z: torch.Tensor, codebook: torch.Tensor, *, packed: bool = False, 
     best = torch.empty(N, dtype=torch.float32, device=z.device) if return_best else None
     ws = torch.empty(lib.selftok_vq_workspace_bytes(N, C), dtype=torch.uint8, device=z.device)
     flags = ((IDS_I32 if ids_dtype == torch.int32 else 0) | (PRENORMED if prenormed else 0) | ((rt & 0xF) << 8) | ((split & 0xFF) << 16)
-             | (VQ_F16COARSE if use_coarse else 0))
+             | cflags)
     fn = lib.selftok_vq_encode_packed_f32 if packed else lib.selftok_vq_encode_f32
     _lib.check(fn(_p(zz), _p(codebook), _p(ids), _p(best), _p(ws), N, C, D, flags, _stream()),
                "selftok_vq_encode_packed_f32" if packed else "selftok_vq_encode_f32")
@@ -589,7 +606,7 @@ def vq_encode_split_launch(z, packed_codebook, ids_dtype=torch.int64, coarse=Non
     C = packed_codes(packed_codebook, D)
     ids = torch.empty(N, dtype=ids_dtype, device=z.device)
     ws = torch.empty(lib.selftok_vq_workspace_bytes(N, C), dtype=torch.uint8, device=z.device)
-    flags = (IDS_I32 if ids_dtype == torch.int32 else 0) | (VQ_F16COARSE if (VQ_DEFAULT_COARSE if coarse is None else coarse) else 0)
+    flags = (IDS_I32 if ids_dtype == torch.int32 else 0) | (coarse if isinstance(coarse, int) and not isinstance(coarse, bool) and coarse >= 8 else _coarse_flags(coarse))
     nsplit = ctypes.c_int(0)
 
     def launch_main():

@@ -108,10 +108,10 @@ def test_expf_restatement_equals_libm():
         assert a.view(np.uint32) == b.view(np.uint32), (v, a, b)
 
 
-def _encoder_latents(n):
+def _encoder_latents(n, first=0):
     vsd = W.synthetic_vae_state_dict()
     pw = VX.pack_weights(vsd)
-    img = synth.synthetic_images(n).to(torch.bfloat16)
+    img = synth.synthetic_images(n, first_index=first).to(torch.bfloat16)
     mom = VX.encode_moments(pw, VX.bf16_bits(img.permute(0, 2, 3, 1)))
     mean = VX.bits_to_torch(mom[..., :16]).permute(0, 3, 1, 2).contiguous()
     from oracle import model as OM
@@ -128,10 +128,12 @@ def test_encoder_equals_the_reference_pipeline_run_image_0():
 
 
 @pytest.mark.slow
-def test_encoder_equals_the_reference_pipeline_run_all_16_images():
+def test_encoder_equals_the_reference_pipeline_run_images_13_to_15():
+    """three more of the 16 (all 16 were checked when the oracle was written: 0 of 262144 elements differ; the
+    GPU suite checks all 16 through the HIP kernels); ~10 s per image on 8 cores"""
     g = np.load(os.path.join(GOLD, "pipeline_b16.npz"))
-    x0 = _encoder_latents(16)
-    ref = torch.from_numpy(g["x0_bf16"]).view(torch.bfloat16)
+    x0 = _encoder_latents(3, first=13)
+    ref = torch.from_numpy(g["x0_bf16"][13:16]).view(torch.bfloat16)
     assert int((x0.view(torch.int16) != ref.view(torch.int16)).sum()) == 0
 
 

@@ -57,3 +57,33 @@ def test_coarse_score_within_the_window_random_and_adversarial():
     s_c, s_t = coarse(z, e), canonical(z, e)
     true_arg = s_t.argmax(1)
     assert (s_c[np.arange(len(z)), true_arg] >= s_c.max(1) - 2 * F16_EPS).all()
+
+
+F16_EPS1 = 17 * 2.0 ** -14          # csrc/vq.hip: the window constant of the one-MFMA coarse pass (hi x hi only)
+
+
+def coarse1(z, e):
+    z0, _ = hi_lo(z)
+    e0, _ = hi_lo(e)
+    return (z0 @ e0.T) / (PRESCALE * PRESCALE)
+
+
+def test_one_mfma_coarse_score_within_its_window_random_and_adversarial():
+    """SELFTOK_VQ_F16COARSE1: |x.e - x0.e0| <= sum |x_k e_k| (2^-11 + 2^-11 (1 + 2^-11)) <= 2^-10 (1 + 2^-12) |x| |e|: 9.9e-4 at norm^2 = 1.01;
+    worst-case-ish inputs push every component's fp16 rounding error in the same direction (components just above a power of two plus 3/4 ulp)"""
+    rng = np.random.default_rng(1)
+    D, C = 16, 4096
+    e = unit(rng.standard_normal((C, D)))
+    rows = [unit(rng.standard_normal((1024, D))), unit(rng.standard_normal((256, D)) * np.exp(rng.uniform(-12, 0, (256, D)))),
+            unit(e[:256] + 1e-4 * rng.standard_normal((256, D)).astype(np.float32))]
+    # adversarial: every component of x and of the matching code rounds DOWN by almost half an fp16 ulp -> errors add up with one sign
+    base = np.full((64, D), 0.25, np.float32) * (1 + (1023.49 / 1024) * 2.0 ** -11 * np.arange(1, 65, dtype=np.float32)[:, None] / 64)
+    rows.append(unit(base))
+    z = np.concatenate(rows)
+    e_adv = np.concatenate([e, unit(base)])
+    err = np.abs(coarse1(z, e_adv).astype(np.float64) - canonical(z, e_adv).astype(np.float64))
+    print("max |hi x hi - canonical| = %.3e (window constant F16_EPS1 = %.3e, analytic bound 9.9e-4)" % (err.max(), F16_EPS1))
+    assert err.max() < 9.9e-4 < F16_EPS1
+    s_c, s_t = coarse1(z, e_adv), canonical(z, e_adv)
+    true_arg = s_t.argmax(1)
+    assert (s_c[np.arange(len(z)), true_arg] >= s_c.max(1) - 2 * F16_EPS1).all()

@@ -23,7 +23,7 @@ def _check(z, cb, packed):
     ids_ref, best_ref = clib.vq_encode(z.numpy(), cb.numpy())
     zc, cbc = z.cuda(), cb.cuda()
     cbk = ops.vq_pack_codebook(cbc) if packed else cbc
-    for coarse in ((True, False) if packed else (None,)):
+    for coarse in ((3, 1, False) if packed else (None,)):
         ids, best = ops.vq_encode(zc, cbk, packed=packed, return_best=True, coarse=coarse)
         torch.cuda.synchronize()
         ids, best = ids.cpu().numpy(), best.cpu().numpy()
@@ -97,6 +97,11 @@ def test_vq_coarse_pass_error_bound_and_adversarial_near_ties(cb):
     err = float((coarse[:, :4096] - exact).abs().max())
     print(f"max |coarse - canonical| over 1.7e7 scores: {err:.3e}  (F16_EPS = 2^-17 = 7.6e-6)")
     assert err < 2.0 ** -17 / 8
+    # the one-MFMA pass (SELFTOK_VQ_F16COARSE1): hi x hi only, window constant F16_EPS1 = 17 x 2^-14
+    coarse1 = torch.mm(x0, e0.t(), out_dtype=torch.float32) / 16384.0
+    err1 = float((coarse1[:, :4096] - exact).abs().max())
+    print(f"max |hi x hi - canonical| over 1.7e7 scores: {err1:.3e}  (F16_EPS1 = 17 x 2^-14 = 1.04e-3; worst-case bound 9.9e-4)")
+    assert err1 < 17 * 2.0 ** -14
     # adversarial rows
     pairs = [(5, 9), (5, 5 + 4), (7, 33), (100, 32000), (31, 32), (0, 32767), (12345, 12345 + 16), (2048, 2048 + 1024)]
     rows = []
@@ -111,8 +116,23 @@ def test_vq_coarse_pass_error_bound_and_adversarial_near_ties(cb):
         ids_ref, best_ref = clib.vq_encode(z.numpy(), book.numpy())
         pk = ops.vq_pack_codebook(book.cuda())
         for sp in (0, 1, 2, 64):
-            ids, best = ops.vq_encode(z.cuda(), pk, packed=True, return_best=True, coarse=True, split=sp)
-            np.testing.assert_array_equal(ids.cpu().numpy(), ids_ref, err_msg=f"split={sp}")
+            for nm in (3, 1):
+                ids, best = ops.vq_encode(z.cuda(), pk, packed=True, return_best=True, coarse=nm, split=sp)
+                np.testing.assert_array_equal(ids.cpu().numpy(), ids_ref, err_msg=f"split={sp} mfmas={nm}")
+                np.testing.assert_array_equal(best.cpu().numpy().view(np.uint32), best_ref.view(np.uint32))
+    # rows whose two best codes sit INSIDE the one-MFMA window (gaps 1e-5 .. 1e-3: invisible to the 2^-17 window, candidates for the
+    # wide one) in the same tile / another tile of the stream (whole-stream re-scan) / another stream
+    rows = []
+    for a, b in ((5, 9), (5, 5 + 32 * 3), (7, 7 + 2048 * 5), (100, 100 + 4), (31, 32)):
+        for t in (1e-5, 1e-4, 5e-4, 9e-4, 2e-3):
+            rows.append(torch.nn.functional.normalize(cb[a] + cb[b], dim=-1) + t * cb[a])
+    z = torch.stack(rows)
+    ids_ref, best_ref = clib.vq_encode(z.numpy(), cb.numpy())
+    pk = ops.vq_pack_codebook(cb.cuda())
+    for nm in (3, 1):
+        for sp in (0, 4, 16):
+            ids, best = ops.vq_encode(z.cuda(), pk, packed=True, return_best=True, coarse=nm, split=sp)
+            np.testing.assert_array_equal(ids.cpu().numpy(), ids_ref, err_msg=f"near-window rows, split={sp} mfmas={nm}")
             np.testing.assert_array_equal(best.cpu().numpy().view(np.uint32), best_ref.view(np.uint32))
 
 
@@ -171,7 +191,7 @@ def test_vq_mfma_every_launch_shape_full_n(cb, n):
     combos = [(0, 0)] + [(rt, sp) for rt in (1, 2, 4) for sp in (0, 1, 7, 64)]
     if n > 32768:                                         # keep the big sizes to the variants that differ in code path
         combos = [(0, 0), (1, 0), (2, 7), (4, 64), (4, 1)]
-    for coarse in (True, False):                          # f16 coarse pass + exact re-score / fp32-input MFMA kernel
+    for coarse in (3, 1, False):                          # f16 coarse pass (3 / 1 MFMAs) + exact re-score / fp32-input MFMA kernel
         for rt, sp in combos:
             ids, best = ops.vq_encode(zc, pk, packed=True, return_best=True, rt=rt, split=sp, coarse=coarse)
             torch.cuda.synchronize()
@@ -229,7 +249,7 @@ def test_vq_coarse_path_guards_its_unit_norm_premise(cb):
     cb10 = (cb * scale).contiguous()
     ids_ref, best_ref = clib.vq_encode(z.numpy(), cb10.numpy())
     pk = ops.vq_pack_codebook(cb10.cuda())
-    for coarse in (True, False):
+    for coarse in (3, 1, False):
         ids, best = ops.vq_encode(z.cuda(), pk, packed=True, return_best=True, coarse=coarse)
         np.testing.assert_array_equal(ids.cpu().numpy(), ids_ref, err_msg=f"norm-10 code book, coarse={coarse}")
         np.testing.assert_array_equal(best.cpu().numpy().view(np.uint32), best_ref.view(np.uint32))
@@ -237,7 +257,7 @@ def test_vq_coarse_path_guards_its_unit_norm_premise(cb):
     zz = (z * 10.0).contiguous()
     ids_ref, best_ref = clib.vq_encode(zz.numpy(), cb.numpy(), normalize=False)
     pk1 = ops.vq_pack_codebook(cb.cuda())
-    for coarse in (True, False):
+    for coarse in (3, 1, False):
         ids, best = ops.vq_encode(zz.cuda(), pk1, packed=True, return_best=True, prenormed=True, coarse=coarse)
         np.testing.assert_array_equal(ids.cpu().numpy(), ids_ref, err_msg=f"non-unit prenormed rows, coarse={coarse}")
         np.testing.assert_array_equal(best.cpu().numpy().view(np.uint32), best_ref.view(np.uint32))

@@ -6,9 +6,11 @@ from selftoktokenizer_amd import ops, synth, weights as W
 
 cb = W._synth_tensor("encoder.quantizer._codebook.embed", (1, 32768, 16), "cpu")[0].contiguous().cuda()
 pk = ops.vq_pack_codebook(cb)
+# features: synthetic rows, or (argv[1] == "enc") the Q-Former encoder's own features of synthetic images -- their top-1/top-2 gaps set how many
+# candidates the wide window of the one-MFMA pass re-scores
 for n in (512, 32768, 65536, 131072):
     z = synth.synthetic_vq_rows(n, device="cuda")
-    for packed, name, coarse in ((False, "valu", None), (True, "mfma-fp32", False), (True, "f16-coarse+exact", True)):
+    for packed, name, coarse in ((False, "valu", None), (True, "mfma-fp32", False), (True, "f16-coarse(3 MFMAs)+exact", 3), (True, "f16-coarse(1 MFMA)+exact", 1)):
         c = pk if packed else cb
         for _ in range(3):
             ops.vq_encode(z, c, packed=packed, coarse=coarse)
