@@ -528,6 +528,11 @@ typedef unsigned vu4 __attribute__((ext_vector_type(4)));
 typedef float vf2 __attribute__((ext_vector_type(2)));
 
 constexpr uint32_t F16_FLAG = 0x80000000u;       // entry.lo bit 31: re-scan the whole stream exactly
+// 4-byte candidates of the one-MFMA pass: truncating the orderable key to its top 21 bits lowers a (2^14-scaled, <= 2^14 + margin) score by
+// less than C4_TRUNC = 2^15 * 2^-12 = 8 scaled units; the finalize widens its window by that much (a truncated maximum and a truncated
+// candidate can each be low by < 8: the candidate test `stored >= stored_max - win` needs win + C4_TRUNC)
+constexpr uint32_t C4_KEY_MASK = 0xFFFFF800u, C4_FLAG = 0x400u, C4_TILE_MASK = 0x3FFu;
+constexpr float C4_TRUNC = 8.0f;
 
 SELFTOK_STAMP_DECL(tune_stamp_vq_f16);
 
@@ -670,14 +675,21 @@ __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z
         // a row / code book with non-finite or out-of-range values: v_max3 skipped the NaNs, m1 means nothing -> every stream of
         // the row must be re-scanned exactly, which the NaN key (sorts highest, opens the window completely) forces
         const uint32_t hi = (bad || v != v) ? KEY_NAN : f32_orderable(v);
-        const uint32_t lo = (flag ? F16_FLAG : 0u) | (uint32_t)t1[t];
         const int r = row0 + t * 32 + col;
-        if (r < N) partial[((size_t)blockIdx.y * 2 + half) * N + r] = ((unsigned long long)hi << 32) | lo;
+        if (NM == 1) {
+            // 4-byte candidate (the one-MFMA window is 34 scaled score units wide, a key truncated to 21 bits moves by < 4 of them):
+            // [31:11] top 21 bits of the orderable key, [10] flag, [9:0] winning tile relative to the split (tiles_per_split <= 1024)
+            const uint32_t e = (hi & C4_KEY_MASK) | (flag ? C4_FLAG : 0u) | (uint32_t)(t1[t] - tile_first);
+            if (r < N) reinterpret_cast<uint32_t*>(partial)[((size_t)blockIdx.y * 2 + half) * N + r] = e;
+        } else {
+            const uint32_t lo = (flag ? F16_FLAG : 0u) | (uint32_t)t1[t];
+            if (r < N) partial[((size_t)blockIdx.y * 2 + half) * N + r] = ((unsigned long long)hi << 32) | lo;
+        }
     }
 }
 
 // exact resolution of the coarse pass: see the comment above vq_f16_kernel.  16 lanes per row.
-template <typename IdT>
+template <typename IdT, bool C4>       // C4: 4-byte candidates of the one-MFMA pass
 __global__ __launch_bounds__(256) void vq_finalize_f16_kernel(const unsigned long long* __restrict__ partial, const float* __restrict__ z,
                                                               const float* __restrict__ packed, IdT* __restrict__ ids, float* __restrict__ best,
                                                               int N, int C, int nsplit, int tiles_per_split, int normalize, float win)
@@ -698,24 +710,33 @@ __global__ __launch_bounds__(256) void vq_finalize_f16_kernel(const unsigned lon
             for (int k = 0; k < D; ++k) x[k] = zz[k];
         }
     }
+    const uint32_t* partial4 = reinterpret_cast<const uint32_t*>(partial);
     // M = best coarse maximum over the streams (NaN keys sort highest and are flagged anyway)
     uint32_t gmax = 0;
     for (int s = gl; s < nentries; s += 16) {
-        const uint32_t hi = (uint32_t)(partial[(size_t)s * N + rr] >> 32);
+        const uint32_t hi = C4 ? (partial4[(size_t)s * N + rr] & C4_KEY_MASK) : (uint32_t)(partial[(size_t)s * N + rr] >> 32);
         gmax = hi > gmax ? hi : gmax;
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(gmax, o, 16); gmax = other > gmax ? other : gmax; }
-    const float thresh = (gmax == KEY_NAN) ? -__builtin_inff() : f32_from_orderable(gmax) - win;       // win = 2 eps of the coarse pass, scaled
+    const bool gnan = C4 ? (gmax == C4_KEY_MASK) : (gmax == KEY_NAN);
+    const float thresh = gnan ? -__builtin_inff() : f32_from_orderable(gmax) - win;       // win = 2 eps of the coarse pass, scaled (+ C4_TRUNC)
 
     Best b;
     best_init(b, 0);
     const int ntiles_total = C >> 5;
     for (int s0 = 0; s0 < nentries; s0 += 16) {
         const int s_mine = s0 + gl;
-        const unsigned long long e = s_mine < nentries ? partial[(size_t)s_mine * N + rr] : 0ull;
+        unsigned long long e = 0ull;
+        if (s_mine < nentries) {
+            if (C4) {       // rebuild the 8-byte form: key in the high word, flag | absolute tile in the low word
+                const uint32_t e4 = partial4[(size_t)s_mine * N + rr];
+                const uint32_t tile = (uint32_t)((s_mine >> 1) * tiles_per_split) + (e4 & C4_TILE_MASK);
+                e = ((unsigned long long)(e4 & C4_KEY_MASK) << 32) | ((e4 & C4_FLAG) ? F16_FLAG : 0u) | tile;
+            } else e = partial[(size_t)s_mine * N + rr];
+        }
         const uint32_t ehi = (uint32_t)(e >> 32);
-        const bool cand = s_mine < nentries && (ehi == KEY_NAN || !(f32_from_orderable(ehi) < thresh));
+        const bool cand = s_mine < nentries && (ehi == (C4 ? C4_KEY_MASK : KEY_NAN) || !(f32_from_orderable(ehi) < thresh));
         uint32_t mask = (uint32_t)((__ballot(cand) >> gsh) & 0xFFFFu);
         while (mask) {
             const int j = __ffs(mask) - 1;
@@ -1092,9 +1113,15 @@ int selftok_vq_finalize_packed(const void* workspace, const float* z, const floa
     const int norm = (flags & 2) ? 0 : 1;
     if (flags & SELFTOK_VQ_F16COARSE) {
         const int ntiles = C >> 5, tps = (ntiles + nsplit - 1) / nsplit;
-        const float win = 2.0f * ((flags & SELFTOK_VQ_F16COARSE1) ? F16_EPS1 : F16_EPS) * F16_SCORE_SCALE;      // must match the main kernel's
-        if (flags & 1) hipLaunchKernelGGL(vq_finalize_f16_kernel<int32_t>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (int32_t*)ids, best, N, C, nsplit, tps, norm, win);
-        else hipLaunchKernelGGL(vq_finalize_f16_kernel<long long>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (long long*)ids, best, N, C, nsplit, tps, norm, win);
+        if (flags & SELFTOK_VQ_F16COARSE1) {
+            const float win = 2.0f * F16_EPS1 * F16_SCORE_SCALE + C4_TRUNC;      // the main kernel's window + the truncation of the 4-byte keys
+            if (flags & 1) hipLaunchKernelGGL((vq_finalize_f16_kernel<int32_t, true>), dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (int32_t*)ids, best, N, C, nsplit, tps, norm, win);
+            else hipLaunchKernelGGL((vq_finalize_f16_kernel<long long, true>), dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (long long*)ids, best, N, C, nsplit, tps, norm, win);
+        } else {
+            const float win = 2.0f * F16_EPS * F16_SCORE_SCALE;                  // must match the main kernel's
+            if (flags & 1) hipLaunchKernelGGL((vq_finalize_f16_kernel<int32_t, false>), dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (int32_t*)ids, best, N, C, nsplit, tps, norm, win);
+            else hipLaunchKernelGGL((vq_finalize_f16_kernel<long long, false>), dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (long long*)ids, best, N, C, nsplit, tps, norm, win);
+        }
         return check_launch("vq_finalize_f16_kernel");
     }
     if (flags & 1) hipLaunchKernelGGL(vq_finalize_packed_kernel<int32_t>, dim3((N + 15) / 16), dim3(256), 0, stream, partial, z, packed, (int32_t*)ids, best, N, 2 * nsplit, norm);
