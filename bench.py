@@ -152,12 +152,34 @@ def cpu_baseline(sd_gpu, vsd_gpu, cfg, K):
             clib.vq_encode_mt(z, cb)
             vq_mt[f"N{n}_rows_per_s"] = round(n / (time.perf_counter() - t0), 1)
     total = t_enc + 25.0 * t_2 + t_vd
+    # the same work through the build's C ABI compiled for the CPU (oracle/libselftok_cpu.so) + torch-CPU GEMMs: the product's own host
+    # modules with every kernel call going to the CPU twin (SURVEY 8d's "libselftok_cpu.so + torch-CPU GEMMs"; oracle/twin_host.py)
+    twin = None
+    try:
+        from oracle import twin_host as TH
+        with torch.no_grad(), TH.on_cpu_twin():
+            enc, dit, flow, ktab = TH.build(sd, K)
+            x0 = OM.process_in(OM.vae_encode_mean(vsd, images.to(torch.bfloat16))).to(torch.float32)
+            t0 = time.perf_counter()
+            _, ids_t = enc(x0, d=None)
+            t_tok = time.perf_counter() - t0
+            ehs = enc.codes_ln(ids_t)
+            t0 = time.perf_counter()
+            flow.p_sample_loop(dit, noise, ehs, ktab, context_see_xt=True, max_steps=1)
+            t_step = time.perf_counter() - t0
+        twin = {"kind": "port (include/selftok_hip.h compiled for the CPU: oracle/libselftok_cpu.so, scalar C + OpenMP, + torch-CPU GEMMs)",
+                "tokenizer_encode_B1_s": round(t_tok, 2), "one_decode_step_B1_s": round(t_step, 2),
+                "ids_equal_to_the_torch_port": int((ids_t.numpy() == ids.numpy()).sum()), "of": int(ids.numel()),
+                "note": "slower than the torch port above (the twin's attention / LayerNorm kernels are checkers, not tuned CPU code): the torch port stays "
+                        "the baseline `value`; both are this build's restatement, not the reference"}
+    except Exception as e:                        # noqa: BLE001 -- a baseline leg must never take the bench line down
+        twin = {"error": f"{type(e).__name__}: {e}"[:300]}
     return {"value": round(1.0 / total, 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"B=1 256x256 K={K}: full encode {t_enc:.2f}s + 2 of 50 decode steps {t_2:.2f}s (x25 extrapolated) "
                       f"+ VAE decode {t_vd:.2f}s on {torch.get_num_threads()} host threads; oracle/ = lean restatement "
                       "(no redundant encoder passes / table recomputes of the reference)",
             "encode_images_per_s": {"B1": round(1.0 / t_enc, 3), "B8": round(8.0 / t_enc8, 3), "B64": round(64.0 / t_enc64, 3)},
-            "vq_lookup_scalar_C_1_thread": vq, "vq_lookup_scalar_C_all_threads": vq_mt,
+            "vq_lookup_scalar_C_1_thread": vq, "vq_lookup_scalar_C_all_threads": vq_mt, "twin": twin,
             "kinds": "every figure here is the build's own CPU restatement (oracle/: torch-CPU GEMMs / convolutions + oracle/libselftok_oracle.so for the "
                      "VQ lookup) on this box's host cores -- 'port'; the reference itself was timed only in the build container (cpu_baseline_reference_survey)"}
 
