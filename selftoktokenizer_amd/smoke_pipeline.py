@@ -15,6 +15,16 @@ def run():
     tokens = pipe.encoding(synth.synthetic_images(1), device="cuda")
     assert tuple(tokens.shape) == (1, 512) and tokens.dtype == torch.int64
     assert int(tokens.min()) >= 0 and int(tokens.max()) < 32768
+    # the exact-order VAE encoder (default at 256 x 256): latents AND token ids of image 0 equal the REFERENCE pipeline's own run, bit for bit
+    import os
+    import numpy as np
+    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "pipeline_b16.npz")
+    if os.path.exists(gold) and pipe.vae.mode == "exact":
+        g = np.load(gold)
+        x0 = pipe.encode_latents(synth.synthetic_images(1, device="cuda")).cpu()
+        assert torch.equal(x0, torch.from_numpy(g["x0_bf16"][:1]).view(torch.bfloat16).float()), "VAE latents differ from the reference pipeline's"
+        assert np.array_equal(tokens.cpu().numpy(), g["tokens"][:1].astype(np.int64)), "token ids from pixels differ from the reference pipeline's"
+        print("[smoke] exact-order VAE encoder: latents bit-equal to the reference pipeline's run, 512 / 512 token ids from pixels")
     rec = pipe.decoding(tokens.cpu().numpy(), device="cuda", noise=synth.synthetic_noise(1), max_steps=2)
     assert tuple(rec.shape) == (1, 3, 256, 256) and rec.dtype == torch.bfloat16
     assert bool(torch.isfinite(rec.float()).all()) and float(rec.min()) >= 0.0 and float(rec.max()) <= 1.0
