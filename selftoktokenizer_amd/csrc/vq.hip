@@ -690,7 +690,8 @@ __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z
 
 // exact resolution of the coarse pass: see the comment above vq_f16_kernel.  16 lanes per row.
 template <typename IdT, bool C4>       // C4: 4-byte candidates of the one-MFMA pass
-__global__ __launch_bounds__(256) void vq_finalize_f16_kernel(const unsigned long long* __restrict__ partial, const float* __restrict__ z,
+// 8 waves per SIMD (<= 64 VGPRs): the kernel is a chain of dependent loads per row; all 2048 workgroups of N = 32768 resident at once
+__global__ __launch_bounds__(256, 8) void vq_finalize_f16_kernel(const unsigned long long* __restrict__ partial, const float* __restrict__ z,
                                                               const float* __restrict__ packed, IdT* __restrict__ ids, float* __restrict__ best,
                                                               int N, int C, int nsplit, int tiles_per_split, int normalize, float win)
 {
@@ -747,17 +748,32 @@ __global__ __launch_bounds__(256) void vq_finalize_f16_kernel(const unsigned lon
             int tfirst, tlast;
             if (lo & F16_FLAG) { tfirst = split * tiles_per_split; tlast = tfirst + tiles_per_split; tlast = tlast < ntiles_total ? tlast : ntiles_total; }
             else { tfirst = (int)(lo & 0x7FFFFFFFu); tlast = tfirst + 1; }
-            for (int tile = tfirst; tile < tlast; ++tile) {              // ascending code order per lane: first maximum wins
+            auto score_tile = [&](int tile) {
                 const float* pt = packed + (size_t)tile * 512;
                 float sc = 0.f;
 #pragma unroll
                 for (int k = 0; k < D; ++k) sc = __builtin_fmaf(x[k], pt[packed_offset(i, k)], sc);
-                // candidates are NOT visited in code order (streams come in entry order): on an exact tie, and among NaNs, the lower
-                // code index wins explicitly (torch.argmax: first maximum; a NaN counts as the maximum, first NaN wins)
+                return sc;
+            };
+            // candidates are NOT visited in code order (streams come in entry order): on an exact tie, and among NaNs, the lower
+            // code index wins explicitly (torch.argmax: first maximum; a NaN counts as the maximum, first NaN wins)
+            auto take = [&](float sc, int tile) {
                 const int idx = tile * 32 + i;
                 if (sc != sc) {
                     if (!b.nan || idx < b.i) { b.nan = true; b.v = __builtin_inff(); b.i = idx; }
                 } else if (!b.nan && (sc > b.v || (sc == b.v && idx < b.i))) { b.v = sc; b.i = idx; }
+            };
+            if (tlast - tfirst == 1) take(score_tile(tfirst), tfirst);
+            else {
+                // whole-stream re-scan (the stream's two best tiles are both inside the window; 0.3 % of the rows with the one-MFMA window
+                // on the encoder's features): 64 tiles, each 16 gathered loads + a 16-FMA chain per lane, two tiles' loads in flight.
+                // (Eight in flight cost 160 VGPRs = 3 waves per SIMD: the 2048 workgroups of N = 32768 then run in 2.7 rounds and the
+                // kernel takes 2.7 x a workgroup's latency -- the walk is rare, the residency is not.)
+                for (int tile = tfirst; tile < tlast; tile += 2) {
+                    const float sa = score_tile(tile), sb2 = score_tile(tile + 1 < tlast ? tile + 1 : tile);
+                    take(sa, tile);
+                    if (tile + 1 < tlast) take(sb2, tile + 1);
+                }
             }
         }
     }

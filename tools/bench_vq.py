@@ -8,8 +8,12 @@ cb = W._synth_tensor("encoder.quantizer._codebook.embed", (1, 32768, 16), "cpu")
 pk = ops.vq_pack_codebook(cb)
 # features: synthetic rows, or (argv[1] == "enc") the Q-Former encoder's own features of synthetic images -- their top-1/top-2 gaps set how many
 # candidates the wide window of the one-MFMA pass re-scores
-for n in (512, 32768, 65536, 131072):
-    z = synth.synthetic_vq_rows(n, device="cuda")
+import numpy as np
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "pipeline_b16.npz")
+real = len(sys.argv) > 1 and sys.argv[1] == "enc"
+zg = torch.from_numpy(np.load(GOLD)["z"]).reshape(-1, 16) if real else None      # 8192 features of the reference's own encoder run
+for n in ((32768,) if real else (512, 32768, 65536, 131072)):
+    z = zg.repeat(n // zg.shape[0], 1).cuda() if real else synth.synthetic_vq_rows(n, device="cuda")
     for packed, name, coarse in ((False, "valu", None), (True, "mfma-fp32", False), (True, "f16-coarse(3 MFMAs)+exact", 3), (True, "f16-coarse(1 MFMA)+exact", 1)):
         c = pk if packed else cb
         for _ in range(3):
