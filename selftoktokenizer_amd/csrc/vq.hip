@@ -528,13 +528,22 @@ typedef unsigned vu4 __attribute__((ext_vector_type(4)));
 typedef float vf2 __attribute__((ext_vector_type(2)));
 
 constexpr uint32_t F16_FLAG = 0x80000000u;       // entry.lo bit 31: re-scan the whole stream exactly
-// 4-byte candidates of the one-MFMA pass: truncating the orderable key to its top 21 bits lowers a (2^14-scaled, <= 2^14 + margin) score by
-// less than C4_TRUNC = 2^15 * 2^-12 = 8 scaled units; the finalize widens its window by that much (a truncated maximum and a truncated
-// candidate can each be low by < 8: the candidate test `stored >= stored_max - win` needs win + C4_TRUNC)
-constexpr uint32_t C4_KEY_MASK = 0xFFFFF800u, C4_FLAG = 0x400u, C4_TILE_MASK = 0x3FFu;
-constexpr float C4_TRUNC = 8.0f;
+constexpr uint32_t F16_HAS2 = 0x40000000u;       // entry.lo bit 30 (one-MFMA pass): a second tile of the stream is inside the window, re-score it too
+// 4-byte candidates of the one-MFMA pass: truncating the orderable key to its top 20 bits lowers a (2^14-scaled, < 2^15) score by
+// less than C4_TRUNC scaled units; the finalize widens its window by that much (the candidate test `stored >= stored_max - win` compares
+// two truncated values: the true maximum's stream has stored >= true - C4_TRUNC >= stored_max - win - C4_TRUNC)
+constexpr uint32_t C4_KEY_MASK = 0xFFFFF000u, C4_HAS2 = 0x800u, C4_FLAG = 0x400u, C4_TILE_MASK = 0x3FFu;
+constexpr float C4_KEYTRUNC = 2.0f;       // the scan keys drop 10 mantissa bits of a value < 2^15: < 2^(14 - 23 + 10) = 2
+constexpr float C4_TRUNC = 16.0f;         // the stored 20-bit key drops 12: < 2^(14 - 23 + 12) = 8, doubled as margin for the [2^14, 2^15) binade
 
 SELFTOK_STAMP_DECL(tune_stamp_vq_f16);
+
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 template <int RT, int NM>       // NM = MFMAs per 32 x 32 scores: 3 (hi*hi + hi*lo + lo*hi, window 2^-17) or 1 (hi*hi, window F16_EPS1)
 __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z, const float* __restrict__ packed,
@@ -598,8 +607,14 @@ __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z
 
     float m1[RT], m2[RT];
     int t1[RT];
+    // one-MFMA pass: the three largest tile maxima of the stream as sortable integer keys, (fp32 bits of max(tile maximum, 0)) with the low
+    // 10 mantissa bits replaced by 1023 - (tile - tile_first): v_max_u32 + two v_med3_u32 per tile keep the top three (value, tile)
+    // pairs, the earlier tile ahead on equal values.  A second tile inside the window is then RE-SCORED (its index goes to the finalize),
+    // only a third one forces the whole-stream walk.  Clamping at 0 costs nothing (it rides in the last v_max3 of the tile maximum);
+    // a stream whose best score is <= 0 is flagged for the exact walk.
+    uint32_t k1[RT], k2[RT], k3[RT];
 #pragma unroll
-    for (int t = 0; t < RT; ++t) { m1[t] = -__builtin_inff(); m2[t] = -__builtin_inff(); t1[t] = tile_first; }
+    for (int t = 0; t < RT; ++t) { m1[t] = -__builtin_inff(); m2[t] = -__builtin_inff(); t1[t] = tile_first; k1[t] = 0u; k2[t] = 0u; k3[t] = 0u; }
 
     auto stage = [&](int chunk, int buf) {      // this wave's share: pieces wave, wave+4, ... of the 2*M_CH 1-KiB (tile, plane) pieces
 #pragma unroll
@@ -652,11 +667,19 @@ __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z
                         const float a0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]), a1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
                         const float a2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]), a3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
                         const float a4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
-                        const float mt = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), __builtin_fmaxf(__builtin_fmaxf(a3, a4), acc[15]));
-                        m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], mt);
-                        const bool g = mt > m1[t];                      // strict: the earliest tile holding the maximum is t1
-                        m1[t] = __builtin_fmaxf(m1[t], mt);
-                        t1[t] = g ? tile : t1[t];
+                        if (NM == 1) {
+                            const float mt0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), __builtin_fmaxf(__builtin_fmaxf(a3, a4), acc[15])), 0.f);
+                            const uint32_t key = (__float_as_uint(mt0) & ~C4_TILE_MASK) | (uint32_t)(1023 - (base + j));     // v_and_or_b32
+                            k3[t] = umed3(k2[t], k3[t], key);
+                            k2[t] = umed3(k1[t], k2[t], key);
+                            k1[t] = key > k1[t] ? key : k1[t];
+                        } else {
+                            const float mt = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), __builtin_fmaxf(__builtin_fmaxf(a3, a4), acc[15]));
+                            m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], mt);
+                            const bool g = mt > m1[t];                      // strict: the earliest tile holding the maximum is t1
+                            m1[t] = __builtin_fmaxf(m1[t], mt);
+                            t1[t] = g ? tile : t1[t];
+                        }
                     }
                 }
             }
@@ -669,19 +692,30 @@ __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z
     const float win = 2.0f * (NM == 1 ? F16_EPS1 : F16_EPS) * F16_SCORE_SCALE;
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-        const bool flag = bad || !(m2[t] < m1[t] - win);                // also true when m1 is NaN
-        float v = m1[t];
-        if (v == 0.0f) v = 0.0f;
-        // a row / code book with non-finite or out-of-range values: v_max3 skipped the NaNs, m1 means nothing -> every stream of
-        // the row must be re-scanned exactly, which the NaN key (sorts highest, opens the window completely) forces
-        const uint32_t hi = (bad || v != v) ? KEY_NAN : f32_orderable(v);
         const int r = row0 + t * 32 + col;
         if (NM == 1) {
-            // 4-byte candidate (the one-MFMA window is 34 scaled score units wide, a key truncated to 21 bits moves by < 4 of them):
-            // [31:11] top 21 bits of the orderable key, [10] flag, [9:0] winning tile relative to the split (tiles_per_split <= 1024)
-            const uint32_t e = (hi & C4_KEY_MASK) | (flag ? C4_FLAG : 0u) | (uint32_t)(t1[t] - tile_first);
-            if (r < N) reinterpret_cast<uint32_t*>(partial)[((size_t)blockIdx.y * 2 + half) * N + r] = e;
+            // values carry a truncation of < C4_KEYTRUNC (10 mantissa bits of a 2^14-scaled score < 2^15): "inside the window" is tested
+            // conservatively.  4-byte candidate: [31:12] top 20 bits of the orderable key of m1, [11] a second tile is inside the window (its
+            // index goes to the side array), [10] a third one is too / bad input / best <= 0: walk the whole stream, [9:0] best tile
+            // relative to the split (tiles_per_split <= 1024)
+            const float v1 = __uint_as_float(k1[t] & ~C4_TILE_MASK), v2 = __uint_as_float(k2[t] & ~C4_TILE_MASK), v3 = __uint_as_float(k3[t] & ~C4_TILE_MASK);
+            const bool has2 = !(v2 < v1 - win - C4_KEYTRUNC) && (1023u - (k2[t] & C4_TILE_MASK)) < (uint32_t)nt;     // k2 == 0: no second tile seen
+            const bool walk = bad || !(v3 < v1 - win - C4_KEYTRUNC) || !(v1 > 0.f);
+            const uint32_t rel1 = 1023u - (k1[t] & C4_TILE_MASK), rel2 = 1023u - (k2[t] & C4_TILE_MASK);
+            const uint32_t hi = bad ? KEY_NAN : f32_orderable(v1);
+            const uint32_t e = (hi & C4_KEY_MASK) | (has2 ? C4_HAS2 : 0u) | (walk ? C4_FLAG : 0u) | rel1;
+            if (r < N) {
+                const size_t at = ((size_t)blockIdx.y * 2 + half) * N + r;
+                reinterpret_cast<uint32_t*>(partial)[at] = e;
+                if (has2 && !walk) reinterpret_cast<uint32_t*>(partial)[(size_t)128 * N + at] = rel2;      // second half of the workspace, sparse
+            }
         } else {
+            const bool flag = bad || !(m2[t] < m1[t] - win);                // also true when m1 is NaN
+            float v = m1[t];
+            if (v == 0.0f) v = 0.0f;
+            // a row / code book with non-finite or out-of-range values: v_max3 skipped the NaNs, m1 means nothing -> every stream of
+            // the row must be re-scanned exactly, which the NaN key (sorts highest, opens the window completely) forces
+            const uint32_t hi = (bad || v != v) ? KEY_NAN : f32_orderable(v);
             const uint32_t lo = (flag ? F16_FLAG : 0u) | (uint32_t)t1[t];
             if (r < N) partial[((size_t)blockIdx.y * 2 + half) * N + r] = ((unsigned long long)hi << 32) | lo;
         }
@@ -730,10 +764,10 @@ __global__ __launch_bounds__(256, 8) void vq_finalize_f16_kernel(const unsigned 
         const int s_mine = s0 + gl;
         unsigned long long e = 0ull;
         if (s_mine < nentries) {
-            if (C4) {       // rebuild the 8-byte form: key in the high word, flag | absolute tile in the low word
+            if (C4) {       // rebuild the 8-byte form: key in the high word; flag | has-second | absolute tile in the low word
                 const uint32_t e4 = partial4[(size_t)s_mine * N + rr];
                 const uint32_t tile = (uint32_t)((s_mine >> 1) * tiles_per_split) + (e4 & C4_TILE_MASK);
-                e = ((unsigned long long)(e4 & C4_KEY_MASK) << 32) | ((e4 & C4_FLAG) ? F16_FLAG : 0u) | tile;
+                e = ((unsigned long long)(e4 & C4_KEY_MASK) << 32) | ((e4 & C4_FLAG) ? F16_FLAG : 0u) | ((e4 & C4_HAS2) ? F16_HAS2 : 0u) | tile;
             } else e = partial[(size_t)s_mine * N + rr];
         }
         const uint32_t ehi = (uint32_t)(e >> 32);
@@ -747,7 +781,9 @@ __global__ __launch_bounds__(256, 8) void vq_finalize_f16_kernel(const unsigned 
             const int i = (gl & 3) + 8 * (gl >> 2) + 4 * half;           // this lane's code inside a tile of that half
             int tfirst, tlast;
             if (lo & F16_FLAG) { tfirst = split * tiles_per_split; tlast = tfirst + tiles_per_split; tlast = tlast < ntiles_total ? tlast : ntiles_total; }
-            else { tfirst = (int)(lo & 0x7FFFFFFFu); tlast = tfirst + 1; }
+            else { tfirst = (int)(lo & 0x3FFFFFFFu); tlast = tfirst + 1; }
+            int tsecond = -1;                                            // one-MFMA pass: the stream's second tile inside the window
+            if (C4 && (lo & F16_HAS2) && !(lo & F16_FLAG)) tsecond = split * tiles_per_split + (int)partial4[(size_t)128 * N + (size_t)stream * N + rr];
             auto score_tile = [&](int tile) {
                 const float* pt = packed + (size_t)tile * 512;
                 float sc = 0.f;
@@ -763,8 +799,11 @@ __global__ __launch_bounds__(256, 8) void vq_finalize_f16_kernel(const unsigned 
                     if (!b.nan || idx < b.i) { b.nan = true; b.v = __builtin_inff(); b.i = idx; }
                 } else if (!b.nan && (sc > b.v || (sc == b.v && idx < b.i))) { b.v = sc; b.i = idx; }
             };
-            if (tlast - tfirst == 1) take(score_tile(tfirst), tfirst);
-            else {
+            if (tlast - tfirst == 1) {
+                const float sa = score_tile(tfirst), sb2 = score_tile(tsecond >= 0 ? tsecond : tfirst);
+                take(sa, tfirst);
+                if (tsecond >= 0) take(sb2, tsecond);
+            } else {
                 // whole-stream re-scan (the stream's two best tiles are both inside the window; 0.3 % of the rows with the one-MFMA window
                 // on the encoder's features): 64 tiles, each 16 gathered loads + a 16-FMA chain per lane, two tiles' loads in flight.
                 // (Eight in flight cost 160 VGPRs = 3 waves per SIMD: the 2048 workgroups of N = 32768 then run in 2.7 rounds and the
@@ -1074,6 +1113,7 @@ int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, vo
         while (row_blocks * split < 512 && split < 64 && ntiles / (split * 2) >= 8) split *= 2;
         if (split > 64) split = 64;
         { const int f_split = (flags >> 16) & 0xFF; if (f_split > 0 && f_split <= 64) split = f_split; }
+        if ((flags & SELFTOK_VQ_F16COARSE1) && (ntiles + split - 1) / split > 1024) split = (ntiles + 1023) / 1024;      // 10-bit tile fields
         const int tps = (ntiles + split - 1) / split;
         split = (ntiles + tps - 1) / tps;
         *nsplit_out = split;

@@ -126,11 +126,15 @@ def test_vq_coarse_pass_error_bound_and_adversarial_near_ties(cb):
     for a, b in ((5, 9), (5, 5 + 32 * 3), (7, 7 + 2048 * 5), (100, 100 + 4), (31, 32)):
         for t in (1e-5, 1e-4, 5e-4, 9e-4, 2e-3):
             rows.append(torch.nn.functional.normalize(cb[a] + cb[b], dim=-1) + t * cb[a])
+    # three (four) codes of ONE stream and wave half in different tiles, all inside the window: second-tile re-score and whole-stream walk
+    for trio in ((5, 5 + 32, 5 + 64), (9, 9 + 32 * 7, 9 + 32 * 40, 9 + 32 * 63), (2048 + 17, 2048 + 17 + 32 * 2, 2048 + 17 + 32 * 9)):
+        for t in (0.0, 2e-4, 1e-3):
+            rows.append(torch.nn.functional.normalize(sum(cb[c] for c in trio), dim=-1) + t * cb[trio[-1]])
     z = torch.stack(rows)
     ids_ref, best_ref = clib.vq_encode(z.numpy(), cb.numpy())
     pk = ops.vq_pack_codebook(cb.cuda())
     for nm in (3, 1):
-        for sp in (0, 4, 16):
+        for sp in (0, 1, 4, 16):
             ids, best = ops.vq_encode(z.cuda(), pk, packed=True, return_best=True, coarse=nm, split=sp)
             np.testing.assert_array_equal(ids.cpu().numpy(), ids_ref, err_msg=f"near-window rows, split={sp} mfmas={nm}")
             np.testing.assert_array_equal(best.cpu().numpy().view(np.uint32), best_ref.view(np.uint32))
