@@ -649,6 +649,35 @@ __global__ __launch_bounds__(256) void vq_f16_kernel(const float* __restrict__ z
             // 148 VGPRs and 95 us, against 92 - 95 us for the loop below; the kernel is not issue-bound: its workgroups keep the matrix
             // pipe ~87 % busy in SHADER cycles while the chip runs them at 1.5 - 2.0 GHz under this load (tools/sweep_vq_f16.py clock
             // stamps, profiles/r3_vq_f16_sweep.txt).  Kept: this loop.)
+            if (NM == 1 && base + M_CH <= nt) {
+                // one-MFMA pass, full chunk: straight-line code -- the chunk's 8 code fragments are read from LDS up front, and the MFMA of
+                // unit u + 1 (unit = tile x row block) is issued BEFORE the scan of unit u (two accumulator sets): the scan's 13 VALU ops
+                // hide the next MFMA's latency inside the wave instead of leaving it to the other three waves of the SIMD (the branchy
+                // per-tile loop below serialised read -> MFMA -> 12 wait states -> scan per unit: 98 cycles per unit for 32 + 52 of work)
+                vh8 ev[M_CH];
+#pragma unroll
+                for (int j = 0; j < M_CH; ++j) ev[j] = *reinterpret_cast<const vh8*>(&s_tile[buf][j * 2048 + lane * 16]);
+                uint32_t maskv;
+                asm("v_mov_b32 %0, 0xfffffc00" : "=v"(maskv));          // in a VGPR: lets (bits & mask) | tile-code be ONE v_and_or_b32
+                auto scan1 = [&](const f32x16& acc, int t, int rel) {
+                    const float a0 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]), a1 = __builtin_fmaxf(__builtin_fmaxf(acc[3], acc[4]), acc[5]);
+                    const float a2 = __builtin_fmaxf(__builtin_fmaxf(acc[6], acc[7]), acc[8]), a3 = __builtin_fmaxf(__builtin_fmaxf(acc[9], acc[10]), acc[11]);
+                    const float a4 = __builtin_fmaxf(__builtin_fmaxf(acc[12], acc[13]), acc[14]);
+                    const float mt0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), __builtin_fmaxf(__builtin_fmaxf(a3, a4), acc[15])), 0.f);
+                    const uint32_t key = (__float_as_uint(mt0) & maskv) | (uint32_t)(1023 - rel);
+                    k3[t] = umed3(k2[t], k3[t], key);
+                    k2[t] = umed3(k1[t], k2[t], key);
+                    k1[t] = key > k1[t] ? key : k1[t];
+                };
+                f32x16 accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(ev[0], __builtin_bit_cast(vh8, x0[0]), zero, 0, 0, 0), accB;
+#pragma unroll
+                for (int u = 0; u < M_CH * RT; u += 2) {
+                    { const int un = u + 1; accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(ev[un / RT], __builtin_bit_cast(vh8, x0[un % RT]), zero, 0, 0, 0); }
+                    scan1(accA, u % RT, base + u / RT);
+                    if (u + 2 < M_CH * RT) { const int un = u + 2; accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(ev[un / RT], __builtin_bit_cast(vh8, x0[un % RT]), zero, 0, 0, 0); }
+                    scan1(accB, (u + 1) % RT, base + (u + 1) / RT);
+                }
+            } else
 #pragma unroll
             for (int j = 0; j < M_CH; ++j) {
                 if (base + j < nt) {                                   // wave-uniform
