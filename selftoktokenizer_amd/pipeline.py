@@ -84,9 +84,8 @@ class _Flow(FlowSchedule):
         """[K] (or batch-uniform [B,K]) visibility pattern -> (device int64 index of the visible tokens, their positions as numpy)"""
         sm = torch.as_tensor(super_mask).cpu()
         if sm.dim() == 2:
-            if not bool((sm == sm[:1]).all()):
-                raise NotImplementedError("a super_mask that differs between the samples of a batch is not implemented "
-                                          "(decode the samples separately, or pass one [K] pattern)")
+            if not bool((sm == sm[:1]).all()):      # SelftokPipeline._sample splits such a batch into groups of equal pattern before it gets here
+                raise NotImplementedError("p_sample_loop takes ONE visibility pattern per call (decode the samples in groups of equal pattern)")
             sm = sm[0]
         if sm.numel() != K:
             raise ValueError(f"super_mask has {sm.numel()} entries, the tokenizer has K = {K} tokens")
@@ -334,6 +333,20 @@ class SelftokPipeline():
     def _sample(self, xt, ehs, max_steps, uncond_scale, use_graph, prefix_k=None, super_mask=None):
         """the 50-step loop, optionally replayed from a hipGraph captured once per (batch, latent size) -- the loop is
         ~21k kernel launches; at small batch the host cannot issue them as fast as the GPU retires them."""
+        if super_mask is not None:
+            sm = torch.as_tensor(super_mask).cpu()
+            if sm.dim() == 2 and sm.shape[0] == xt.shape[0] and not bool((sm == sm[:1]).all()):
+                # a visibility pattern PER SAMPLE (the reference's `mask * super_mask` with a [B, K] tensor, rectified_flow.py:226-227):
+                # samples are independent, so the batch is decoded in groups of equal pattern (a group's context is gathered once)
+                rows = sm.reshape(sm.shape[0], -1).bool().numpy()
+                out = torch.empty(xt.shape, dtype=torch.float32, device=self.device)
+                seen = {}
+                for b in range(rows.shape[0]):
+                    seen.setdefault(rows[b].tobytes(), []).append(b)
+                for idx in seen.values():
+                    sel = torch.as_tensor(idx)
+                    out[sel.to(self.device)] = self._sample(xt[sel], ehs[sel.to(ehs.device)], max_steps, uncond_scale, use_graph, prefix_k, rows[idx[0]])
+                return out
         if not use_graph:
             return self.flow.p_sample_loop(self.model.model, xt, ehs, self.k_table, context_see_xt=True,
                                            uncond_scale=uncond_scale, max_steps=max_steps, prefix_k=prefix_k, super_mask=super_mask)

@@ -393,8 +393,15 @@ def test_sampler_options_vs_reference(pipe, gemm):
     _, le = pipe.decoding(g["ids"], noise=noise, max_steps=2, super_mask=np.ones(512, bool), return_latent=True)
     _, lf = pipe.decoding(g["ids"], noise=noise, max_steps=2, return_latent=True)
     torch.testing.assert_close(le, lf, rtol=0, atol=2e-5)
-    with pytest.raises(NotImplementedError):
-        pipe.decoding(np.repeat(g["ids"], 2, 0), noise=synth.synthetic_noise(2), max_steps=1, super_mask=np.stack([pre, ~pre]))
+    # a pattern PER SAMPLE: decoded in groups of equal pattern = the samples decoded one by one
+    ids3, noise3 = np.repeat(g["ids"], 3, 0), synth.synthetic_noise(3)
+    masks3 = np.stack([pre, g["super_mask"], pre])
+    _, l3 = pipe.decoding(ids3, noise=noise3, max_steps=2, super_mask=masks3, return_latent=True)
+    for b in range(3):
+        _, l1 = pipe.decoding(ids3[b:b + 1], noise=noise3[b:b + 1], max_steps=2, super_mask=masks3[b], return_latent=True)
+        torch.testing.assert_close(l3[b:b + 1], l1, rtol=0, atol=2e-5)
+    with pytest.raises(NotImplementedError):       # the sampler itself still takes one pattern per call
+        pipe.flow.p_sample_loop(pipe.model.model, noise3[:2], pipe._codes(ids3[:2]), pipe.k_table, max_steps=1, super_mask=np.stack([pre, ~pre]))
     with pytest.raises(ValueError):
         pipe.decoding(g["ids"], noise=noise, max_steps=1, super_mask=np.ones(100, bool))
     # a non-prefix pattern inside a hipGraph capture (the mask is resolved on the host BEFORE the capture)
