@@ -17,6 +17,7 @@
  *               partial sum per ic-block that is added to the total when its 9 taps are done; conv_in (3 channels) is ONE chunk of
  *               27 elements in (kw, kh, ic) order.  The bias is added to the fp32 total, then ONE rounding to bf16.
  *               Checked against F.conv2d on every layer shape of the encoder, B = 1, 2: 0 mismatches in 1e8 outputs.
+ *               (Not modelled: the AMX unit flushes fp32 denormals, DAZ = FTZ = 1; partial sums below 1.2e-38 do not occur here.)
  *  GroupNorm    ATen GroupNormKernelImpl (contiguous NCHW path) runs the AVX2 build of RowwiseMoments (moments_utils.h): 16-element
  *               bf16 vectors split in two 8-lane fp32 halves, Welford over chunks of 16 vectors with FMAs, a binary cascade of
  *               AddMomentsVec, the 8 lanes combined by scalar AddMoments (whose two updates GCC contracts into FMAs),
