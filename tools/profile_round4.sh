@@ -19,4 +19,9 @@ bash "$R/tools/pmc_vq_traffic.sh" > "$O/pmc_vq_traffic.log" 2>&1
 cp "$R/gpurun_out/pmc_vq/vq_traffic.json" "$O/vq_traffic.json"
 SELFTOK_ONE_GPU=1 SELFTOK_DIST_BACKEND=gloo timeout 600 python "$R/bench.py" --gpus 2 --batch 8 $COMMON 2> "$O/dryrun2.err" | grep -o '{"metric.*' > "$O/r4_bench_dryrun_2ranks_gloo_one_gpu.json"
 timeout 900 python "$R/bench.py" --tokens 1024 --steps 1 --warmup 1 --no-cpu-baseline --no-token-check --no-kernel-roofs --no-latency 2>/dev/null | grep -o '{"metric.*' > "$O/r4_bench_config2_k1024.json"
+# where the waves of the two new hot kernels spend their cycles (SQ counters, one PMC pass each, kernel-trace only)
+bash "$R/tools/pmc_sq.sh" xconv xconv_kernel -- python "$R/tools/bench_vae_exact.py" 16 > "$O/pmc_sq_xconv.log" 2>&1
+cp "$R/gpurun_out/pmc_sq_xconv/summary.json" "$O/r4_pmc_sq_xconv.json"
+bash "$R/tools/pmc_sq.sh" vq vq_f16_kernel -- python "$R/tools/pmc_vq.py" 32768 > "$O/pmc_sq_vq.log" 2>&1
+cp "$R/gpurun_out/pmc_sq_vq/summary.json" "$O/r4_pmc_sq_vq.json"
 ls -la "$O"
