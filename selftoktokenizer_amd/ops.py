@@ -653,6 +653,8 @@ def vx_groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, silu_
     _need_cuda(x, gamma, beta, silu_table)
     assert x.dtype == torch.bfloat16 and x.is_contiguous()
     B, C = x.shape[0], x.shape[-1]
+    if B == 0:
+        return (torch.empty_like(x), torch.empty(0, groups, 2, dtype=torch.float32, device=x.device)) if want_stats else torch.empty_like(x)
     HW = x.numel() // (B * C)
     lib = _lib.load()
     nbytes = lib.selftok_vx_groupnorm_workspace_bytes(B, HW, C)
@@ -673,6 +675,8 @@ def vx_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Ten
     B, T, C = q.shape
     lib = _lib.load()
     out = torch.empty_like(q)
+    if B == 0:
+        return out
     ws = torch.empty(lib.selftok_vx_attention_workspace_bytes(B, T, C), dtype=torch.uint8, device=q.device)
     _lib.check(lib.selftok_vx_attention_bf16(_p(q), _p(k), _p(v), _p(out), _p(ws), B, T, C, _stream()), "selftok_vx_attention_bf16")
     return out

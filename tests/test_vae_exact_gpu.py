@@ -127,6 +127,7 @@ def test_encoder_latents_equal_the_reference_pipeline_bit_for_bit():
     flips = int((ids != g["tokens"].astype(np.int64)).sum())
     print("token ids from pixels vs the reference pipeline run:", ids.size - flips, "/", ids.size)
     assert flips == 0
+    assert tuple(pipe.vae.encode_moments(imgs[:0]).shape) == (0, 32, 32, 32)       # empty batch through every exact-order entry
     # batch independence by construction: one image alone, and a batch of 64 whose first 16 are these
     assert torch.equal(pipe.encode_latents(imgs[3:4]), x0[3:4])
     big = pipe.encode_latents(synth.synthetic_images(64, device="cuda"))
