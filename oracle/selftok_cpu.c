@@ -855,6 +855,7 @@ int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const
                            int ksize, int stride, int order, hipStream_t s)
 {
     (void)s;
+    if (B == 0) return SELFTOK_OK;
     if (!x || !w || !bias || !out || B < 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (stride == 2 && ksize != 3)) return fail("vx_conv2d: bad argument");
     if (order == 2 ? (Cin != 3 || ksize != 3 || stride != 1 || residual) : ((order != 0 && order != 3) || Cin % 32 || ldx != Cin || Cout % 32))
         return fail("vx_conv2d: need Cin % 32 == 0, Cout % 32 == 0, order 0 / 2 / 3");
@@ -881,6 +882,7 @@ int selftok_vx_groupnorm_bf16(const void* x, const void* gamma, const void* beta
                               int C, int groups, double eps, hipStream_t s)
 {
     (void)s; (void)workspace;
+    if (B == 0) return SELFTOK_OK;
     if (!x || !gamma || !beta || !out || B < 0 || groups <= 0 || C % groups) return fail("vx_groupnorm: bad argument");
     vx_group_norm_nhwc((const uint16_t*)x, (const uint16_t*)gamma, (const uint16_t*)beta, (uint16_t*)out, B, HW, C, groups, eps, (const uint16_t*)silu_table, stats);
     return SELFTOK_OK;
@@ -906,6 +908,7 @@ size_t selftok_vx_attention_workspace_bytes(int B, int T, int C)
 int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void* out, void* workspace, int B, int T, int C, hipStream_t s)
 {
     (void)s; (void)workspace;
+    if (B == 0) return SELFTOK_OK;
     if (!q || !k || !v || !out || B < 0 || T != 1024 || C % 128) return fail("vx_attention: one head, T == 1024, C % 128 == 0");
     return vx_attention((const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (uint16_t*)out, B, T, C) ? fail("vx_attention") : SELFTOK_OK;
 }

@@ -575,10 +575,10 @@ extern "C" {
 int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int B, int H, int W, int ldx, int Cin, int Cout,
                            int ksize, int stride, int order, hipStream_t stream)
 {
+    if (B == 0) return SELFTOK_OK;                       // empty batch: nothing to do (the pointers of empty tensors may be null)
     if (!x || !w || !bias || !out || B < 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (stride == 2 && ksize != 3)) {
         set_last_error("vx_conv2d: bad argument"); return SELFTOK_EINVAL;
     }
-    if (B == 0) return SELFTOK_OK;
     const int OH = stride == 2 ? H / 2 : H, OW = stride == 2 ? W / 2 : W;
     const long P = (long)B * OH * OW;
     if (order == 2) {
@@ -607,11 +607,11 @@ size_t selftok_vx_groupnorm_workspace_bytes(int B, int HW, int C)
 int selftok_vx_groupnorm_bf16(const void* x, const void* gamma, const void* beta, void* out, void* workspace, const void* silu_table, float* stats, int B, int HW,
                               int C, int groups, double eps, hipStream_t stream)
 {
+    if (B == 0) return SELFTOK_OK;
     const int RP = HW >= 4096 ? 4096 : 1024;
     if (!x || !gamma || !beta || !out || !workspace || B < 0 || groups <= 0 || C % groups || C % 128 || HW % RP || (C / groups) & ((C / groups) - 1) || ((HW / RP) & (HW / RP - 1))) {
         set_last_error("vx_groupnorm: need C % 128 == 0, H*W a multiple of 1024 (of 4096 above 4096), power-of-two channels per group and ranges"); return SELFTOK_EINVAL;
     }
-    if (B == 0) return SELFTOK_OK;
     const int R = HW / RP;
     Mom* nodes = (Mom*)workspace;
     float* scale = (float*)((char*)workspace + (size_t)B * C * R * 8 * sizeof(Mom));
@@ -647,10 +647,10 @@ size_t selftok_vx_attention_workspace_bytes(int B, int T, int C)
 
 int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void* out, void* workspace, int B, int T, int C, hipStream_t stream)
 {
+    if (B == 0) return SELFTOK_OK;
     if (!q || !k || !v || !out || !workspace || B < 0 || T != 1024 || C % 128 || C > 4096) {
         set_last_error("vx_attention: one head, T == 1024 (two kv blocks of 512, the SD3 VAE at 256 x 256), C % 128 == 0"); return SELFTOK_EINVAL;
     }
-    if (B == 0) return SELFTOK_OK;
     float* s = (float*)workspace;
     unsigned short* p = (unsigned short*)((char*)workspace + (size_t)B * T * T * 4);
     unsigned short* vt = p + (size_t)B * T * T;
