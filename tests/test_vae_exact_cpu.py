@@ -128,12 +128,12 @@ def test_encoder_equals_the_reference_pipeline_run_image_0():
 
 
 @pytest.mark.slow
-def test_encoder_equals_the_reference_pipeline_run_images_13_to_15():
-    """three more of the 16 (all 16 were checked when the oracle was written: 0 of 262144 elements differ; the
+def test_encoder_equals_the_reference_pipeline_run_image_15():
+    """one more of the 16 (all 16 were checked when the oracle was written: 0 of 262144 elements differ; the
     GPU suite checks all 16 through the HIP kernels); ~10 s per image on 8 cores"""
     g = np.load(os.path.join(GOLD, "pipeline_b16.npz"))
-    x0 = _encoder_latents(3, first=13)
-    ref = torch.from_numpy(g["x0_bf16"][13:16]).view(torch.bfloat16)
+    x0 = _encoder_latents(1, first=15)
+    ref = torch.from_numpy(g["x0_bf16"][15:16]).view(torch.bfloat16)
     assert int((x0.view(torch.int16) != ref.view(torch.int16)).sum()) == 0
 
 
