@@ -20,7 +20,8 @@
 //                  LDS with coalesced 16-byte loads (one full row per 4 threads), double buffered, one barrier per chunk, the next
 //                  chunk in flight during this chunk's 32 MFMAs per wave; lanes read their row's four 16-byte pieces back with
 //                  ds_read_b128 (XOR-swizzled: rows are 16 banks apart).  A first version had every lane read its own row from
-//                  global memory: 8x the cache-line accesses, 0.595 of the fp32 matrix peak (profiles/r4_vae_exact_bench_first.txt).  Epilogues: bf16(C + bias) [+ residual with its own rounding]; fp32 C * scale (attention scores);
+//                  global memory: 8x the cache-line accesses, 0.595 of the fp32 matrix peak (profiles/r4_vae_exact_bench_first.txt).
+//                  Epilogues: bf16(C + bias) [+ residual with its own rounding]; fp32 C * scale (attention scores);
 //                  a per-row rescale of C at a chunk boundary and bf16(C * rowscale) (the P V product of the flash kernel).
 //   xconv_in       conv_in: 3 input channels = ONE chunk of 27 elements in (kw, kh, ic) order; fp32 VALU FMAs, weights in LDS.
 //   xgn_*          ATen's GroupNorm: Welford over 16-element vectors in 8 fp32 lanes, chunks of 16 vectors, binary cascade,
