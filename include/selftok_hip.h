@@ -188,6 +188,20 @@ int selftok_linear_f16x2_split(const void* a_blk, const void* packed, const floa
 int selftok_linear_f16x2_split_residual(const void* a_blk, const void* packed, const float* bias,
                                         const float* resid, long ldr, const float* gate, long gate_stride_b, long gate_stride_t, int T,
                                         float* out, long ldo, int M, int N, int K, int* overflow, hipStream_t stream);
+/* Small-M forms of the two entry points above (one image: M = 256 image rows / <= 513 context rows -- the reference's own
+ * configs[0] call, SelftokPipeline.py:224-291 with a batch of one).  A 256 x 128 tile grid then has 12 .. 96 work-groups on 256 CUs and
+ * each walks all of K alone; here `ksplit` (2 .. 64, a divisor of K / 32) work-groups share an output tile, each over K / ksplit
+ * consecutive k, their fp32 partial sums go to `workspace` (selftok_linear_f16x2_splitk_workspace_bytes = ksplit M N 4, 16-byte
+ * aligned) and a second launch adds them in ascending k order (deterministic, independent of scheduling) and runs the same
+ * epilogue.  The sum is then rounded at ksplit - 1 more places than the single-pass kernel's: results agree with it to fp32
+ * rounding, not bit for bit (tests/test_gemm_gpu.py; the CPU twin models the order exactly).  ksplit == 1 forwards to the single-pass
+ * entry point (workspace unused). */
+size_t selftok_linear_f16x2_splitk_workspace_bytes(int M, int N, int ksplit);
+int selftok_linear_f16x2_split_k(const void* a_blk, const void* packed, const float* bias, float* out, void* out_blk, long ldo,
+                                 int M, int N, int K, int flags, int ksplit, void* workspace, int* overflow, hipStream_t stream);
+int selftok_linear_f16x2_split_residual_k(const void* a_blk, const void* packed, const float* bias,
+                                          const float* resid, long ldr, const float* gate, long gate_stride_b, long gate_stride_t, int T,
+                                          float* out, long ldo, int M, int N, int K, int ksplit, void* workspace, int* overflow, hipStream_t stream);
 
 /* ---- two-segment attention with implicit prefix-visibility mask ------------------------------
  * Replaces attention(q,k,v,heads,mask)=SDPA with a materialised bool mask (sd3/other_impls.py:37-45,

@@ -553,10 +553,10 @@ static inline float gelu_sig(float x) { const float k0 = 0.7978845608028654f, k1
 /* row m of (a0, a1) against weight row n: separate fp32 accumulators for the high and the two low terms, combined once.  One
  * v_mfma_f32_32x32x16_f16 adds 16 exact fp16 x fp16 products to its fp32 accumulator with ONE rounding: modelled as a double sum of the
  * 16 products (exact: 22-bit products, 16 of them) rounded to fp32 together with the accumulator, k-blocks in ascending order. */
-static float dot_split(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* wp, int n, int K)
+static float dot_split_range(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* wp, int n, int K, int kbeg, int kend)
 {
     float hi = 0.f, lo = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
         double sh = 0.0, s1 = 0.0, s2 = 0.0;
         for (int k = k0; k < k0 + 16; ++k) {
             const double a0 = f16_to_f32(a_hi[k]), a1 = f16_to_f32(a_lo[k]);
@@ -569,8 +569,18 @@ static float dot_split(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_
     }
     return hi + lo * (1.0f / 2048.0f);
 }
-static int linear_core(const float* A, long lda, const uint16_t* a_blk, const void* packed, const float* bias, float* out, uint16_t* out_blk, long ldo,
-                       const float* resid, long ldr, const float* gate, long gsb, long gst, int T, int M, int N, int K, int flags, int* overflow)
+/* ksplit == 1: the single-pass kernel.  ksplit > 1 (selftok_linear_f16x2_split_k): each of the ksplit work-groups of a tile produces
+ * hi + lo 2^-11 over its K / ksplit consecutive k (+ 0 bias), the finish kernel adds those fp32 partials in ascending order */
+static float dot_split(const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* wp, int n, int K, int ksplit)
+{
+    const int span = K / ksplit;
+    float v = dot_split_range(a_hi, a_lo, wp, n, K, 0, span);
+    if (ksplit > 1) v = v + 0.f;                      /* the partial kernel's epilogue adds a zero bias: -0 becomes +0 */
+    for (int s = 1; s < ksplit; ++s) v = v + (dot_split_range(a_hi, a_lo, wp, n, K, s * span, (s + 1) * span) + 0.f);
+    return v;
+}
+static int linear_core_k(const float* A, long lda, const uint16_t* a_blk, const void* packed, const float* bias, float* out, uint16_t* out_blk, long ldo,
+                       const float* resid, long ldr, const float* gate, long gsb, long gst, int T, int M, int N, int K, int flags, int ksplit, int* overflow)
 {
     if (!packed || selftok_linear_f16x2_packed_bytes(N, K) == 0 || M < 0) return fail("linear_f16x2: bad argument (N % 128 == 0, K % 32 == 0)");
     const uint16_t* wp = (const uint16_t*)packed;
@@ -583,7 +593,8 @@ static int linear_core(const float* A, long lda, const uint16_t* a_blk, const vo
             else { ah[k] = a_blk[split_blk_index(m, k, 0, K / 32)]; al[k] = a_blk[split_blk_index(m, k, 1, K / 32)]; }
         }
         for (int n = 0; n < N; ++n) {
-            float v = dot_split(ah, al, wp, n, K) + (bias ? bias[n] : 0.f);
+            float v = dot_split(ah, al, wp, n, K, ksplit);
+            if (bias || ksplit == 1) v = v + (bias ? bias[n] : 0.f);
             if (flags & SELFTOK_LINEAR_GELU) v = gelu_sig(v);
             if (resid) {
                 const float g = gate ? gate[(size_t)(m / T) * gsb + (size_t)(m % T) * gst + n] : 1.0f;
@@ -596,6 +607,11 @@ static int linear_core(const float* A, long lda, const uint16_t* a_blk, const vo
     }
     if (ovf && overflow) *overflow |= ovf;
     return SELFTOK_OK;
+}
+static int linear_core(const float* A, long lda, const uint16_t* a_blk, const void* packed, const float* bias, float* out, uint16_t* out_blk, long ldo,
+                       const float* resid, long ldr, const float* gate, long gsb, long gst, int T, int M, int N, int K, int flags, int* overflow)
+{
+    return linear_core_k(A, lda, a_blk, packed, bias, out, out_blk, ldo, resid, ldr, gate, gsb, gst, T, M, N, K, flags, 1, overflow);
 }
 int selftok_linear_f16x2_f32(const float* A, long lda, const void* packed, const float* bias, float* out, long ldo, int M, int N, int K, int flags, int* overflow, hipStream_t s)
 {
@@ -615,6 +631,25 @@ int selftok_linear_f16x2_split_residual(const void* a_blk, const void* packed, c
     (void)s;
     if (!a_blk || !resid || !out || T <= 0 || K > 6144) return fail("linear_f16x2_split_residual: bad argument");
     return linear_core(NULL, 0, (const uint16_t*)a_blk, packed, bias, out, NULL, ldo, resid, ldr, gate, gsb, gst, T, M, N, K, 0, overflow);
+}
+
+size_t selftok_linear_f16x2_splitk_workspace_bytes(int M, int N, int ksplit) { return (M > 0 && N > 0 && ksplit > 1) ? (size_t)ksplit * M * N * 4 : 0; }
+static int splitk_ok(int K, int ksplit, const void* workspace) { return ksplit >= 2 && ksplit <= 64 && (K / BK) % ksplit == 0 && workspace && !((size_t)workspace & 15); }
+int selftok_linear_f16x2_split_k(const void* a_blk, const void* packed, const float* bias, float* out, void* out_blk, long ldo, int M, int N, int K, int flags,
+                                 int ksplit, void* workspace, int* overflow, hipStream_t s)
+{
+    if (ksplit == 1) return selftok_linear_f16x2_split(a_blk, packed, bias, out, out_blk, ldo, M, N, K, flags, overflow, s);
+    if (M == 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0) return SELFTOK_OK;
+    if (!a_blk || (!out && !out_blk) || K > 6144 || K <= 0 || K % BK || !splitk_ok(K, ksplit, workspace)) return fail("linear_f16x2_split_k: bad argument");
+    return linear_core_k(NULL, 0, (const uint16_t*)a_blk, packed, bias, out, (uint16_t*)out_blk, ldo, NULL, 0, NULL, 0, 0, 1, M, N, K, flags, ksplit, overflow);
+}
+int selftok_linear_f16x2_split_residual_k(const void* a_blk, const void* packed, const float* bias, const float* resid, long ldr, const float* gate, long gsb, long gst, int T,
+                                          float* out, long ldo, int M, int N, int K, int ksplit, void* workspace, int* overflow, hipStream_t s)
+{
+    if (ksplit == 1) return selftok_linear_f16x2_split_residual(a_blk, packed, bias, resid, ldr, gate, gsb, gst, T, out, ldo, M, N, K, overflow, s);
+    if (M == 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0) return SELFTOK_OK;
+    if (!a_blk || !resid || !out || T <= 0 || K > 6144 || K <= 0 || K % BK || !splitk_ok(K, ksplit, workspace)) return fail("linear_f16x2_split_residual_k: bad argument");
+    return linear_core_k(NULL, 0, (const uint16_t*)a_blk, packed, bias, out, NULL, ldo, resid, ldr, gate, gsb, gst, T, M, N, K, 0, ksplit, overflow);
 }
 
 /* ================================================================================================================================

@@ -48,6 +48,9 @@ SIGNATURES = {
     "selftok_split_f16x2_f32": (_i, [_vp, _l, _vp, _l, _i, _vp, _vp]),
     "selftok_linear_f16x2_split": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp, _vp]),
     "selftok_linear_f16x2_split_residual": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _l, _l, _i, _vp, _l, _i, _i, _i, _vp, _vp]),
+    "selftok_linear_f16x2_splitk_workspace_bytes": (_sz, [_i, _i, _i]),
+    "selftok_linear_f16x2_split_k": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "selftok_linear_f16x2_split_residual_k": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _l, _l, _i, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp]),
     "selftok_groupnorm_silu_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "selftok_latent_process_in": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     "selftok_latent_process_out": (_i, [_vp, _vp, _l, _f, _f, _vp]),

@@ -486,6 +486,17 @@ __device__ __forceinline__ HiLo split_pair_scaled(float a, float b)
     return HiLo{__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, l)};
 }
 __device__ __forceinline__ h16x8 as_h8(const u32x4& v) { return __builtin_bit_cast(h16x8, v); }
+// tools/ builds only: what the staging pass would cost if K / V arrived already split (one conversion per pair stands in for the
+// v_perm of a 16-bit transpose; results are hi-only, i.e. wrong in the low bits -- a timing probe, tools/bench_attn.py)
+#if defined(SELFTOK_TUNE) && defined(SELFTOK_ATTN_PRESPLIT_PROBE)
+__device__ __forceinline__ HiLo split_pair_kv(float a, float b)
+{
+    const f32x2 x = {a, b};
+    return HiLo{__builtin_bit_cast(unsigned, __builtin_convertvector(x, h16x2)), 0u};
+}
+#else
+__device__ __forceinline__ HiLo split_pair_kv(float a, float b) { return split_pair(a, b); }
+#endif
 
 __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int* __restrict__ overflow)
 {
@@ -574,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
             for (int e = 0; e < 2; ++e) {
                 u32x4 hi, lo;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const HiLo t_ = split_pair(v[8 * e + 2 * j], v[8 * e + 2 * j + 1]); hi[j] = t_.hi; lo[j] = t_.lo; }
+                for (int j = 0; j < 4; ++j) { const HiLo t_ = split_pair_kv(v[8 * e + 2 * j], v[8 * e + 2 * j + 1]); hi[j] = t_.hi; lo[j] = t_.lo; }
                 const int g = (st_d >> 3) + e;
                 *reinterpret_cast<u32x4*>(base + g * KG_STRIDE + st_key * 16) = hi;
                 *reinterpret_cast<u32x4*>(base + K_PLANE + g * KG_STRIDE + st_key * 16) = lo;
@@ -588,8 +599,8 @@ __global__ __launch_bounds__(256, 2) void attn64_f16x2_kernel(AttnParams P, int*
 #pragma unroll
             for (int i = 0; i < 4; ++i) {              // d = st_d + i  ->  d' = (d&3)*16 + d/4 = i*16 + st_d/4
                 u32x2 hi, lo;
-                { const HiLo t_ = split_pair(v[0][i], v[1][i]); hi[0] = t_.hi; lo[0] = t_.lo; }
-                { const HiLo t_ = split_pair(v[2][i], v[3][i]); hi[1] = t_.hi; lo[1] = t_.lo; }
+                { const HiLo t_ = split_pair_kv(v[0][i], v[1][i]); hi[0] = t_.hi; lo[0] = t_.lo; }
+                { const HiLo t_ = split_pair_kv(v[2][i], v[3][i]); hi[1] = t_.hi; lo[1] = t_.lo; }
                 const int dp = i * 16 + (st_d >> 2);
                 *reinterpret_cast<u32x2*>(vb + dp * 16) = hi;
                 *reinterpret_cast<u32x2*>(vb + V_PLANE + dp * 16) = lo;

@@ -363,12 +363,16 @@ __device__ __forceinline__ void lds_dma16(const void* base, unsigned voff, unsig
 // fp32 operations, exactly as residual_ln_mod_kernel performs them on the stored y: same bits, one tensor round trip less.
 struct ResArgs { const float* resid; long ldr; const float* gate; long gsb, gst; int T; };
 
-template <int ACT, int OSPLIT, int PP = 1, int ABL = 0, int RES = 0>
+// SK = 1 (small M: a 256-row tile grid has 12 .. 96 work-groups for this model's Linears at one image): gridDim.y work-groups share an
+// output tile, each over K / gridDim.y consecutive k-tiles, and write their raw partial sums (no bias) to plane blockIdx.y of a
+// [gridDim.y][M][ldo] fp32 workspace (`out`); splitk_finish_kernel adds the planes in ascending order and runs the epilogue.
+template <int ACT, int OSPLIT, int PP = 1, int ABL = 0, int RES = 0, int SK = 0>
 __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16* __restrict__ Ablk,
                                                                   const _Float16* __restrict__ Wp, const float* __restrict__ bias,
                                                                   float* __restrict__ out, _Float16* __restrict__ oblk, long ldo,
                                                                   int M, int N, int K, int* __restrict__ overflow, int mblocks, int nblocks, ResArgs res)
 {
+    static_assert(!SK || (ACT == 0 && OSPLIT == 0 && RES == 0), "a split-K partial has no epilogue");
     __shared__ __attribute__((aligned(16))) unsigned char smem[P_LDS_BYTES];
     unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, rt0 = 0;
     if (ABL & 2048) { tk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
@@ -390,7 +394,10 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
         nb = in / gsz;
     }
     const int m0 = mb * BM, n0 = nb * BN;
-    const int KT = K / BK, KL = KT - 1;
+    const int KTA = K / BK;                                         // k-tiles of the operands (their strides)
+    const int KT = SK ? KTA / (int)gridDim.y : KTA, KL = KT - 1;    // k-tiles of this work-group
+    const int kt_off = SK ? (int)blockIdx.y * KT : 0;
+    if (SK) out += (size_t)blockIdx.y * M * ldo;
 
     // ---- DMA maps: wave w moves rows 16w..16w+15 and 128+16w.. of both planes (4 instructions) and 2 KiB of the weight tile.
     // Every source address is (uniform 64-bit base in SGPRs) + (per-lane 32-bit offset that never changes) and every LDS
@@ -403,8 +410,8 @@ __global__ __launch_bounds__(512, 2) void linear_f16x2_pre_kernel(const _Float16
     rb0 = rb0 < rb_last ? rb0 : rb_last;
     rb1 = rb1 < rb_last ? rb1 : rb_last;
     // chunk (row block rb, k-tile kt, plane p) starts at ((rb KT + kt) 2 + p) KiB
-    const unsigned char* const a_base[2] = {(const unsigned char*)Ablk + (size_t)rb0 * KT * 2048, (const unsigned char*)Ablk + (size_t)rb1 * KT * 2048};
-    const unsigned char* const w_base = (const unsigned char*)(Wp + (size_t)nb * KT * (W_BYTES / 2) + (size_t)wave * 512);
+    const unsigned char* const a_base[2] = {(const unsigned char*)Ablk + ((size_t)rb0 * KTA + kt_off) * 2048, (const unsigned char*)Ablk + ((size_t)rb1 * KTA + kt_off) * 2048};
+    const unsigned char* const w_base = (const unsigned char*)(Wp + ((size_t)nb * KTA + kt_off) * (W_BYTES / 2) + (size_t)wave * 512);
     const unsigned w_off = lane * 16;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     auto dma_a = [&](int kt, int stage) {
@@ -671,6 +678,81 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     if (!(mx < F16_MAX) && overflow) atomicOr(overflow, 1);
 }
 
+// Second launch of a split-K Linear: v = sum_s partial[s] (planes in ascending order: deterministic) + bias, then the epilogue of
+// linear_f16x2_pre_kernel, operation for operation -- GELU, the split-activation output for the next Linear, or the fused residual
+// update.  One thread per (row, 8 consecutive columns): 16-byte loads per plane, one 16-byte store per fp16 plane or two float4.
+template <int ACT, int OSPLIT, int RES>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, int S, const float* __restrict__ bias,
+                                                            float* __restrict__ out, _Float16* __restrict__ oblk, long ldo,
+                                                            int M, int N, int* __restrict__ overflow, ResArgs res)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n8 = N >> 3;
+    if (idx >= (long)M * n8) return;
+    const int row = (int)(idx / n8), col = (int)(idx - (long)row * n8) << 3;
+    const float* p = ws + (size_t)row * N + col;
+    const size_t plane = (size_t)M * N;
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    for (int s_ = 1; s_ < S; ++s_) {
+        const float4 c = *reinterpret_cast<const float4*>(p + s_ * plane), d = *reinterpret_cast<const float4*>(p + s_ * plane + 4);
+        a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+        b.x += d.x; b.y += d.y; b.z += d.z; b.w += d.w;
+    }
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (ACT == 1) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = gelu_tanh_f(v[c]);
+    }
+    float chk = 0.f;
+    if (OSPLIT) {
+        f16x4 h0, l0, h1, l1;
+        split4(make_float4(opaque_f32(v[0]), opaque_f32(v[1]), opaque_f32(v[2]), opaque_f32(v[3])), h0, l0);
+        split4(make_float4(opaque_f32(v[4]), opaque_f32(v[5]), opaque_f32(v[6]), opaque_f32(v[7])), h1, l1);
+        const f16x8 h = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]}, l = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) chk = __builtin_fmaf((float)h[c], 0.f, chk);
+        *reinterpret_cast<f16x8*>(oblk + split_blk_index(row, col, 0, N / 32)) = h;
+        *reinterpret_cast<f16x8*>(oblk + split_blk_index(row, col, 1, N / 32)) = l;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) chk = __builtin_fmaf(v[c], 0.f, chk);
+        if (RES) {
+            const float* rp = res.resid + (size_t)row * res.ldr + col;
+            const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+            const float r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            if (res.gate) {
+                const int bb = row / res.T, t = row - bb * res.T;
+                const float* gp = res.gate + bb * res.gsb + t * res.gst + col;
+                const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+                const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = r[c] + g[c] * v[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] += r[c];
+            }
+        }
+        float* op = out + (size_t)row * ldo + col;
+        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    if (overflow && chk != 0.f) atomicOr(overflow, 1);
+}
+
+// first launch of a split-K Linear: the partial planes
+static int launch_splitk_partials(const void* a_blk, const void* packed, float* ws, int M, int N, int K, int ksplit, int* overflow, hipStream_t stream)
+{
+    const int mblocks = (M + BM - 1) / BM, nblocks = N / BN;
+    hipLaunchKernelGGL((linear_f16x2_pre_kernel<0, 0, 1, 0, 0, 1>), dim3((unsigned)(mblocks * nblocks), (unsigned)ksplit), dim3(512), 0, stream,
+                       (const _Float16*)a_blk, (const _Float16*)packed, (const float*)nullptr, ws, (_Float16*)nullptr, (long)N,
+                       M, N, K, overflow, mblocks, nblocks, ResArgs{});
+    return check_launch("linear_f16x2_pre_kernel(split-K partials)");
+}
+
 }  // namespace selftok
 
 using namespace selftok;
@@ -779,6 +861,63 @@ int selftok_linear_f16x2_split_residual(const void* a_blk, const void* packed, c
                        (const _Float16*)a_blk, (const _Float16*)packed, bias, out, (_Float16*)nullptr, ldo,
                        M, N, K, overflow, mblocks, nblocks, ResArgs{resid, ldr, gate, gate_stride_b, gate_stride_t, T});
     return check_launch("linear_f16x2_pre_kernel(residual)");
+}
+
+size_t selftok_linear_f16x2_splitk_workspace_bytes(int M, int N, int ksplit)
+{
+    if (M <= 0 || N <= 0 || ksplit <= 1) return 0;
+    return (size_t)ksplit * M * N * sizeof(float);
+}
+
+static bool splitk_ok(int K, int ksplit, const void* workspace)
+{
+    return ksplit >= 2 && ksplit <= 64 && (K / BK) % ksplit == 0 && workspace && !((size_t)workspace & 15);
+}
+
+int selftok_linear_f16x2_split_k(const void* a_blk, const void* packed, const float* bias, float* out, void* out_blk, long ldo,
+                                 int M, int N, int K, int flags, int ksplit, void* workspace, int* overflow, hipStream_t stream)
+{
+    if (ksplit == 1) return selftok_linear_f16x2_split(a_blk, packed, bias, out, out_blk, ldo, M, N, K, flags, overflow, stream);
+    if (M < 0 || N <= 0 || K <= 0 || N % BN || K % BK) { set_last_error("linear_f16x2_split_k: need N % 128 == 0 and K % 32 == 0"); return SELFTOK_EINVAL; }
+    if (M == 0) return SELFTOK_OK;
+    const bool osplit = out_blk != nullptr;
+    if (!a_blk || !packed || ((size_t)a_blk & 15) || ((size_t)out & 15) || ((size_t)out_blk & 15) || (bias && ((size_t)bias & 15))
+        || (osplit ? out != nullptr : (!out || ldo < N || (ldo & 3))) || !splitk_ok(K, ksplit, workspace)) {
+        set_last_error("linear_f16x2_split_k: bad pointers/strides (as linear_f16x2_split), or ksplit not in 2..64 / not a divisor of K / 32, or no 16-byte aligned workspace");
+        return SELFTOK_EINVAL;
+    }
+    float* ws = (float*)workspace;
+    if (int rc = launch_splitk_partials(a_blk, packed, ws, M, N, K, ksplit, overflow, stream)) return rc;
+    const long n = (long)M * (N / 8);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    _Float16* ob = (_Float16*)out_blk;
+#define FIN_LAUNCH(ACT, OS) hipLaunchKernelGGL((splitk_finish_kernel<ACT, OS, 0>), grid, dim3(256), 0, stream, (const float*)ws, ksplit, bias, out, ob, ldo, M, N, overflow, ResArgs{})
+    if (flags & SELFTOK_LINEAR_GELU) { if (osplit) FIN_LAUNCH(1, 1); else FIN_LAUNCH(1, 0); }
+    else { if (osplit) FIN_LAUNCH(0, 1); else FIN_LAUNCH(0, 0); }
+#undef FIN_LAUNCH
+    return check_launch("splitk_finish_kernel");
+}
+
+int selftok_linear_f16x2_split_residual_k(const void* a_blk, const void* packed, const float* bias,
+                                          const float* resid, long ldr, const float* gate, long gate_stride_b, long gate_stride_t, int T,
+                                          float* out, long ldo, int M, int N, int K, int ksplit, void* workspace, int* overflow, hipStream_t stream)
+{
+    if (ksplit == 1)
+        return selftok_linear_f16x2_split_residual(a_blk, packed, bias, resid, ldr, gate, gate_stride_b, gate_stride_t, T, out, ldo, M, N, K, overflow, stream);
+    if (M < 0 || N <= 0 || K <= 0 || N % BN || K % BK) { set_last_error("linear_f16x2_split_residual_k: need N % 128 == 0 and K % 32 == 0"); return SELFTOK_EINVAL; }
+    if (M == 0) return SELFTOK_OK;
+    if (!a_blk || !packed || !resid || !out || ldo < N || (ldo & 3) || ldr < N || (ldr & 3) || T <= 0
+        || ((size_t)a_blk & 15) || ((size_t)out & 15) || ((size_t)resid & 15) || (bias && ((size_t)bias & 15))
+        || (gate && (((size_t)gate & 15) || (gate_stride_b & 3) || (gate_stride_t & 3))) || !splitk_ok(K, ksplit, workspace)) {
+        set_last_error("linear_f16x2_split_residual_k: bad pointers/strides (as linear_f16x2_split_residual), or ksplit not in 2..64 / not a divisor of K / 32, or no 16-byte aligned workspace");
+        return SELFTOK_EINVAL;
+    }
+    float* ws = (float*)workspace;
+    if (int rc = launch_splitk_partials(a_blk, packed, ws, M, N, K, ksplit, overflow, stream)) return rc;
+    const long n = (long)M * (N / 8);
+    hipLaunchKernelGGL((splitk_finish_kernel<0, 0, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)ws, ksplit, bias, out,
+                       (_Float16*)nullptr, ldo, M, N, overflow, ResArgs{resid, ldr, gate, gate_stride_b, gate_stride_t, T});
+    return check_launch("splitk_finish_kernel(residual)");
 }
 
 }  // extern "C"

@@ -36,6 +36,7 @@ class MMDiTGPU(ModuleSurface):
     _sd_prefix = "model."
     GEMM_MODES = ("fp32", "f16x2")
     PRESPLIT = True     # f16x2 mode: producers (LN-modulate, attention, fc1+GELU) hand the next Linear its input already split
+    SPLITK = True       # f16x2 mode, <= ops.SPLITK_MAX_ROWS rows (one .. four images): several work-groups per output tile (ops.f16x2_ksplit)
 
     def __init__(self, sd: Dict[str, torch.Tensor], device, K: int, renderer: bool = False, gemm: str = "fp32"):
         self.device, self.K, self.renderer = device, K, renderer
@@ -93,13 +94,17 @@ class MMDiTGPU(ModuleSurface):
         w, b = self.w[name + ".weight"], self.w[name + ".bias"]
         if isinstance(x, ops.SplitAct):
             assert name in self._packed, f"split activation handed to Linear {name!r}, which has no f16x2-split weight (set_gemm('f16x2') packs the block Linears)"
-            return ops.linear_f16x2_split(x, self._packed[name], b, w.shape[0], gelu=gelu, overflow=self.overflow, out_split=out_split)
+            return ops.linear_f16x2_split(x, self._packed[name], b, w.shape[0], gelu=gelu, overflow=self.overflow, out_split=out_split,
+                                          ksplit=self._ksplit(x.rows, w))
         assert not out_split
         if self.gemm == "f16x2" and name in self._packed:
             return ops.linear_f16x2(x, self._packed[name], b, w.shape[0], gelu=gelu, overflow=self.overflow)
         if gelu:
             return ops.linear_gelu(x, w, b)
         return F.linear(x, w, b)
+
+    def _ksplit(self, rows: int, w) -> int:
+        return ops.f16x2_ksplit(rows, w.shape[0], w.shape[1]) if self.SPLITK else 1
 
     def _pre(self, name) -> bool:
         """does Linear `name` take its input as a split activation?"""
@@ -118,7 +123,7 @@ class MMDiTGPU(ModuleSurface):
             assert lin_name in self._packed, f"split activation handed to Linear {lin_name!r}, which has no f16x2-split weight"
             w, b = self.w[lin_name + ".weight"], self.w[lin_name + ".bias"]
             x = ops.linear_f16x2_split_residual(lin_in, self._packed[lin_name], b, w.shape[0], x, gate=gate, gate_per_sample=gate_per_sample,
-                                                overflow=self.overflow)
+                                                overflow=self.overflow, ksplit=self._ksplit(lin_in.rows, w))
             _, n = ops.residual_ln_mod(x, split=split, overflow=self.overflow, **ln_kw)
             return x, n
         return ops.residual_ln_mod(x, y=self.lin(lin_name, lin_in), gate=gate, gate_per_sample=gate_per_sample, split=split,

@@ -338,29 +338,60 @@ def split_to_f32(xs: SplitAct) -> torch.Tensor:
     return p[0].float() + p[1].float() * (1.0 / 2048.0)
 
 
+SPLITK_MAX_ROWS = 1024      # rows up to which the block Linears of the f16x2 mode are worth splitting along K (one .. four images)
+
+
+def f16x2_ksplit(M: int, N: int, K: int) -> int:
+    """how many work-groups should share an output tile of a [M, K] x [K, N] f16x2 Linear: 1 = the single-pass kernel.  Small M only
+    (<= SPLITK_MAX_ROWS): the 256 x 128 tile grid then leaves most of the 256 CUs idle while each work-group walks all of K.  Among
+    the divisors s of K / 32 that keep the grid within one work-group per CU (a second round of work-groups costs ~10 us:
+    profiles/r4_splitk_sweep.txt) and >= 3 k-tiles per work-group (the DMA pipeline depth), the minimum of a two-term cost fitted to
+    that sweep: 0.42 us per k-tile of the longest chain + 1.2 us per million fp32 partials written and re-read, + 4 us for the
+    second launch."""
+    if M <= 0 or M > SPLITK_MAX_ROWS:
+        return 1
+    tiles = ((M + 255) // 256) * (N // 128)
+    kt = K // 32
+    best, best_cost = 1, 0.42 * kt
+    for s in range(2, 65):
+        if kt % s or kt // s < 3 or tiles * s > 256:
+            continue
+        cost = 0.42 * (kt // s) + 1.2e-6 * s * M * N + 4.0
+        if cost < best_cost:
+            best, best_cost = s, cost
+    return best
+
+
+def _splitk_ws(M: int, N: int, ksplit: int, device) -> torch.Tensor:
+    return torch.empty(ksplit * M * N, dtype=torch.float32, device=device)
+
+
 def linear_f16x2_split(xs: SplitAct, packed: torch.Tensor, bias, N: int, gelu: bool = False, overflow: torch.Tensor = None,
-                       out_split: bool = False):
+                       out_split: bool = False, ksplit: int = 1):
     """linear_f16x2 on a split activation: both operands reach LDS by LDS-DMA.  Returns fp32 [..., N], or with out_split a SplitAct
-    [..., N] for the next Linear.  Same results as linear_f16x2 on the fp32 tensor."""
+    [..., N] for the next Linear.  Same results as linear_f16x2 on the fp32 tensor.  ksplit > 1 (small M, `f16x2_ksplit`): that many
+    work-groups per output tile + a reduction launch; deterministic, equal to the single-pass result up to fp32 rounding of the
+    partial sums (selftok_linear_f16x2_split_k)."""
     _need_cuda(xs.data, packed)
     K = xs.shape[-1]
     assert packed.numel() * 2 == 4 * N * K, "packed weight does not match (N, K)"
     M, lead = xs.rows, xs.shape[:-1]
     lib = _lib.load()
     flags = LINEAR_GELU if gelu else 0
+    ws = _splitk_ws(M, N, ksplit, xs.device) if (ksplit > 1 and M > 0) else None
     if out_split:
         out = SplitAct((*lead, N), xs.device)
-        _lib.check(lib.selftok_linear_f16x2_split(_p(xs.data), _p(packed), _p(bias), None, _p(out.data), N, M, N, K, flags, _p(overflow), _stream()),
-                   "selftok_linear_f16x2_split")
+        _lib.check(lib.selftok_linear_f16x2_split_k(_p(xs.data), _p(packed), _p(bias), None, _p(out.data), N, M, N, K, flags, ksplit, _p(ws), _p(overflow), _stream()),
+                   "selftok_linear_f16x2_split_k")
         return out
     out = torch.empty(M, N, dtype=torch.float32, device=xs.device)
-    _lib.check(lib.selftok_linear_f16x2_split(_p(xs.data), _p(packed), _p(bias), _p(out), None, N, M, N, K, flags, _p(overflow), _stream()),
-               "selftok_linear_f16x2_split")
+    _lib.check(lib.selftok_linear_f16x2_split_k(_p(xs.data), _p(packed), _p(bias), _p(out), None, N, M, N, K, flags, ksplit, _p(ws), _p(overflow), _stream()),
+               "selftok_linear_f16x2_split_k")
     return out.reshape(*lead, N)
 
 
 def linear_f16x2_split_residual(xs: SplitAct, packed: torch.Tensor, bias, N: int, resid: torch.Tensor, gate=None,
-                                gate_per_sample: bool = False, overflow: torch.Tensor = None) -> torch.Tensor:
+                                gate_per_sample: bool = False, overflow: torch.Tensor = None, ksplit: int = 1) -> torch.Tensor:
     """resid + gate * (xs @ W.T + bias): linear_f16x2_split with the block's residual update fused into the epilogue.
     resid [B,T,N] fp32 contiguous; gate a 2-D view [T,N] (per token) or [B,N] (gate_per_sample) with unit inner stride, or None.
     Bit-identical to residual_ln_mod(resid, y=linear_f16x2_split(...), gate=gate)[0]."""
@@ -376,8 +407,9 @@ def linear_f16x2_split_residual(xs: SplitAct, packed: torch.Tensor, bias, N: int
         assert gate.dim() == 2 and gate.stride(1) == 1 and gate.shape == ((B, N) if gate_per_sample else (T, N))
         gsb, gst = (gate.stride(0), 0) if gate_per_sample else (0, gate.stride(0))
     out = torch.empty_like(resid)
-    _lib.check(_lib.load().selftok_linear_f16x2_split_residual(_p(xs.data), _p(packed), _p(bias), _p(resid), N, _p(gate), gsb, gst, T,
-                                                           _p(out), N, M, N, K, _p(overflow), _stream()), "selftok_linear_f16x2_split_residual")
+    ws = _splitk_ws(M, N, ksplit, resid.device) if (ksplit > 1 and M > 0) else None
+    _lib.check(_lib.load().selftok_linear_f16x2_split_residual_k(_p(xs.data), _p(packed), _p(bias), _p(resid), N, _p(gate), gsb, gst, T,
+                                                             _p(out), N, M, N, K, ksplit, _p(ws), _p(overflow), _stream()), "selftok_linear_f16x2_split_residual_k")
     return out
 
 

@@ -352,7 +352,7 @@ class SelftokPipeline():
                                            uncond_scale=uncond_scale, max_steps=max_steps, prefix_k=prefix_k, super_mask=super_mask)
         visible = None if super_mask is None else self.flow.resolve_super_mask(super_mask, self.K)     # host read + upload: before the capture
         sm_key = None if visible is None else visible[1].tobytes()
-        key = (tuple(xt.shape), tuple(ehs.shape), max_steps, float(uncond_scale), self.model.model.gemm, prefix_k, sm_key)
+        key = (tuple(xt.shape), tuple(ehs.shape), max_steps, float(uncond_scale), self.model.model.gemm, self.model.model.PRESPLIT, self.model.model.SPLITK, prefix_k, sm_key)
         if key not in self._graphs:
             s_noise = torch.empty(xt.shape, dtype=torch.float32, device=self.device)
             s_ehs = torch.empty_like(ehs)

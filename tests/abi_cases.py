@@ -369,7 +369,8 @@ def _(alloc):
     return "selftok_linear_f16x2_pack_weight", [alloc(w).ptr, packed.ptr, 256, 96, ov.ptr, None], dict(packed=packed, overflow=ov)
 
 
-def _linear(kind, flags=0, M=70, N=256, K=160, seed=33):
+def _linear(kind, flags=0, M=70, N=256, K=160, seed=33, ksplit=0):
+    """ksplit > 0: the small-M entry points (selftok_linear_f16x2_split_k / _split_residual_k) with that many work-groups per tile"""
     def fn(alloc):
         r = rng(seed)
         a, w, bias = f32(r.standard_normal((M, K))), f32(r.standard_normal((N, K)) / np.sqrt(K)), f32(r.standard_normal(N))
@@ -382,16 +383,19 @@ def _linear(kind, flags=0, M=70, N=256, K=160, seed=33):
             return "selftok_linear_f16x2_f32", [alloc(a).ptr, K, packed.ptr, alloc(bias).ptr, out.ptr, N, M, N, K, flags, ov.ptr, None], outs, pre
         ablk = alloc(np.zeros(((M + 15) // 16) * 16 * K * 2, np.uint16))
         pre.append(("selftok_split_f16x2_f32", [alloc(a).ptr, K, ablk.ptr, M, K, ov.ptr, None]))
+        ws = alloc(np.zeros(max(ksplit, 1) * M * N, np.float32))
+        ktail = [ksplit, ws.ptr] if ksplit else []
+        sfx = "_k" if ksplit else ""
         if kind == "split":
-            return "selftok_linear_f16x2_split", [ablk.ptr, packed.ptr, alloc(bias).ptr, out.ptr, None, N, M, N, K, flags, ov.ptr, None], outs, pre
+            return "selftok_linear_f16x2_split" + sfx, [ablk.ptr, packed.ptr, alloc(bias).ptr, out.ptr, None, N, M, N, K, flags] + ktail + [ov.ptr, None], outs, pre
         if kind == "split_to_split":
             oblk = alloc(np.zeros(((M + 15) // 16) * 16 * N * 2, np.uint16))
-            return ("selftok_linear_f16x2_split", [ablk.ptr, packed.ptr, alloc(bias).ptr, None, oblk.ptr, N, M, N, K, flags, ov.ptr, None],
+            return ("selftok_linear_f16x2_split" + sfx, [ablk.ptr, packed.ptr, alloc(bias).ptr, None, oblk.ptr, N, M, N, K, flags] + ktail + [ov.ptr, None],
                     dict(out_blk=oblk, overflow=ov, _rows=M, _cols=N), pre)
         T = 35
         resid, gate = f32(r.standard_normal((M, N))), f32(r.standard_normal((M // T, N)))
-        return ("selftok_linear_f16x2_split_residual", [ablk.ptr, packed.ptr, alloc(bias).ptr, alloc(resid).ptr, N, alloc(gate).ptr if kind == "resid_gate" else None, N, 0, T,
-                                                        out.ptr, N, M, N, K, ov.ptr, None], outs, pre)
+        return ("selftok_linear_f16x2_split_residual" + sfx, [ablk.ptr, packed.ptr, alloc(bias).ptr, alloc(resid).ptr, N, alloc(gate).ptr if kind == "resid_gate" else None, N, 0, T,
+                                                              out.ptr, N, M, N, K] + ktail + [ov.ptr, None], outs, pre)
     return fn
 
 
@@ -401,6 +405,11 @@ case("linear_f16x2_split", exact=False, tol=1e-6)(_linear("split"))
 case("linear_f16x2_split_to_split", exact=False, tol=1e-6)(_linear("split_to_split", GELU))
 case("linear_f16x2_split_residual_gate", exact=False, tol=1e-6)(_linear("resid_gate"))
 case("linear_f16x2_split_residual_nogate", exact=False, tol=1e-6)(_linear("resid"))
+case("linear_f16x2_split_k2", exact=False, tol=1e-6)(_linear("split", K=192, ksplit=2))
+case("linear_f16x2_split_k3_to_split_gelu", exact=False, tol=1e-6)(_linear("split_to_split", GELU, K=192, ksplit=3))
+case("linear_f16x2_split_k6_nobias_rows", exact=False, tol=1e-6)(_linear("split", M=300, K=192, ksplit=6, seed=35))
+case("linear_f16x2_split_residual_k2_gate", exact=False, tol=1e-6)(_linear("resid_gate", K=192, ksplit=2))
+case("linear_f16x2_split_residual_k3_nogate", exact=False, tol=1e-6)(_linear("resid", K=192, ksplit=3))
 
 
 # ---- attention --------------------------------------------------------------------------------------------------------------------

@@ -180,6 +180,60 @@ def test_residual_epilogue_bit_identical(B, T, N, K):
     assert int(flag.item()) == 0
 
 
+@pytest.mark.parametrize("M", [1, 256, 257, 513])
+@pytest.mark.parametrize("N,K", [(4608, 1536), (1536, 1536), (6144, 1536), (1536, 6144)])
+def test_split_k_small_m(M, N, K):
+    """the small-M entry points (one image: 256 image rows, <= 513 context rows) at the model's four Linear shapes: `ksplit` work-groups
+    per output tile + the reduction launch.  Deterministic (two runs bit-equal), every epilogue (plain, GELU + split output, residual
+    with gate) a function of the SAME reduced sum, within fp32 rounding of the single-pass kernel, and not less accurate against fp64."""
+    ks = max(ops.f16x2_ksplit(M, N, K), 2)                   # where the heuristic keeps the single-pass kernel, exercise 2 anyway
+    assert (K // 32) % ks == 0 and ops.f16x2_ksplit(2048, N, K) == 1
+    a, w, b = _data(M, N, K, seed=11 * M + N + K)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    packed = ops.linear_f16x2_pack(w, flag)
+    xs = ops.split_f16x2(a.reshape(1, M, K), flag)
+    one = ops.linear_f16x2_split(xs, packed, b, N, overflow=flag)
+    out = ops.linear_f16x2_split(xs, packed, b, N, overflow=flag, ksplit=ks)
+    again = ops.linear_f16x2_split(xs, packed, b, N, overflow=flag, ksplit=ks)
+    assert torch.equal(out, again)
+    ref = (a.double() @ w.double().T + b.double())
+    e_one, e_k = float((one[0].double() - ref).abs().max()), float((out[0].double() - ref).abs().max())
+    d = float((out - one).abs().max())
+    scale = float(ref.abs().max())
+    print(f"M={M} N={N} K={K} ksplit={ks}: |split-K - single pass| max {d:.3e} (outputs up to {scale:.2f}); vs fp64: single pass {e_one:.3e}, split-K {e_k:.3e}")
+    assert d <= 1.5e-6 * scale and e_k <= 1.5 * e_one + 1e-7 * scale
+    # GELU + split output == the split of the GELU'd fp32 output of the same launch pair
+    g32 = ops.linear_f16x2_split(xs, packed, b, N, gelu=True, overflow=flag, ksplit=ks)
+    gsp = ops.linear_f16x2_split(xs, packed, b, N, gelu=True, overflow=flag, ksplit=ks, out_split=True)
+    assert torch.equal(gsp.planes(), ops.split_f16x2(g32).planes())
+    assert float((g32 - ops.linear_f16x2_split(xs, packed, b, N, gelu=True)).abs().max()) <= 1.5e-6 * scale
+    # no bias
+    nb = ops.linear_f16x2_split(xs, packed, None, N, ksplit=ks)
+    assert float((nb + b - out).abs().max()) <= 1e-6 * scale
+    if N == 1536:                                           # residual epilogue (a hidden size residual_ln_mod supports)
+        g = torch.Generator(device="cuda").manual_seed(2)
+        resid = torch.randn(1, M, N, device="cuda", generator=g)
+        tab = torch.randn(M, 2 * N, device="cuda", generator=g)
+        for gate in (tab[:, N:], None):
+            want, _ = ops.residual_ln_mod(resid, y=out, gate=gate, want_n=False)
+            got = ops.linear_f16x2_split_residual(xs, packed, b, N, resid, gate=gate, overflow=flag, ksplit=ks)
+            assert torch.equal(got, want)
+    assert int(flag.item()) == 0
+    from selftoktokenizer_amd._lib import SelftokHipError
+    with pytest.raises(SelftokHipError):
+        ops.linear_f16x2_split(xs, packed, b, N, ksplit=7)                  # not a divisor of K / 32
+
+
+def test_split_k_overflow_flag_and_empty():
+    a, w, b = _data(40, 128, 192, seed=4)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    xs = ops.split_f16x2(a * 3.0e3)
+    ops.linear_f16x2_split(xs, ops.linear_f16x2_pack(w * 50.0), None, 128, overflow=flag, out_split=True, ksplit=3)
+    assert int(flag.item()) & 1
+    packed = ops.linear_f16x2_pack(w)
+    assert ops.linear_f16x2_split(ops.split_f16x2(a[:0]), packed, b, 128, ksplit=2).shape == (0, 128)
+
+
 def test_gemm_tune_installs_measured_kernels_and_keeps_the_numbers(capsys):
     """gemm_tune.autotune_linears: every family gets a report entry; whatever kernel it installs for a row count of the step, the Linear's
     result stays an fp32 GEMM of the same accuracy against fp64 as the default kernel's (a different summation order, nothing else).

@@ -111,6 +111,7 @@ def test_f16x2_presplit_activations_bit_identical(sd, encoder):
     forward must be bit-identical to the path that keeps fp32 activations between kernels."""
     from selftoktokenizer_amd.mmdit import MMDiTGPU
     d = MMDiTGPU(sd, torch.device("cuda"), 512, gemm="f16x2")
+    d.SPLITK = False            # B = 2 is inside the small-M regime: compare the single-pass kernels (split-K changes the summation order)
     ids = torch.from_numpy(synth.synthetic_token_ids(2)).cuda()
     ehs = encoder.codes_ln(ids)
     x = synth.synthetic_noise(2, device="cuda")
@@ -123,6 +124,27 @@ def test_f16x2_presplit_activations_bit_identical(sd, encoder):
     assert int(d.overflow.item()) == 0
     for name in ("masked", "full"):
         assert torch.equal(outs[True, name], outs[False, name]), name
+
+
+def test_f16x2_small_m_split_k_forward(sd, encoder):
+    """one image (M = 256 image rows, k + 1 context rows): the block Linears take the split-K entry points (ops.f16x2_ksplit); the
+    velocity agrees with the single-pass kernels' to fp32 summation noise, run to run bit for bit, and B = 8 (2048 rows) is untouched"""
+    from selftoktokenizer_amd.mmdit import MMDiTGPU
+    d = MMDiTGPU(sd, torch.device("cuda"), 512, gemm="f16x2")
+    ids = torch.from_numpy(synth.synthetic_token_ids(1)).cuda()
+    ehs = encoder.codes_ln(ids)
+    x = synth.synthetic_noise(1, device="cuda")
+    t = torch.tensor([620.0], device="cuda")
+    mask = torch.arange(512, device="cuda")[None] <= 300
+    assert d.SPLITK and ops.f16x2_ksplit(256, 1536, 1536) > 1 and ops.f16x2_ksplit(8 * 256, 1536, 1536) == 1
+    v1, _ = d(x, t, encoder_hidden_states=ehs, mask=mask, context_see_xt=True)
+    v2, _ = d(x, t, encoder_hidden_states=ehs, mask=mask, context_see_xt=True)
+    d.SPLITK = False
+    v0, _ = d(x, t, encoder_hidden_states=ehs, mask=mask, context_see_xt=True)
+    assert int(d.overflow.item()) == 0 and torch.equal(v1, v2)
+    e = float((v1 - v0).abs().max())
+    print(f"B=1 MMDiT.forward, split-K vs single-pass Linears: max abs diff {e:.3e} (|v| up to {float(v0.abs().max()):.2f})")
+    assert e < 2e-5
 
 
 def test_dit_truncated_context_equals_masked(dit, encoder):
