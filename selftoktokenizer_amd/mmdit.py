@@ -42,6 +42,7 @@ class MMDiTGPU(ModuleSurface):
         self.device, self.K, self.renderer = device, K, renderer
         self.gemm = "fp32"
         self._packed = {}                                                   # linear name -> f16x2-split weight image
+        self._mod_cache = {}                                                # (timestep name, gemm mode) -> modulations of a single-image step
         self.overflow = torch.zeros(1, dtype=torch.int32, device=device)    # sticky fp16-range flag of the split GEMMs
         self.w = {k: v.to(device=device, dtype=torch.float32).contiguous() for k, v in sd.items() if k.startswith("model.")}
         H = DIT_HIDDEN
@@ -162,20 +163,47 @@ class MMDiTGPU(ModuleSurface):
         return self.lin("model.joint_blocks.0.context_block.attn.qkv", cn)
 
     @torch.no_grad()
-    def core(self, xe: torch.Tensor, c: torch.Tensor, ctx: Optional[torch.Tensor], seg0_sees_seg1: bool = True,
-             kvis: Optional[torch.Tensor] = None, cqkv0: Optional[torch.Tensor] = None, tables=None) -> torch.Tensor:
+    def modulations(self, c: torch.Tensor, has_ctx: bool = True):
+        """the 26 adaLN_modulation Linears of one model evaluation (sd3/mmdit.py:430-470, 641-645): functions of c = t_embedder(t) alone.
+        -> ([24 x [B,6H]] image stream, [B,2H] last context block or None, [B,2H] final layer)"""
+        sc = ops.silu(c)                                     # every adaLN_modulation starts with SiLU(c)
+        mods_x = [self.lin(f"model.joint_blocks.{i}.x_block.adaLN_modulation.1", sc) for i in range(DIT_DEPTH)]   # [B,6H]
+        mods_c_last = self.lin(f"model.joint_blocks.{DIT_DEPTH - 1}.context_block.adaLN_modulation.1", sc) if has_ctx else None  # [B,2H]
+        mods_f = self.lin("model.final_layer.adaLN_modulation.1", sc)                                              # [B,2H]
+        return mods_x, mods_c_last, mods_f
+
+    MOD_CACHE_MAX = 256     # entries (one per scheduled timestep and branch; 0.9 MB each); 0: off
+
+    def _step_modulations(self, t_freq: torch.Tensor, t_key):
+        """`modulations(time_embed(t_freq))` of a sampler step, remembered per timestep for single-image calls: the reference evaluates
+        t_embedder and the adaLN Linears at every step of every call (28 M = 1 GEMMs streaming 1.4 GB of weights: 27 of the 360 ms of a
+        one-image decode), but they depend on the scheduled timestep alone.  B == 1 only: there the remembered tensors ARE what the
+        step would compute (same shapes, same kernels, bit for bit); at larger B the GEMMs are 0.1 % of the step.  Nothing is stored
+        while a stream is capturing (tensors made during a capture belong to the graph's pool); the warm-up pass before a capture
+        fills the table, the capture then reads it."""
+        key = None if (t_key is None or t_freq.shape[0] != 1 or self.MOD_CACHE_MAX <= 0) else (t_key, self.gemm)
+        if key is not None and key in self._mod_cache:
+            return self._mod_cache[key]
+        mods = self.modulations(self.time_embed(t_freq), True)
+        if key is not None and not (t_freq.is_cuda and torch.cuda.is_current_stream_capturing()):
+            if len(self._mod_cache) >= self.MOD_CACHE_MAX:
+                self._mod_cache.clear()
+            self._mod_cache[key] = mods
+        return mods
+
+    @torch.no_grad()
+    def core(self, xe: torch.Tensor, c: Optional[torch.Tensor], ctx: Optional[torch.Tensor], seg0_sees_seg1: bool = True,
+             kvis: Optional[torch.Tensor] = None, cqkv0: Optional[torch.Tensor] = None, tables=None, mods=None) -> torch.Tensor:
         """xe [B,n_x,H] embedded image tokens, c [B,H], ctx [B,n_ctx,H] live context tokens (or None / n_ctx = 0)
         -> FinalLayer output [B,n_x,64] (before unpatchify).  `tables`: per-block context adaLN tables whose row j belongs to context
-        row j (default: the position tables; `gather_context` returns the rows of a visibility pattern)."""
+        row j (default: the position tables; `gather_context` returns the rows of a visibility pattern).  `mods`: the result of
+        `modulations(c, ...)` if the caller already has it (c is then unused)."""
         H, NH = DIT_HIDDEN, DIT_HEADS
         B, nx, _ = xe.shape
         n = 0 if ctx is None else ctx.shape[1]
         has_ctx = n > 0
         amode = ops.ATTN_F16X2 if self.gemm == "f16x2" else 0   # 'f16x2': the joint attention runs as split products too
-        sc = ops.silu(c)                                     # every adaLN_modulation starts with SiLU(c)
-        mods_x = [self.lin(f"model.joint_blocks.{i}.x_block.adaLN_modulation.1", sc) for i in range(DIT_DEPTH)]   # [B,6H]
-        mods_c_last = self.lin(f"model.joint_blocks.{DIT_DEPTH - 1}.context_block.adaLN_modulation.1", sc) if has_ctx else None  # [B,2H]
-        mods_f = self.lin("model.final_layer.adaLN_modulation.1", sc)                                              # [B,2H]
+        mods_x, mods_c_last, mods_f = mods if mods is not None else self.modulations(c, has_ctx)
         tab = [t[:n] for t in (tables or self.ctx_tables)]
         x = xe
         blk = "model.joint_blocks.{}.{}_block.{}".format
@@ -242,12 +270,13 @@ class MMDiTGPU(ModuleSurface):
         return ops.add_rows_(xe, self._pos_bias(Hh // 2, Ww // 2))
 
     @torch.no_grad()
-    def velocity_tokens(self, x, t_freq, ctx0, n_live: int, context_see_xt: bool = True, cqkv0=None, tables=None):
-        """one model evaluation inside the sampler: returns the FinalLayer tokens [B,256,64]"""
-        c = self.time_embed(t_freq)
+    def velocity_tokens(self, x, t_freq, ctx0, n_live: int, context_see_xt: bool = True, cqkv0=None, tables=None, t_key=None):
+        """one model evaluation inside the sampler: returns the FinalLayer tokens [B,256,64].  `t_key`: a hashable name of the
+        timestep t_freq embeds (the same for every sample), see `_step_modulations`."""
+        mods = self._step_modulations(t_freq, t_key)
         ctx = ctx0[:, :n_live].contiguous() if n_live < ctx0.shape[1] else ctx0
-        return self.core(self.embed_image(x), c, ctx if n_live > 0 else None, context_see_xt, cqkv0=cqkv0 if n_live > 0 else None,
-                         tables=tables)
+        return self.core(self.embed_image(x), None, ctx if n_live > 0 else None, context_see_xt, cqkv0=cqkv0 if n_live > 0 else None,
+                         tables=tables, mods=mods)
 
     @torch.no_grad()
     def gather_context(self, ctx0: torch.Tensor, visible: torch.Tensor = None, index: torch.Tensor = None):

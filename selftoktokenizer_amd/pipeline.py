@@ -121,15 +121,16 @@ class _Flow(FlowSchedule):
             if vis_pos is not None:                                           # visible tokens at positions < n_live: a prefix of the gathered list
                 n_live = int(np.searchsorted(vis_pos, n_live, side="left"))
             tf = self.t_freq[i:i + 1].expand(B, -1).contiguous()
+            t_name = float(self.scheduled_t[i])                               # names the embedded timestep (MMDiTGPU._step_modulations)
             if uncond_scale == 1.0:
-                y = dit.velocity_tokens(x, tf, ctx0, n_live, context_see_xt, cqkv0, tables)
+                y = dit.velocity_tokens(x, tf, ctx0, n_live, context_see_xt, cqkv0, tables, t_key=("t", t_name))
                 yu = None
             else:
                 # CFG branch (rectified_flow.py:280-289): the conditional call omits context_see_xt (-> False) and
                 # the unconditional one sees no context token at all
-                y = dit.velocity_tokens(x, tf, ctx0, n_live, False, cqkv0, tables)
+                y = dit.velocity_tokens(x, tf, ctx0, n_live, False, cqkv0, tables, t_key=("t", t_name))
                 tfu = self.t_freq_uncond[i:i + 1].expand(B, -1).contiguous()
-                yu = dit.velocity_tokens(x, tfu, ctx0, 0, False)              # cfg_inference: no context key visible at all
+                yu = dit.velocity_tokens(x, tfu, ctx0, 0, False, t_key=("floor", t_name))   # cfg_inference: no context key visible at all
             if self.parameterization == "x0":
                 # the model output is the clean latent: x_prev = v + a_prev (x - v) / a_t  (euler_step, rectified_flow.py:305-307);
                 # the CFG mix rides in the unpatchify kernel, the update is the reference's own chain of fp32 element-wise ops

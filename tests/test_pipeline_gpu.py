@@ -322,6 +322,36 @@ def test_hipgraph_replay_equals_eager(pipe):
     assert torch.equal(eager2, g2)
 
 
+@pytest.mark.parametrize("gemm", ["fp32", "f16x2"])
+def test_single_image_decode_remembers_the_timestep_modulations(pipe, gemm):
+    """one image: t_embedder + the 26 adaLN Linears of a step depend on the scheduled timestep alone and are remembered across steps'
+    calls (MMDiTGPU._step_modulations) -- same tensors the step would compute: latents bit-equal with the table off, on (filling),
+    on (reading), and through a hipGraph captured after the table was filled; CFG's second branch (floor(t 1000)) has its own entries"""
+    dit = pipe.model.model
+    assert pipe.set_gemm(gemm) == gemm
+    ids, noise = synth.synthetic_token_ids(1, first_index=3), synth.synthetic_noise(1, first_index=3)
+    try:
+        dit._mod_cache.clear()
+        keep, dit.MOD_CACHE_MAX = dit.MOD_CACHE_MAX, 0
+        _, off = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=4)
+        _, off_cfg = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=4, uncond_scale=2.0)
+        assert len(dit._mod_cache) == 0
+        dit.MOD_CACHE_MAX = keep
+        _, fill = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=4)
+        assert len(dit._mod_cache) == 4
+        _, read = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=4)
+        _, graph = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=4, use_graph=True)
+        _, cfg = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=4, uncond_scale=2.0)
+        assert len(dit._mod_cache) == 8
+        assert torch.equal(off, fill) and torch.equal(off, read) and torch.equal(off, graph) and torch.equal(off_cfg, cfg)
+        n = len(dit._mod_cache)
+        pipe.decoding(synth.synthetic_token_ids(2), noise=synth.synthetic_noise(2), max_steps=2)      # B > 1: computed per step, nothing stored
+        assert len(dit._mod_cache) == n
+    finally:
+        dit.MOD_CACHE_MAX = keep
+        pipe.set_gemm("fp32")
+
+
 def test_full_batch_size_independence(pipe):
     """BASELINE configs[1] batch (B=64): every image's tokens / latent must not depend on its batch-mates.
     The exact / parity VAE (csrc/vae_exact.hip, csrc/conv.hip + the fp64-statistics GroupNorm: no library, no solver choice, fixed summation order per output
