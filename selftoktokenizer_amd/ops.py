@@ -5,6 +5,7 @@ libselftok_hip.so, and returns torch tensors.  PyTorch is only the allocator / s
 """
 from __future__ import annotations
 
+import functools
 from typing import Optional
 
 import torch
@@ -341,6 +342,7 @@ def split_to_f32(xs: SplitAct) -> torch.Tensor:
 SPLITK_MAX_ROWS = 1024      # rows up to which the block Linears of the f16x2 mode are worth splitting along K (one .. four images)
 
 
+@functools.lru_cache(maxsize=4096)
 def f16x2_ksplit(M: int, N: int, K: int) -> int:
     """how many work-groups should share an output tile of a [M, K] x [K, N] f16x2 Linear: 1 = the single-pass kernel.  Small M only
     (<= SPLITK_MAX_ROWS): the 256 x 128 tile grid then leaves most of the 256 CUs idle while each work-group walks all of K.  Among
