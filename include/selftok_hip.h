@@ -296,6 +296,33 @@ int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void*
 /* glibc's expf (what `std::exp(float)` evaluates inside the flash kernel), element-wise; exposed for the parity tests. */
 int selftok_vx_expf_f32(const float* x, float* y, long n, hipStream_t stream);
 
+/* ---- the fp32 Q-Former encoder in the reference's exact summation orders (round 5; csrc/encoder_exact.hip, CPU twin oracle/encoder_exact.c) ----
+ * Replaces, bit for bit, what torch-CPU executes for `Encoder.forward` (mimogpt/models/selftok/models_ours.py:204-257, 315-343) and
+ * `DualBlock` / `DualAttention` (modules.py:165-327): every nn.Linear / F.linear (MKL sgemm: sequential fmaf chains per K-block of 384,
+ * two halves for 384 < K < 768), the k2 s2 PatchEmbed convolution (one 64-tap chain = a Linear over the (kh, kw, ic)-ordered patch),
+ * nn.LayerNorm (ATen RowwiseMoments), GELU(tanh) / SiLU (Sleef tanhf_u10 / expf_u10), F.scaled_dot_product_attention (ATen's fp32
+ * cpu_flash_attention).  Every output row depends on its own input row only: results do not depend on the batch size.
+ *
+ * selftok_ex_linear_f32: out[m][n] = bias[n] + sum_k x[m][k] w[n][k]   (modules.py:109,186-199,293 ...; F.linear)
+ *   x rows at stride ldx (a column slice of a fused projection is fine; 16-byte aligned), w [N][K] contiguous, K % 16 == 0.
+ *   gelu != 0: out = GELU_tanh(out) (timm Mlp fc1 -> act).  res != NULL: out = res[m % res_mod][n] + (gate ? gate[m % gate_mod][n] * out : out)
+ *   with the product and the sum rounded separately (`x + attn`, `q + gate(q_attn, g)`, modules.py:322-326); res_mod / gate_mod 0 = no modulo.
+ *   out may alias res. */
+int selftok_ex_linear_f32(const float* x, long ldx, const float* w, const float* bias, const float* res, long ldr, int res_mod, const float* gate,
+                          long ldg, int gate_mod, float* out, long ldo, long M, int N, int K, int gelu, hipStream_t stream);
+/* nn.LayerNorm(N, eps) [affine gamma / beta or NULL] followed, when shift / scale are given, by the reference's modulate
+ * `x * (1 + scale[tok]) + shift[tok]` (modules.py:29-32), tok = row % T, table rows at stride ldt.  stats (may be NULL): [rows][2] mean, rstd. */
+int selftok_ex_layernorm_mod_f32(const float* x, long ldx, float* out, long ldo, const float* shift, const float* scale, long ldt, int T, const float* gamma,
+                                 const float* beta, float* stats, long rows, int N, float eps, hipStream_t stream);
+/* element-wise: mode 0 GELU(tanh) (ATen GeluKernelImpl), 1 SiLU, and the building blocks 2 Sleef expf_u10, 3 Sleef tanhf_u10, 4 ATen exp_u20 */
+int selftok_ex_unary_f32(const float* x, float* y, long n, int mode, hipStream_t stream);
+/* F.scaled_dot_product_attention (no mask) as ATen's fp32 flash kernel evaluates it.  q [B][Tq][..] rows at stride qs, head h = columns
+ * h*D .. h*D+D-1; keys / values [B][Tk1][..] at stride kvs1 and an optional second segment (Tk2 rows, stride kvs2) that follows the first
+ * (`torch.cat([k, query_k], dim=2)`, modules.py:250-251); out [B][Tq][H*D].  workspace >= selftok_ex_attention_workspace_bytes. */
+size_t selftok_ex_attention_workspace_bytes(int B, int H, int Tq, int Tk, int D);
+int selftok_ex_attention_f32(const float* q, long qs, const float* k1, const float* v1, long kvs1, int Tk1, const float* k2, const float* v2, long kvs2, int Tk2,
+                             float* out, void* workspace, int B, int H, int Tq, int D, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,359 @@
+/* oracle/encoder_exact.c -- TEST INFRASTRUCTURE (only tests/, __graft_entry__.smoke() and bench.py's checker legs may load it).
+ *
+ * A bit-for-bit CPU restatement of the fp32 arithmetic torch 2.10 (CPU, this image: MKL 2024.2, oneDNN 3.7.1, ATen AVX-512 kernels,
+ * Sleef, glibc 2.35) executes for the reference's Q-Former encoder (`Encoder.forward`, mimogpt/models/selftok/models_ours.py:204-257,
+ * 315-343; `DualBlock` / `DualAttention`, modules.py:165-327; `TimestepEmbedder`, models.py:56-79; `VectorQuantize.project_in`,
+ * vector_quantize_pytorch.py:844).  The reference's token ids are the argmax of these features: a token at a near-tie of its two best
+ * codes (the reference run of 64 images has 18 tokens with a gap below 1e-5, tests/golden/encode_b64.npz) flips under ANY other
+ * summation order, so "ids bit-exact at the configured batch" needs the ORDER of every reduction and the exact polynomial of every
+ * transcendental.  How each was established (round 5, tools/probe_cpu_fp32/, profiles/r5_cpu_fp32_orders.txt):
+ *
+ *  Linear       at::addmm -> MKL sgemm.  Per output element: the K products are summed by sequential fmaf chains that start from 0, one
+ *               chain per K-block; blocks are 384 wide, except that 384 < K < 768 splits into two halves; out = ((bias + c0) + c1) + ...
+ *               FPRev probe (a +2^40 / -2^40 pair among unit summands exposes the summation tree: fprev_linear.py, fprev_blocks.py),
+ *               then random data at every Linear shape of the encoder, M = 512 and 4096, 1 / 4 / 8 threads: 0 mismatches
+ *               (check_linear_emul.py).  Row-count independent for M >= 512; the reference itself is bit-identical for batches of
+ *               8, 16 and 64 images and differs at B = 1 (tests/golden/PINNING.json: encode64.ref_split_z_bits_equal).
+ *  conv k2 s2   PatchEmbed (oneDNN fp32 jit convolution): ONE sequential fmaf chain over the 64 taps in (kh, kw, ic) order.
+ *  LayerNorm    ATen LayerNormKernelImpl: RowwiseMoments over 8-lane vectors (Welford with FMAs, chunks of 16 vectors, binary cascade
+ *               of AddMomentsVec, scalar AddMoments with GCC's FMA contraction), rstd = 1 / sqrtf(var + eps) in fp32,
+ *               y = fma((x - mean) * rstd, gamma, beta) (gamma = 1, beta = 0 without affine).  0 mismatches incl. mean / rstd.
+ *  GELU(tanh)   ATen GeluKernelImpl: 0.5 x (1 + tanh(kBeta * fma(kKappa, x^3, x))) with Sleef_tanhf16_u10; SiLU: x / (1 + Sleef_expf16_u10(-x)).
+ *               Sleef's two routines are restated below from its published algorithm (double-float arithmetic in the FMA form) and
+ *               checked against the functions exported by libtorch_cpu.so on ALL 2^32 inputs: 0 mismatches; GELU and SiLU against
+ *               torch on all finite fp32 inputs: 0 mismatches.
+ *  attention    ATen cpu_flash_attention (fp32): q rows independent; kv blocks of 512; scores = one fmaf chain over head_dim (MKL,
+ *               K <= 64), * 1/sqrt(d); probabilities by Vectorized<float>::exp_u20 (ATen/cpu/vec/vec512/vec512_float.h) summed in 16
+ *               lanes (lane = key mod 16) then folded 8 / 4 / 2 / 1; sum = fma(exp, old sum, block sum) with glibc's expf for the
+ *               rescale; P V by MKL with K = block length (512 -> two chains of 256, 256 -> one), added to the rescaled accumulator;
+ *               out = acc * (1 / sum).  0 mismatches against F.scaled_dot_product_attention at (4 x 16, 256 keys), (8 x 64, 768 keys),
+ *               (8 x 64, 1280 keys).
+ *  elementwise  `x * (1 + scale) + shift`, `q + gate * y`, `x + y`: separate torch kernels = separately rounded fp32 operations.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * Sleef 3.x (the copy linked into libtorch_cpu.so), single precision, FMA build
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+#define XE_R_LN2f 1.442695040888963407359924681001892137426645954152985934135449406931f
+#define XE_L2Uf 0.693145751953125f
+#define XE_L2Lf 1.428606765330187045e-06f
+static inline float pow2if(int q) { return u2f((uint32_t)(q + 0x7f) << 23); }
+static inline float ldexp2kf(float d, int e) { return d * pow2if(e >> 1) * pow2if(e - (e >> 1)); }
+
+float xe_sleef_expf(float d) {                       /* Sleef_expf16_u10 */
+    int q = (int)rintf(d * XE_R_LN2f);
+    float qf = (float)q;
+    float s = fmaf(qf, -XE_L2Uf, d);
+    s = fmaf(qf, -XE_L2Lf, s);
+    float u = 0.000198527617612853646278381f;
+    u = fmaf(u, s, 0.00139304355252534151077271f);
+    u = fmaf(u, s, 0.00833336077630519866943359f);
+    u = fmaf(u, s, 0.0416664853692054748535156f);
+    u = fmaf(u, s, 0.166666671633720397949219f);
+    u = fmaf(u, s, 0.5f);
+    u = 1.0f + fmaf(s * s, u, s);
+    u = ldexp2kf(u, q);
+    if (d < -104.0f) u = 0.0f;
+    if (d > 104.0f) u = INFINITY;
+    return u;
+}
+
+typedef struct { float x, y; } xf2;                  /* double-float: value = x + y */
+static inline xf2 dfadd2_f2_f(xf2 x, float y) { xf2 r; r.x = x.x + y; float v = r.x - x.x; r.y = (x.x - (r.x - v)) + (y - v); r.y = r.y + x.y; return r; }
+static inline xf2 dfadd2_f2_f2(xf2 x, xf2 y) { xf2 r; r.x = x.x + y.x; float v = r.x - x.x; r.y = (x.x - (r.x - v)) + (y.x - v); r.y = r.y + (x.y + y.y); return r; }
+static inline xf2 dfadd_f_f2(float x, xf2 y) { xf2 r; r.x = x + y.x; r.y = ((x - r.x) + y.x) + y.y; return r; }
+static inline xf2 dfadd_f2_f2(xf2 x, xf2 y) { xf2 r; r.x = x.x + y.x; r.y = (((x.x - r.x) + y.x) + x.y) + y.y; return r; }
+static inline xf2 dfmul_f2_f(xf2 x, float y) { xf2 r; r.x = x.x * y; r.y = fmaf(x.x, y, -r.x); r.y = fmaf(x.y, y, r.y); return r; }
+static inline xf2 dfmul_f2_f2(xf2 x, xf2 y) { xf2 r; r.x = x.x * y.x; r.y = fmaf(x.x, y.x, -r.x); r.y = fmaf(x.y, y.x, r.y); r.y = fmaf(x.x, y.y, r.y); return r; }
+static inline xf2 dfsqu_f2(xf2 x) { xf2 r; r.x = x.x * x.x; r.y = fmaf(x.x, x.x, -r.x); r.y = fmaf(x.x + x.x, x.y, r.y); return r; }
+static inline xf2 dfrec_f2(xf2 d) { xf2 r; float s = 1.0f / d.x; r.x = s; r.y = s * fmaf(-d.y, s, fmaf(-d.x, s, 1.0f)); return r; }
+static inline xf2 dfdiv_f2_f2(xf2 n, xf2 d) {
+    xf2 q; float t = 1.0f / d.x; q.x = n.x * t;
+    float u = fmaf(t, n.x, -q.x), v = fmaf(-d.y, t, fmaf(-d.x, t, 1.0f));
+    q.y = fmaf(q.x, v, fmaf(n.y, t, u));
+    return q;
+}
+static inline xf2 expk2f(xf2 d) {
+    float u = (d.x + d.y) * XE_R_LN2f;
+    int q = (int)rintf(u);
+    float qf = (float)q;
+    xf2 s = dfadd2_f2_f(d, qf * -XE_L2Uf);
+    s = dfadd2_f2_f(s, qf * -XE_L2Lf);
+    u = u2f(0x394fb7ffu);                                             /* +0.1980960224e-3 */
+    u = fmaf(u, s.x, u2f(0x3ab6bf7cu));                               /* +0.1394256484e-2 */
+    u = fmaf(u, s.x, u2f(0x3c08890du));                               /* +0.8333456703e-2 */
+    u = fmaf(u, s.x, u2f(0x3d2aaa5cu));                               /* +0.4166637361e-1 */
+    xf2 t = dfadd2_f2_f(dfmul_f2_f(s, u), u2f(0x3e2aaaaau));          /* +0.1666666567 */
+    t = dfadd2_f2_f(dfmul_f2_f2(s, t), 0.5f);
+    t = dfadd2_f2_f2(s, dfmul_f2_f2(dfsqu_f2(s), t));
+    t = dfadd_f_f2(1.0f, t);
+    t.x = ldexp2kf(t.x, q); t.y = ldexp2kf(t.y, q);
+    if (d.x < -104.0f) { t.x = 0.0f; t.y = 0.0f; }
+    return t;
+}
+float xe_sleef_tanhf(float x) {                      /* Sleef_tanhf16_u10 */
+    float y = fabsf(x);
+    xf2 d0 = {y, 0.0f};
+    xf2 d = expk2f(d0);
+    xf2 e = dfrec_f2(d);
+    xf2 ne = {-e.x, -e.y};
+    d = dfdiv_f2_f2(dfadd_f2_f2(d, ne), dfadd_f2_f2(d, e));
+    y = d.x + d.y;
+    if (fabsf(x) > 8.664339742f || y != y) y = 1.0f;
+    y = u2f(f2u(y) ^ (f2u(x) & 0x80000000u));
+    if (x != x) y = u2f(0xffffffffu);
+    return y;
+}
+
+float xe_gelu_tanh1(float v) {                       /* ATen GeluKernelImpl, approximate = "tanh", Vectorized<float> path */
+    const float kBeta = (float)(M_SQRT2 * M_2_SQRTPI * 0.5), kKappa = (float)0.044715;
+    float cube = v * v * v;
+    float inner = kBeta * fmaf(kKappa, cube, v);
+    return 0.5f * v * (1.0f + xe_sleef_tanhf(inner));
+}
+float xe_silu1(float v) { return v / (1.0f + xe_sleef_expf(-v)); }
+
+void xe_gelu_tanh(const float* x, float* y, long n) {
+#pragma omp parallel for
+    for (long i = 0; i < n; i++) y[i] = xe_gelu_tanh1(x[i]);
+}
+void xe_silu(const float* x, float* y, long n) {
+#pragma omp parallel for
+    for (long i = 0; i < n; i++) y[i] = xe_silu1(x[i]);
+}
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * Linear in MKL's order.  x [M][K], w [N][K], bias [N] or NULL, out [M][N]
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+int xe_mkl_kblock(int K, int k0) {                   /* length of the K-block that starts at k0 */
+    if (K <= 384) return K;
+    if (K < 768) return k0 == 0 ? (K + 1) / 2 : K - k0;
+    return K - k0 < 384 ? K - k0 : 384;
+}
+
+void xe_linear(const float* x, const float* w, const float* bias, float* out, long M, int N, int K) {
+    /* wt[k][n]: lets the n loop vectorise (each lane is its own fmaf chain, the order per output element is untouched) */
+    float* wt = (float*)malloc((size_t)K * N * sizeof(float));
+    for (int n = 0; n < N; n++) for (int k = 0; k < K; k++) wt[(size_t)k * N + n] = w[(size_t)n * K + k];
+#pragma omp parallel
+    {
+        float* acc = (float*)malloc((size_t)N * sizeof(float));
+#pragma omp for schedule(static)
+        for (long m = 0; m < M; m++) {
+            const float* a = x + (size_t)m * K;
+            float* c = out + (size_t)m * N;
+            for (int n = 0; n < N; n++) c[n] = bias ? bias[n] : 0.0f;
+            for (int k0 = 0; k0 < K;) {
+                const int kb = xe_mkl_kblock(K, k0);
+                for (int n = 0; n < N; n++) acc[n] = 0.0f;
+                for (int k = k0; k < k0 + kb; k++) {
+                    const float av = a[k];
+                    const float* wr = wt + (size_t)k * N;
+#pragma omp simd
+                    for (int n = 0; n < N; n++) acc[n] = fmaf(av, wr[n], acc[n]);
+                }
+                for (int n = 0; n < N; n++) c[n] = c[n] + acc[n];
+                k0 += kb;
+            }
+        }
+        free(acc);
+    }
+    free(wt);
+}
+
+/* PatchEmbed: conv k = 2, s = 2.  x [B][C][H][W] fp32, w [OC][C][2][2], bias [OC] -> y [B][(H/2)*(W/2)][OC] (flatten(2).transpose(1,2)).
+ * `bias_first`: the chain starts from the bias (1) or from 0 with the bias added last (0). */
+void xe_patch_embed(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W, int OC, int bias_first) {
+    const int oh = H / 2, ow = W / 2;
+#pragma omp parallel for collapse(2)
+    for (int b = 0; b < B; b++)
+        for (int p = 0; p < oh * ow; p++) {
+            const int oy = p / ow, ox = p % ow;
+            for (int oc = 0; oc < OC; oc++) {
+                float acc = bias_first ? bias[oc] : 0.0f;
+                for (int kh = 0; kh < 2; kh++)
+                    for (int kw = 0; kw < 2; kw++)
+                        for (int ic = 0; ic < C; ic++)
+                            acc = fmaf(x[(((size_t)b * C + ic) * H + 2 * oy + kh) * W + 2 * ox + kw], w[(((size_t)oc * C + ic) * 2 + kh) * 2 + kw], acc);
+                y[((size_t)b * oh * ow + p) * OC + oc] = bias_first ? acc : acc + bias[oc];
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * LayerNorm (ATen): RowwiseMoments<float> with 8-lane vectors
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+#define XL 8
+typedef struct { float v[XL]; } xvec;
+static void add_moments_vec(int64_t m0_add, const xvec* m1_add, const xvec* m2_add, int64_t* m0, xvec* m1, xvec* m2) {
+    int64_t n = *m0 + m0_add;
+    float c = n == 0 ? 0.f : (float)m0_add / (float)n;
+    float m0f = (float)*m0;
+    for (int l = 0; l < XL; l++) {
+        float delta = m1_add->v[l] - m1->v[l];
+        float m2_tmp = m2->v[l] + m2_add->v[l];
+        float c_delta = c * delta;
+        float m0_delta = delta * m0f;
+        m1->v[l] = m1->v[l] + c_delta;
+        m2->v[l] = fmaf(m0_delta, c_delta, m2_tmp);
+    }
+    *m0 = n;
+}
+static void add_moments(int64_t m0_add, float m1_add, float m2_add, int64_t* m0, float* m1, float* m2) {
+    int64_t n = *m0 + m0_add;
+    float c = n == 0 ? 0.f : (float)m0_add / (float)n;
+    float delta = m1_add - *m1;
+    *m1 = fmaf(c, delta, *m1);
+    *m2 = *m2 + fmaf(delta * delta * c, (float)(*m0), m2_add);
+    *m0 = n;
+}
+void xe_rowwise_moments(const float* X, int64_t N, float* mean, float* var) {
+    const int kVec = XL, kChunk = 16;
+    int64_t n = N / kVec, m = (n + kChunk - 1) / kChunk;
+    int depth = 0; while (((int64_t)1 << depth) < m) depth++;
+    int64_t m0_stk[32]; xvec m1_stk[32], m2_stk[32];
+    memset(m0_stk, 0, sizeof m0_stk); memset(m1_stk, 0, sizeof m1_stk); memset(m2_stk, 0, sizeof m2_stk);
+    for (int64_t i = 0; i < m; i++) {
+        const float* Xp = X + i * kChunk * kVec;
+        int64_t m0 = n - i * kChunk < kChunk ? n - i * kChunk : kChunk;
+        xvec a1, a2; memset(&a1, 0, sizeof a1); memset(&a2, 0, sizeof a2);
+        for (int64_t j = 0; j < m0; j++) {
+            float cj = 1.0f / (float)(j + 1);
+            for (int l = 0; l < XL; l++) {
+                float x0 = Xp[j * kVec + l];
+                float d0 = x0 - a1.v[l];
+                a1.v[l] = fmaf(d0, cj, a1.v[l]);
+                float e0 = x0 - a1.v[l];
+                a2.v[l] = fmaf(d0, e0, a2.v[l]);
+            }
+        }
+        add_moments_vec(m0, &a1, &a2, &m0_stk[0], &m1_stk[0], &m2_stk[0]);
+        int64_t mask = i + 1;
+        for (int j = 1; j < depth && (mask & 1) == 0; ++j) {
+            add_moments_vec(m0_stk[j - 1], &m1_stk[j - 1], &m2_stk[j - 1], &m0_stk[j], &m1_stk[j], &m2_stk[j]);
+            m0_stk[j - 1] = 0; memset(&m1_stk[j - 1], 0, sizeof(xvec)); memset(&m2_stk[j - 1], 0, sizeof(xvec));
+            mask >>= 1;
+        }
+    }
+    for (int i = 1; i < depth; i++) add_moments_vec(m0_stk[i], &m1_stk[i], &m2_stk[i], &m0_stk[0], &m1_stk[0], &m2_stk[0]);
+    int64_t m0 = 0; float m1 = 0.f, m2 = 0.f;
+    for (int64_t i = n * kVec; i < N; i++) { float x = X[i], delta = x - m1; ++m0; m1 += delta / (float)m0; m2 += delta * (x - m1); }
+    for (int l = 0; l < XL; l++) add_moments(n, m1_stk[0].v[l], m2_stk[0].v[l], &m0, &m1, &m2);
+    *mean = m1; *var = m2 / (float)N;
+}
+/* y = LayerNorm(x) over the last dim N; gamma / beta may be NULL; stats (may be NULL) receives mean, rstd per row */
+void xe_layernorm(const float* X, float* Y, const float* gamma, const float* beta, long rows, int N, float eps, float* stats) {
+#pragma omp parallel for
+    for (long r = 0; r < rows; r++) {
+        float mean, var; xe_rowwise_moments(X + (size_t)r * N, N, &mean, &var);
+        float rstd = 1.0f / sqrtf(fmaxf(var, 0.f) + eps);
+        if (stats) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+        for (int j = 0; j < N; j++) {
+            float t = (X[(size_t)r * N + j] + -mean) * rstd;
+            Y[(size_t)r * N + j] = fmaf(t, gamma ? gamma[j] : 1.0f, beta ? beta[j] : 0.0f);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * attention (ATen cpu_flash_attention, fp32)
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+float xe_exp_u20(float x) {                          /* Vectorized<float>::exp_u20, vec512_float.h */
+    const float f1 = 0.999999701f, f2 = 0.499991506f, f3 = 0.166676521f, f4 = 0.0418978221f, f5 = 0.00828929059f;
+    const float log2e = u2f(0x3fb8aa3b), ln2f = u2f(0x3f317218), lmin = u2f(0xc2aeac50), lmax = u2f(0x42b17218);
+    float src = x < lmax ? x : lmax;
+    src = src > lmin ? src : lmin;
+    float fx = floorf(fmaf(src, log2e, 0.5f));
+    float r = fmaf(-fx, ln2f, src);
+    float res = fmaf(r, f5, f4); res = fmaf(r, res, f3); res = fmaf(r, res, f2); res = fmaf(r, res, f1); res = fmaf(r, res, 1.0f);
+    int n1 = (int)rintf(fx - 1.0f);
+    float two = u2f((uint32_t)(n1 + 127) << 23);
+    if (x < lmin) two = 0.0f;
+    res = res * two;
+    return res * 2.0f;
+}
+
+static const uint64_t EXP2F_T[32] = {
+    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b, 0x3fef54873168b9aa,
+    0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d,
+    0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429, 0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74,
+    0x3feea11473eb0187, 0x3feea589994cce13, 0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d,
+    0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
+    0x3fefa4afa2a490da, 0x3fefd0765b6e4540};
+float xe_expf(float x) {                             /* glibc 2.35 expf = std::exp(float) in the flash kernel's rescale */
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32, Shift = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+    if (x != x) return x;
+    if (x > 0x1.62e42ep6f) return INFINITY;
+    if (x < -0x1.9fe368p6f) return 0.f;
+    double xd = (double)x, z = InvLn2N * xd, kd = z + Shift;
+    uint64_t ki; memcpy(&ki, &kd, 8);
+    kd -= Shift;
+    double r = z - kd;
+    uint64_t t = EXP2F_T[ki % 32] + (ki << 47);
+    double s; memcpy(&s, &t, 8);
+    double zz = fma(C0, r, C1), r2 = r * r, y = fma(C2, r, 1.0);
+    y = fma(zz, r2, y);
+    return (float)(y * s);
+}
+
+/* q [B][Tq][*] with row stride qs, head h at column h*D; k, v likewise with Tk rows; a second key/value segment (k2, v2: Tk2 rows, may
+ * be NULL) follows the first (`torch.cat([k, query_k], dim=2)`, modules.py:250-251).  out [B][Tq][H*D] (the transpose(1,2).reshape of
+ * the reference).  kv blocks of 512 run across the concatenation. */
+void xe_attention(const float* Q, long qs, const float* K1, const float* V1, long kvs1, int Tk1, const float* K2, const float* V2, long kvs2,
+                  int Tk2, float* O, int B, int H, int Tq, int D) {
+    const float scale = (float)(1.0 / sqrt((double)D));
+    const int Tk = Tk1 + Tk2, kvsplit = 512;
+#pragma omp parallel for collapse(3) schedule(dynamic, 8)
+    for (int b = 0; b < B; b++)
+        for (int h = 0; h < H; h++)
+            for (int i = 0; i < Tq; i++) {
+                const float* q = Q + ((size_t)b * Tq + i) * qs + h * D;
+                float s[512], p[512], dst[128];
+                float m_old = -INFINITY, sum_old = 0.f;
+                for (int n0 = 0; n0 < Tk; n0 += kvsplit) {
+                    const int nb = Tk - n0 < kvsplit ? Tk - n0 : kvsplit;
+                    float bm = -INFINITY;
+                    for (int j = 0; j < nb; j++) {
+                        const int t = n0 + j;
+                        const float* kr = t < Tk1 ? K1 + ((size_t)b * Tk1 + t) * kvs1 + h * D : K2 + ((size_t)b * Tk2 + (t - Tk1)) * kvs2 + h * D;
+                        float c = 0.f;
+                        for (int k = 0; k < D; k++) c = fmaf(q[k], kr[k], c);
+                        s[j] = c * scale;
+                        if (s[j] > bm) bm = s[j];
+                    }
+                    const float m_new = m_old > bm ? m_old : bm;
+                    float lane[16];
+                    for (int l = 0; l < 16; l++) lane[l] = 0.f;
+                    for (int j = 0; j < nb; j++) { float e = xe_exp_u20(s[j] - m_new); lane[j % 16] += e; p[j] = e; }
+                    for (int st = 8; st >= 1; st /= 2) for (int l = 0; l < st; l++) lane[l] = lane[l] + lane[l + st];
+                    const float exp_tmp = xe_expf(m_old - m_new);
+                    sum_old = fmaf(exp_tmp, sum_old, lane[0]);
+                    m_old = m_new;
+                    for (int d = 0; d < D; d++) {
+                        float c = n0 > 0 ? dst[d] * exp_tmp : 0.f;
+                        for (int j0 = 0; j0 < nb;) {
+                            const int kb = xe_mkl_kblock(nb, j0);
+                            float acc = 0.f;
+                            for (int j = j0; j < j0 + kb; j++) {
+                                const int t = n0 + j;
+                                const float vv = t < Tk1 ? V1[((size_t)b * Tk1 + t) * kvs1 + h * D + d] : V2[((size_t)b * Tk2 + (t - Tk1)) * kvs2 + h * D + d];
+                                acc = fmaf(p[j], vv, acc);
+                            }
+                            c = c + acc;
+                            j0 += kb;
+                        }
+                        dst[d] = c;
+                    }
+                }
+                const float rs = 1.0f / sum_old;
+                for (int d = 0; d < D; d++) O[((size_t)b * Tq + i) * (H * D) + h * D + d] = dst[d] * rs;
+            }
+}

@@ -51,9 +51,15 @@ class _Quantizer:
 
 class QformerEncoderGPU(ModuleSurface):
     _sd_prefix = "encoder."
-    def __init__(self, sd: Dict[str, torch.Tensor], device, K: int):
+    def __init__(self, sd: Dict[str, torch.Tensor], device, K: int, mode: str = "exact"):
+        """`mode`: 'exact' (default) -- every reduction / transcendental in the summation order torch-CPU executes for the reference
+        (csrc/encoder_exact.hip): the pre-quantizer features, and with them the token ids, are the reference's bit for bit and do not
+        depend on the batch size; 'fast' -- hipBLASLt GEMMs + the rounds 1-3 fused kernels (features within 6e-5, ids equal except
+        at reference near-ties, ~2x faster encoder)."""
         g = lambda k: sd[k].to(device=device, dtype=torch.float32).contiguous()
-        self.device, self.K = device, K
+        if mode not in ("exact", "fast"):
+            raise ValueError(f"encoder mode {mode!r}: expected 'exact' or 'fast'")
+        self.device, self.K, self.mode = device, K, mode
         self.post_norm = True
         self.w = {k: g(k) for k in sd if k.startswith("encoder.") and "_codebook" not in k and "quantizer.c" not in k and "quantizer.s" not in k}
         self.codebook = g("encoder.quantizer._codebook.embed")[0].contiguous()
@@ -64,11 +70,17 @@ class QformerEncoderGPU(ModuleSurface):
         # input-independent adaLN tables: Linear(SiLU(t_embedder(1000+8k)))  [K, 6*512] per block
         pos_emb = sinusoid_host(torch.from_numpy(DiTiCont.get_position(np.arange(K))).to(torch.int64)).to(device)
         self.tables = []
+        lin = ops.ex_linear if mode == "exact" else F.linear
+        silu = (lambda t: ops.ex_unary(t.contiguous(), "silu")) if mode == "exact" else ops.silu
         for i in range(ENC_DEPTH):
             p = f"encoder.blocks.{i}"
-            h = F.linear(pos_emb, self.w[p + ".t_embedder.mlp.0.weight"], self.w[p + ".t_embedder.mlp.0.bias"])
-            h = F.linear(ops.silu(h), self.w[p + ".t_embedder.mlp.2.weight"], self.w[p + ".t_embedder.mlp.2.bias"])
-            self.tables.append(F.linear(ops.silu(h), self.w[p + ".adaLN_modulation.1.weight"], self.w[p + ".adaLN_modulation.1.bias"]).contiguous())
+            h = lin(pos_emb, self.w[p + ".t_embedder.mlp.0.weight"], self.w[p + ".t_embedder.mlp.0.bias"])
+            h = lin(silu(h), self.w[p + ".t_embedder.mlp.2.weight"], self.w[p + ".t_embedder.mlp.2.bias"])
+            self.tables.append(lin(silu(h), self.w[p + ".adaLN_modulation.1.weight"], self.w[p + ".adaLN_modulation.1.bias"]).contiguous())
+        # exact mode: the PatchEmbed convolution as ONE 64-tap chain in (kh, kw, ic) order = a Linear over the re-ordered patch
+        # (oracle/encoder_exact.c); ops.patchify emits (ic, kh, kw)
+        self.pe_w_exact = self.w["encoder.x_embedder.proj.weight"].permute(0, 2, 3, 1).reshape(ENC_HIDDEN, -1).contiguous()
+        self._pe_perm = torch.arange(64, device=device).reshape(16, 2, 2).permute(1, 2, 0).reshape(-1)
         self.quantizer = _Quantizer(self)
 
     def _flat_weights(self):
@@ -104,9 +116,51 @@ class QformerEncoderGPU(ModuleSurface):
         return (ar == d.unsqueeze(1)) if single_token else (ar <= d.unsqueeze(1))
 
     # ---- forward -------------------------------------------------------------------------------
+    def _pos_only(self, h: int, w: int) -> torch.Tensor:
+        """centre-cropped sin-cos table WITHOUT the conv bias (exact mode adds the bias inside the Linear, then the table: two roundings) -> [h*w, 64]"""
+        key = ("pos", h, w)
+        if key not in self._pos_cache:
+            pe = self.w["encoder.pos_embed"]
+            grid = int(round(math.sqrt(pe.shape[1])))
+            top, left = (grid - h) // 2, (grid - w) // 2
+            self._pos_cache[key] = pe.reshape(grid, grid, -1)[top:top + h, left:left + w].reshape(h * w, -1).contiguous()
+        return self._pos_cache[key]
+
+    @torch.no_grad()
+    def features_exact(self, x0: torch.Tensor) -> torch.Tensor:
+        """`features` with every operation in the order / polynomial torch-CPU executes for the reference (models_ours.py:204-257,
+        modules.py:216-327): z equals the reference's pre-quantizer features bit for bit (tests/golden/encode_b64.npz, pipeline_b16.npz)."""
+        B, _, Hh, Ww = x0.shape
+        H, Q, K = ENC_HIDDEN, ENC_QDIM, self.K
+        w = self.w
+        lin = lambda name, t, **kw: ops.ex_linear(t, w[name + ".weight"], w[name + ".bias"], **kw)
+        patch = ops.patchify(x0)[..., self._pe_perm].contiguous()            # [B, N, 64] in (kh, kw, ic) order
+        N = patch.shape[1]
+        x = ops.ex_linear(patch, self.pe_w_exact, w["encoder.x_embedder.proj.bias"], res=self._pos_only(Hh // 2, Ww // 2), res_mod=N)
+        q = w["encoder.query_tokens"].expand(B, -1, -1).contiguous()
+        for i in range(ENC_DEPTH):
+            p = f"encoder.blocks.{i}"
+            t = self.tables[i]
+            xn = ops.ex_layernorm_mod(x)
+            qn = ops.ex_layernorm_mod(q, shift=t[:, 0:Q], scale=t[:, Q:2 * Q])
+            qkv = lin(p + ".attn.qkv", xn)                          # [B,N,3*64]
+            kvx = lin(p + ".attn.to_query_kv", xn)                  # [B,N,2*512]
+            qq = lin(p + ".attn.query_linear", qn)                  # [B,K,3*512]
+            xa = ops.ex_attention(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], ENC_HEADS)
+            qa = ops.ex_attention(qq[..., :Q], kvx[..., :Q], kvx[..., Q:], ENC_QHEADS, qq[..., Q:2 * Q], qq[..., 2 * Q:])
+            x = lin(p + ".attn.proj", xa, res=x)                                            # x + proj(attn)
+            h = lin(p + ".mlp.fc1", ops.ex_layernorm_mod(x), gelu=True)
+            x = lin(p + ".mlp.fc2", h, res=x)                                               # x + mlp(LN(x))
+            q = lin(p + ".attn.query_proj", qa, res=q, gate=t[:, 2 * Q:3 * Q], gate_mod=K)   # q + g1 * proj(attn_q)
+            h = lin(p + ".q_mlp.fc1", ops.ex_layernorm_mod(q, shift=t[:, 3 * Q:4 * Q], scale=t[:, 4 * Q:5 * Q]), gelu=True)
+            q = lin(p + ".q_mlp.fc2", h, res=q, gate=t[:, 5 * Q:6 * Q], gate_mod=K)          # q + g2 * mlp_q(mod(LN(q)))
+        return lin("encoder.quantizer.project_in", q)
+
     @torch.no_grad()
     def features(self, x0: torch.Tensor) -> torch.Tensor:
         """x0 [B,16,h,w] fp32 -> pre-quantizer features z [B,K,16] (incl. quantizer.project_in)"""
+        if self.mode == "exact":
+            return self.features_exact(x0)
         B, _, Hh, Ww = x0.shape
         H, Q, K = ENC_HIDDEN, ENC_QDIM, self.K
         x = torch.matmul(ops.patchify(x0), self.pe_w)

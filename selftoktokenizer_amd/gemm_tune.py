@@ -18,7 +18,7 @@ then raises inside the probing `F.linear` (`TORCH_CHECK(iter != ops_.end())`, no
 support the shape.  So: when `torch.cuda.tunable.get_validators()` differs from `FOUND_WITH`, `autotune_linears` does nothing and says
 so; and every probe runs under try/except, a candidate that fails is dropped (and its key withdrawn by a default-kernel entry).
 
-OPT-IN (`SelftokPipeline(..., tune_gemm=True)`, `pipe.tune_linears(batch)`, or SELFTOK_TUNE_GEMM=1; bench.py asks for it).  Process state:
+OPT-IN (`SelftokPipeline(..., tune_gemm=True)` or `pipe.tune_linears(batch)`; bench.py asks for it).  Process state:
 TunableOp is only enabled (tuning OFF) inside `enabled()` blocks -- the pipeline wraps its own sampler calls in one -- and the caller's
 `torch.cuda.tunable` enabled / tuning flags are restored on exit; TunableOp's results file name points into the temp dir unless the caller had set
 one ($PYTORCH_TUNABLEOP_FILENAME).  The entries themselves stay in TunableOp's in-memory table for the process: keys of THIS model's Linear shapes only.  The

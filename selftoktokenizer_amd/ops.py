@@ -722,3 +722,87 @@ def vx_expf(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty_like(x)
     _lib.check(_lib.load().selftok_vx_expf_f32(_p(x), _p(y), x.numel(), _stream()), "selftok_vx_expf_f32")
     return y
+
+
+# ----------------------------------------------------------------------------------------------
+# the fp32 Q-Former encoder in the reference's exact summation orders (csrc/encoder_exact.hip)
+# ----------------------------------------------------------------------------------------------
+
+def _rows2d(t: torch.Tensor):
+    """a [..., C] fp32 tensor whose rows are equally strided (contiguous, or a column slice of a contiguous fused projection) -> (rows, row stride)"""
+    assert t.dtype == torch.float32 and t.stride(-1) == 1
+    ld = t.stride(-2) if t.dim() > 1 else t.shape[-1]
+    rows = t.numel() // t.shape[-1]
+    for d in range(t.dim() - 2, 0, -1):                              # leading dims must step by whole row blocks
+        assert t.stride(d - 1) == t.stride(d) * t.shape[d], "rows are not equally strided"
+    return rows, ld
+
+
+def ex_linear(x: torch.Tensor, weight: torch.Tensor, bias=None, *, gelu: bool = False, res=None, res_mod: int = 0, gate=None, gate_mod: int = 0,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F.linear in MKL sgemm's summation order (bit-equal to torch-CPU's nn.Linear for M >= 512 rows), optional exact GELU(tanh),
+    optional `res + gate * y` epilogue (res / gate rows taken modulo res_mod / gate_mod when non-zero: per-token tables)."""
+    _need_cuda(x, weight, bias, res, gate)
+    N, K = weight.shape
+    assert weight.dtype == torch.float32 and weight.is_contiguous() and x.shape[-1] == K
+    M, ldx = _rows2d(x)
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() or out.stride(-1) == 1
+    _, ldo = _rows2d(out)
+    ldr = _rows2d(res)[1] if res is not None else 0
+    ldg = _rows2d(gate)[1] if gate is not None else 0
+    _lib.check(_lib.load().selftok_ex_linear_f32(_p(x), ldx, _p(weight), _p(bias), _p(res), ldr, int(res_mod), _p(gate), ldg, int(gate_mod), _p(out), ldo,
+                                                 M, N, K, int(gelu), _stream()), "selftok_ex_linear_f32")
+    return out
+
+
+def ex_layernorm_mod(x: torch.Tensor, shift=None, scale=None, gamma=None, beta=None, eps: float = 1e-6, want_stats: bool = False):
+    """nn.LayerNorm in ATen's arithmetic, then `* (1 + scale[tok]) + shift[tok]` (tok = row % T; shift / scale [T, N] views, equal row stride)"""
+    _need_cuda(x, shift, scale, gamma, beta)
+    N = x.shape[-1]
+    rows, ldx = _rows2d(x)
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    T, ldt = 0, 0
+    if shift is not None:
+        assert scale is not None and shift.dim() == 2 and shift.shape == scale.shape and shift.stride(0) == scale.stride(0) and shift.stride(1) == 1 == scale.stride(1)
+        T, ldt = shift.shape[0], shift.stride(0)
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    _lib.check(_lib.load().selftok_ex_layernorm_mod_f32(_p(x), ldx, _p(out), N, _p(shift), _p(scale), ldt, T, _p(gamma), _p(beta), _p(stats), rows, N, float(eps),
+                                                        _stream()), "selftok_ex_layernorm_mod_f32")
+    return (out, stats) if want_stats else out
+
+
+EX_UNARY = {"gelu_tanh": 0, "silu": 1, "sleef_expf": 2, "sleef_tanhf": 3, "exp_u20": 4}
+
+
+def ex_unary(x: torch.Tensor, kind: str) -> torch.Tensor:
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().selftok_ex_unary_f32(_p(x), _p(y), x.numel(), EX_UNARY[kind], _stream()), "selftok_ex_unary_f32")
+    return y
+
+
+def ex_attention(q: torch.Tensor, k1: torch.Tensor, v1: torch.Tensor, heads: int, k2=None, v2=None) -> torch.Tensor:
+    """F.scaled_dot_product_attention (no mask) as ATen's fp32 CPU flash kernel evaluates it.  q [B,Tq,H*D], k1 / v1 [B,Tk1,H*D] and an
+    optional second key / value segment that follows the first; all may be column slices of fused projections.  -> [B,Tq,H*D]"""
+    _need_cuda(q, k1, v1, k2, v2)
+    B, Tq, HD = q.shape
+    D = HD // heads
+    _, qs = _rows2d(q)
+    _, ks1 = _rows2d(k1)
+    assert _rows2d(v1)[1] == ks1 and k1.shape == v1.shape
+    Tk1 = k1.shape[1]
+    Tk2, ks2 = 0, 0
+    if k2 is not None:
+        Tk2, ks2 = k2.shape[1], _rows2d(k2)[1]
+        assert _rows2d(v2)[1] == ks2 and k2.shape == v2.shape
+    lib = _lib.load()
+    out = torch.empty(B, Tq, HD, dtype=torch.float32, device=q.device)
+    if B == 0:
+        return out
+    ws = torch.empty(lib.selftok_ex_attention_workspace_bytes(B, heads, Tq, Tk1 + Tk2, D), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.selftok_ex_attention_f32(_p(q), qs, _p(k1), _p(v1), ks1, Tk1, _p(k2), _p(v2), ks2, Tk2, _p(out), _p(ws), B, heads, Tq, D, _stream()),
+               "selftok_ex_attention_f32")
+    return out

@@ -12,8 +12,6 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
-import os
-
 import numpy as np
 import torch
 
@@ -159,23 +157,27 @@ class SelftokPipeline():
     def __init__(self, cfg, ckpt_path, sd3_path, datasize=256, start=1.0, cfg_scale=1, model_type='sd3',
                  dtype=torch.bfloat16, ema_decoder=False, device=None, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, verbose: bool = True, gemm: Optional[str] = None,
-                 vae_mode: Optional[str] = None, tune_gemm: Optional[bool] = None):
+                 vae_mode: Optional[str] = None, tune_gemm: Optional[bool] = None, encoder_mode: Optional[str] = None):
         """cfg: parse_args_from_yaml(...) ; ckpt_path: tokenizer .pth ; sd3_path: diffusers SD3 folder (…/vae/…).
         `state_dict` / `vae_state_dict` (extensions) bypass the files, e.g. with weights.synthetic_state_dict().
         `gemm` (extension): arithmetic of the MMDiT block Linears, 'fp32' (hipBLASLt fp32) or 'f16x2' (fp32-equivalent
-        split GEMM on the f16 matrix cores, csrc/gemm_split.hip); default from $SELFTOK_GEMM, else DEFAULT_GEMM.
+        split GEMM on the f16 matrix cores, csrc/gemm_split.hip); default DEFAULT_GEMM.
         `vae_mode` (extension): 'exact' (default at datasize 256: the encoder reproduces the summation ORDER of every reduction of the
         reference's torch-CPU run, csrc/vae_exact.hip -- latents and token ids from pixels equal the reference's bit for bit; decoder as
         'parity'), 'parity' (default otherwise: every convolution / GroupNorm through csrc/conv.hip -- fp32 accumulation with the
         bias inside, one rounding, the reference's CPU arithmetic; no MIOpen, bit-stable, batch independent), 'miopen' (the same
         arithmetic coaxed out of MIOpen's GEMM algorithm, 3x slower) or 'fast' (MIOpen's searched solvers with a separate bias add:
-        looser parity, not bit-stable; see vae.AutoencoderKLGPU); default from $SELFTOK_VAE.
+        looser parity, not bit-stable; see vae.AutoencoderKLGPU).
+        `encoder_mode` (extension): 'exact' (default: the Q-Former encoder in the summation order of every reduction and the polynomial of every
+        transcendental torch-CPU executes for the reference, csrc/encoder_exact.hip -- pre-quantizer features and token ids equal the reference's
+        bit for bit at every batch size) or 'fast' (hipBLASLt GEMMs + the fused rounds 1-3 kernels: features within 6e-5, ~2x faster encoder).
+        No environment variable is read: every knob is a constructor argument.
         `tune_gemm` (extension, OPT-IN): pick hipBLASLt's kernel for the fp32 block Linears by a ~4 s measurement per batch size
         (gemm_tune.py) -- up front through `pipe.tune_linears(batch)`, or at the first decode of a batch size.  TunableOp is enabled
         (tuning off) only inside this pipeline's own sampler calls and the caller's torch.cuda.tunable flags are restored; on another
-        hipBLASLt build than the one the candidate kernels were found with it does nothing, loudly.  Default from $SELFTOK_TUNE_GEMM, else off."""
+        hipBLASLt build than the one the candidate kernels were found with it does nothing, loudly.  Default off."""
         _lib.load()                                                           # fail loudly if the HIP library is missing
-        self.tune_gemm = (os.environ.get("SELFTOK_TUNE_GEMM", "0") == "1") if tune_gemm is None else bool(tune_gemm)
+        self.tune_gemm = bool(tune_gemm)
         self.gemm_tune_report = None
         if device is None:
             device = "cuda"
@@ -190,9 +192,9 @@ class SelftokPipeline():
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         with torch.cuda.device(self.device):                                  # our launches use the current device's stream
-            self._build(cfg, ckpt_path, sd3_path, start, cfg_scale, dtype, ema_decoder, state_dict, vae_state_dict, verbose, gemm, vae_mode)
+            self._build(cfg, ckpt_path, sd3_path, start, cfg_scale, dtype, ema_decoder, state_dict, vae_state_dict, verbose, gemm, vae_mode, encoder_mode)
 
-    def _build(self, cfg, ckpt_path, sd3_path, start, cfg_scale, dtype, ema_decoder, state_dict, vae_state_dict, verbose, gemm, vae_mode=None):
+    def _build(self, cfg, ckpt_path, sd3_path, start, cfg_scale, dtype, ema_decoder, state_dict, vae_state_dict, verbose, gemm, vae_mode=None, encoder_mode=None):
         p = cfg.tokenizer.params
         p.noise_schedule_config.is_eval = cfg.common.is_eval
         # configuration knobs the reference honours but this hot path does not implement: refuse, never ignore silently
@@ -216,7 +218,7 @@ class SelftokPipeline():
 
         vsd = vae_state_dict if vae_state_dict is not None else W.load_vae_checkpoint(sd3_path)
         W.check_vae_state_dict(vsd)
-        self.vae = AutoencoderKLGPU(vsd, self.device, dtype, mode=vae_mode or os.environ.get("SELFTOK_VAE") or ("exact" if int(self.datasize) == 256 else "parity"))
+        self.vae = AutoencoderKLGPU(vsd, self.device, dtype, mode=vae_mode or ("exact" if int(self.datasize) == 256 else "parity"))
 
         self.verbose = verbose
         self._say("Loading all...")
@@ -226,9 +228,9 @@ class SelftokPipeline():
         dit_sd = sd
         if ema_decoder:   # reference :193-194: EMA copy of the DiT under 'ema_state_dict' (keys without the 'model.' prefix)
             dit_sd = {"model." + k: v for k, v in sd["ema_state_dict"].items()}       # strict contract checked above: bare MMDiT keys only
-        encoder = QformerEncoderGPU(sd, self.device, K)
+        encoder = QformerEncoderGPU(sd, self.device, K, mode=encoder_mode or "exact")
         dit = MMDiTGPU(dit_sd, self.device, K, renderer=renderer)
-        dit.set_gemm(gemm or os.environ.get("SELFTOK_GEMM") or DEFAULT_GEMM)
+        dit.set_gemm(gemm or DEFAULT_GEMM)
         self.model = _Tokenizer(encoder, dit, self.diti)
 
         self.count = 0

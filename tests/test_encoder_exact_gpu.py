@@ -1,0 +1,178 @@
+"""-m gpu: csrc/encoder_exact.hip against its bit-for-bit CPU twin oracle/encoder_exact.c (itself pinned on the CPU to torch's own
+fp32 ops and, end to end, to the pre-quantizer features of the REFERENCE pipeline runs: tests/test_encoder_exact_cpu.py), and the
+whole encoder against the reference's goldens.  Everything here is BIT-EXACT: a single differing fp32 element fails."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder_exact as EX
+from selftoktokenizer_amd import ops, synth, weights as W
+from selftoktokenizer_amd.schedule import DiTiCont
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _same(gpu: torch.Tensor, ref: np.ndarray, what: str, allow_nan_payload: bool = False):
+    g = gpu.detach().cpu().numpy()
+    assert g.shape == ref.shape, (g.shape, ref.shape)
+    bad = g.view(np.uint32) != ref.view(np.uint32)
+    bad &= ~((g == 0) & (ref == 0))                       # +0 / -0: equal values (torch's own kernels differ in the sign of an exact zero)
+    if allow_nan_payload:
+        bad &= ~(np.isnan(g) & np.isnan(ref))
+    n = int(bad.sum())
+    if n:
+        i = np.argwhere(bad)[0]
+        raise AssertionError(f"{what}: {n} of {g.size} fp32 elements differ from the oracle; first at {tuple(i)}: {g[tuple(i)]!r} vs {ref[tuple(i)]!r}")
+
+
+def _rand(seed, shape, scale=1.0, shift=0.0):
+    return (synth.hash_normalish(seed, shape) * scale + shift).float().contiguous()
+
+
+# ---- transcendental building blocks ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,cname", [("gelu_tanh", "xe_gelu_tanh1"), ("silu", "xe_silu1"), ("sleef_expf", "xe_sleef_expf"), ("sleef_tanhf", "xe_sleef_tanhf"),
+                                         ("exp_u20", "xe_exp_u20")])
+def test_unary_bit_patterns(kind, cname):
+    """2^22 evenly spaced fp32 bit patterns (every exponent, both signs, inf / NaN) + a dense sweep of the working range"""
+    bits = np.concatenate([np.arange(0, 2 ** 32, 2 ** 10, dtype=np.uint64).astype(np.uint32),
+                           np.linspace(-12, 12, 1 << 20, dtype=np.float32).view(np.uint32),
+                           np.array([0, 0x80000000, 0x7f800000, 0xff800000, 0x7fc00000, 0x00000001, 0x80000001, 0x7f7fffff, 0xff7fffff], dtype=np.uint32)])
+    x = np.ascontiguousarray(bits.view(np.float32))
+    fn = getattr(EX.lib(), cname)
+    ref = np.array([fn(float(v)) for v in x[::64]], dtype=np.float32)            # ctypes scalar calls: a 1/64 sample ...
+    out = ops.ex_unary(torch.from_numpy(x).cuda(), kind)
+    torch.cuda.synchronize()
+    _same(out[::64], ref, kind + " (scalar sample)", allow_nan_payload=True)
+    if kind in ("gelu_tanh", "silu"):                                            # ... and everything through the vectorised entry points
+        full = EX.gelu_tanh(x) if kind == "gelu_tanh" else EX.silu(x)
+        _same(out, full, kind, allow_nan_payload=True)
+
+
+# ---- Linear in MKL's order ------------------------------------------------------------------------------------------------------
+LINEARS = [("attn.qkv 64->192", 64, 192), ("to_query_kv 64->1024", 64, 1024), ("query_linear 512->1536", 512, 1536), ("proj 64->64", 64, 64),
+           ("mlp.fc1 64->256", 64, 256), ("mlp.fc2 256->64", 256, 64), ("query_proj 512->512", 512, 512), ("q_mlp.fc1 512->2048", 512, 2048),
+           ("q_mlp.fc2 2048->512", 2048, 512), ("project_in 512->16", 512, 16), ("t_embedder 256->512", 256, 512), ("adaLN 512->3072", 512, 3072)]
+
+
+@pytest.mark.parametrize("name,K,N", LINEARS, ids=[c[0] for c in LINEARS])
+def test_linear_mkl_order(name, K, N):
+    M = 1024
+    x = _rand(0xE0 + K, (M, K), 1.2, 0.05)
+    w = _rand(0xE1 + N, (N, K), (1.0 / K) ** 0.5)
+    b = _rand(0xE2, (N,), 0.2)
+    ref = EX.linear(x.numpy(), w.numpy(), b.numpy())
+    out = ops.ex_linear(x.cuda(), w.cuda(), b.cuda())
+    torch.cuda.synchronize()
+    _same(out, ref, name)
+
+
+def test_linear_epilogues_and_views():
+    """GELU, `res + gate * y` with per-token tables, a column slice of a fused projection as input, rows not a multiple of the tile"""
+    M, K, N, T = 2 * 512 + 64, 512, 2048, 512
+    x3 = _rand(0xF0, (M, 3 * K), 1.1)
+    w = _rand(0xF1, (N, K), (1.0 / K) ** 0.5)
+    b = _rand(0xF2, (N,), 0.2)
+    xs = x3[:, K:2 * K]
+    ref = EX.gelu_tanh(EX.linear(np.ascontiguousarray(xs.numpy()), w.numpy(), b.numpy()))
+    out = ops.ex_linear(x3.cuda()[:, K:2 * K], w.cuda(), b.cuda(), gelu=True)
+    _same(out, ref, "fc1 + GELU on a column slice")
+    w2 = _rand(0xF3, (K, N), (1.0 / N) ** 0.5)
+    b2 = _rand(0xF4, (K,), 0.2)
+    res = _rand(0xF5, (M, K))
+    table = _rand(0xF6, (T, 6 * K), 0.7)
+    y = EX.linear(ref, w2.numpy(), b2.numpy())
+    gate = table[:, 5 * K:6 * K].numpy()
+    ref2 = res.numpy() + gate[np.arange(M) % T] * y
+    out2 = ops.ex_linear(out, w2.cuda(), b2.cuda(), res=res.cuda(), gate=table.cuda()[:, 5 * K:6 * K], gate_mod=T)
+    _same(out2, ref2, "q + gate * fc2(h)")
+    ref3 = res.numpy() + y
+    out3 = ops.ex_linear(out, w2.cuda(), b2.cuda(), res=res.cuda())
+    torch.cuda.synchronize()
+    _same(out3, ref3, "x + fc2(h)")
+
+
+# ---- LayerNorm -------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,affine,mod", [(64, False, False), (512, False, True), (16, True, False), (1536, False, True)])
+def test_layernorm_aten_order(N, affine, mod):
+    rows, T = 3 * 512, 512
+    x = _rand(0xA0 + N, (rows, N), 2.0, 0.3)
+    g = _rand(0xA1, (N,), 0.1, 1.0) if affine else None
+    b = _rand(0xA2, (N,), 0.1) if affine else None
+    ref, st = EX.layernorm(x.numpy(), None if g is None else g.numpy(), None if b is None else b.numpy(), want_stats=True)
+    table = _rand(0xA3, (T, 6 * N), 0.5)
+    if mod:
+        sh, sc = table[:, 3 * N:4 * N].numpy(), table[:, 4 * N:5 * N].numpy()
+        ref = ref * (np.float32(1) + sc[np.arange(rows) % T]) + sh[np.arange(rows) % T]
+    tc = table.cuda()
+    out, stats = ops.ex_layernorm_mod(x.cuda(), shift=tc[:, 3 * N:4 * N] if mod else None, scale=tc[:, 4 * N:5 * N] if mod else None,
+                                      gamma=None if g is None else g.cuda(), beta=None if b is None else b.cuda(), want_stats=True)
+    torch.cuda.synchronize()
+    _same(stats, st, f"LayerNorm({N}) mean / rstd")
+    _same(out, ref, f"LayerNorm({N})")
+
+
+# ---- attention -------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,B,H,Tq,Tk1,Tk2,D", [("latent self-attention 4 x 16", 2, 4, 256, 256, 0, 16), ("query attention 8 x 64, 256 + 512 keys", 2, 8, 512, 256, 512, 64),
+                                                  ("K = 1024 tokenizer: 256 + 1024 keys", 1, 8, 1024, 256, 1024, 64), ("128 px: 64 + 512 keys", 1, 8, 512, 64, 512, 64)])
+def test_attention_flash_order(name, B, H, Tq, Tk1, Tk2, D):
+    HD = H * D
+    qq = _rand(0xB0 + Tq, (B, Tq, 3 * HD), 1.4)                     # fused projections, as the encoder holds them
+    kvx = _rand(0xB1 + Tk1, (B, Tk1, 2 * HD), 1.4)
+    if Tk2:
+        ref = EX.attention(qq[..., :HD].numpy(), kvx[..., :HD].numpy(), kvx[..., HD:].numpy(), H, qq[:, :Tk2, HD:2 * HD].numpy(), qq[:, :Tk2, 2 * HD:].numpy())
+        qc, kc = qq.cuda(), kvx.cuda()
+        out = ops.ex_attention(qc[..., :HD], kc[..., :HD], kc[..., HD:], H, qc[:, :Tk2, HD:2 * HD], qc[:, :Tk2, 2 * HD:])
+    else:
+        ref = EX.attention(qq[..., :HD].numpy(), qq[..., HD:2 * HD].numpy(), qq[..., 2 * HD:].numpy(), H)
+        qc = qq.cuda()
+        out = ops.ex_attention(qc[..., :HD], qc[..., HD:2 * HD], qc[..., 2 * HD:], H)
+    torch.cuda.synchronize()
+    _same(out, ref, name)
+
+
+# ---- the whole encoder against the REFERENCE's own runs --------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def encoder():
+    from selftoktokenizer_amd.encoder import QformerEncoderGPU
+    shapes = {k: v for k, v in W.expected_shapes(512).items() if k.startswith("encoder.")}
+    return QformerEncoderGPU(W.synthetic_state_dict(shapes), torch.device("cuda", torch.cuda.current_device()), 512, mode="exact")
+
+
+def test_sinusoid_tables_host_independent():
+    """the position tables are evaluated on the HOST with torch-CPU's cos / sin / exp (the reference's own arithmetic): their bits on this
+    box must be the ones of the build container (the crc below), or 'bit-exact' would depend on the machine"""
+    import zlib
+    from selftoktokenizer_amd.encoder import sinusoid_host
+    t = sinusoid_host(torch.from_numpy(DiTiCont.get_position(np.arange(512))).to(torch.int64)).numpy()
+    assert zlib.crc32(np.ascontiguousarray(t).tobytes()) == SINUSOID_CRC, hex(zlib.crc32(np.ascontiguousarray(t).tobytes()))
+
+
+SINUSOID_CRC = 0x9fb366ff        # torch 2.10 CPU, build container (AVX-512 Xeon)
+
+
+def test_features_equal_reference_16_images(encoder):
+    g = np.load(os.path.join(GOLD, "pipeline_b16.npz"))
+    x0 = torch.from_numpy(g["x0_bf16"]).view(torch.bfloat16).float().cuda()
+    z = encoder.features(x0)
+    torch.cuda.synchronize()
+    _same(z, g["z"], "pre-quantizer features vs the reference pipeline's 16-image run")
+    ids = encoder(x0)[1].cpu().numpy()
+    assert np.array_equal(ids, g["tokens"].astype(np.int64))
+
+
+def test_features_and_ids_equal_reference_64_images_and_batch_invariance(encoder):
+    """BASELINE configs[1]'s batch: the reference's `encoding` on 64 images in ONE batch (tests/golden/encode_b64.npz): features bit-equal,
+    ids 32768 / 32768; the same 64 latents as 4 x 16, 8 x 8 and 64 x 1 give IDENTICAL features (every kernel is row-independent)"""
+    g = np.load(os.path.join(GOLD, "encode_b64.npz"))
+    x0 = torch.from_numpy(g["x0_bf16"]).view(torch.bfloat16).float().cuda()
+    z = encoder.features(x0)
+    _same(z, g["z"], "pre-quantizer features vs the reference's B = 64 run")
+    ids = encoder(x0)[1]
+    assert np.array_equal(ids.cpu().numpy(), g["tokens"].astype(np.int64))
+    for gsz in (16, 8, 1):
+        zg = torch.cat([encoder.features(x0[i:i + gsz]) for i in range(0, 64, gsz)])
+        assert torch.equal(zg, z), f"features depend on the batch size ({64 // gsz} x {gsz})"
+    assert torch.equal(torch.cat([encoder(x0[i:i + 8])[1] for i in range(0, 64, 8)]), ids)

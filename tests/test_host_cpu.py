@@ -364,4 +364,4 @@ def test_gemm_tune_row_counts_and_file_format(tmp_path):
     with G.enabled() as on:                                                           # no GPU: the scope is a no-op
         assert on is False
     src = open(os.path.join(ROOT, "selftoktokenizer_amd", "pipeline.py")).read()
-    assert 'os.environ.get("SELFTOK_TUNE_GEMM", "0") == "1"' in src
+    assert "os.environ" not in src and "self.tune_gemm = bool(tune_gemm)" in src        # opt-in by constructor argument only; the pipeline reads no environment variable
