@@ -21,7 +21,8 @@
  *  GELU(tanh)   ATen GeluKernelImpl: 0.5 x (1 + tanh(kBeta * fma(kKappa, x^3, x))) with Sleef_tanhf16_u10; SiLU: x / (1 + Sleef_expf16_u10(-x)).
  *               Sleef's two routines are restated below from its published algorithm (double-float arithmetic in the FMA form) and
  *               checked against the functions exported by libtorch_cpu.so on ALL 2^32 inputs: 0 mismatches; GELU and SiLU against
- *               torch on all finite fp32 inputs: 0 mismatches.
+ *               torch on all finite fp32 inputs: 0 mismatches.  (ATen's vector loop: an element in the scalar tail of a thread's range -- tensor
+ *               sizes that are not a multiple of 16 x threads -- goes through libm instead; the encoder's tensors have no tails.)
  *  attention    ATen cpu_flash_attention (fp32): q rows independent; kv blocks of 512; scores = one fmaf chain over head_dim (MKL,
  *               K <= 64), * 1/sqrt(d); probabilities by Vectorized<float>::exp_u20 (ATen/cpu/vec/vec512/vec512_float.h) summed in 16
  *               lanes (lane = key mod 16) then folded 8 / 4 / 2 / 1; sum = fma(exp, old sum, block sum) with glibc's expf for the

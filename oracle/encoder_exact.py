@@ -67,7 +67,7 @@ def silu(x):
     return y
 
 
-def patch_embed(x, w, b, bias_first=1):
+def patch_embed(x, w, b, bias_first=0):
     """x [B,C,H,W], w [OC,C,2,2] -> [B, H/2*W/2, OC]"""
     x = _f32(x); w = _f32(w); b = _f32(b)
     B, Cc, H, W = x.shape; OC = w.shape[0]
@@ -98,10 +98,12 @@ def timestep_embedding(t, dim=256):
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1).numpy()
 
 
-def encoder_tables(sd, K, positions):
-    """[K, 6*512] adaLN tables per block: adaLN_modulation(SiLU(t_embedder(pos)))  (modules.py:312-318)"""
+def encoder_tables(sd, K, pos_emb):
+    """[K, 6*512] adaLN tables per block: adaLN_modulation(SiLU(t_embedder(pos)))  (modules.py:312-318).  `pos_emb` [K, 256]: the sinusoidal
+    embedding of the positions 1000 + 8 k -- `timestep_embedding(positions)` on the build container (MKL VML: host dependent), or the
+    table the product ships (selftoktokenizer_amd/data/encoder_pos_sincos.npy), which is that very array."""
     g = lambda k: sd[k].detach().cpu().numpy() if hasattr(sd[k], "detach") else sd[k]
-    emb = timestep_embedding(positions)
+    emb = _f32(pos_emb)[:K]
     out = []
     for i in range(ENC_DEPTH):
         p = f"encoder.blocks.{i}"
@@ -117,13 +119,13 @@ def crop_pos(pos, h, w):
     return pos.reshape(grid, grid, -1)[top:top + h, left:left + w].reshape(1, h * w, -1)
 
 
-def encoder_features(sd, x0, positions, tables=None, bias_first=1, trace=None):
+def encoder_features(sd, x0, pos_emb, tables=None, bias_first=0, trace=None):
     """x0 [B,16,h,w] fp32 -> pre-quantizer features z [B,K,16] with the reference's bits (B >= 8: see encoder_exact.c)"""
     g = lambda k: sd[k].detach().cpu().numpy() if hasattr(sd[k], "detach") else sd[k]
     x0 = _f32(x0)
     B, _, H, W = x0.shape
     K = g("encoder.query_tokens").shape[1]
-    tables = tables or encoder_tables(sd, K, positions)
+    tables = tables or encoder_tables(sd, K, pos_emb)
     x = patch_embed(x0, g("encoder.x_embedder.proj.weight"), g("encoder.x_embedder.proj.bias"), bias_first) + crop_pos(g("encoder.pos_embed"), H // 2, W // 2)
     q = np.broadcast_to(g("encoder.query_tokens"), (B, K, ENC_QDIM)).copy()
     Hd, Q = ENC_HIDDEN, ENC_QDIM

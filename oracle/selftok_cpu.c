@@ -954,3 +954,85 @@ int selftok_vx_expf_f32(const float* x, float* y, long n, hipStream_t s)
     for (long i = 0; i < n; ++i) y[i] = vx_expf(x[i]);
     return SELFTOK_OK;
 }
+
+/* ---- the exact-order Q-Former encoder entries (include/selftok_hip.h, round 5): the CPU twin IS oracle/encoder_exact.c ------------ */
+void xe_linear(const float* x, const float* w, const float* bias, float* out, long M, int N, int K);
+void xe_layernorm(const float* X, float* Y, const float* gamma, const float* beta, long rows, int N, float eps, float* stats);
+void xe_attention(const float* Q, long qs, const float* K1, const float* V1, long kvs1, int Tk1, const float* K2, const float* V2, long kvs2, int Tk2, float* O,
+                  int B, int H, int Tq, int D);
+float xe_gelu_tanh1(float v);
+float xe_silu1(float v);
+float xe_sleef_expf(float v);
+float xe_sleef_tanhf(float v);
+float xe_exp_u20(float v);
+
+int selftok_ex_linear_f32(const float* x, long ldx, const float* w, const float* bias, const float* res, long ldr, int res_mod, const float* gate, long ldg,
+                          int gate_mod, float* out, long ldo, long M, int N, int K, int gelu, hipStream_t s)
+{
+    (void)s;
+    if (M == 0) return SELFTOK_OK;
+    if (!x || !w || !out || M < 0 || N <= 0 || K <= 0 || K % 16 || ldx % 4 || ldx < K || ldo < N || (gate && !res)) return fail("ex_linear: bad argument");
+    float* xc = (float*)malloc((size_t)M * K * sizeof(float));
+    float* yc = (float*)malloc((size_t)M * N * sizeof(float));
+    if (!xc || !yc) { free(xc); free(yc); return fail("ex_linear: out of memory"); }
+    for (long m = 0; m < M; ++m) memcpy(xc + (size_t)m * K, x + (size_t)m * ldx, (size_t)K * sizeof(float));
+    xe_linear(xc, w, bias, yc, M, N, K);
+    for (long m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) {
+            float v = yc[(size_t)m * N + n];
+            if (gelu) v = xe_gelu_tanh1(v);
+            if (gate) v = gate[(size_t)(gate_mod ? m % gate_mod : m) * ldg + n] * v;
+            if (res) v = res[(size_t)(res_mod ? m % res_mod : m) * ldr + n] + v;
+            out[(size_t)m * ldo + n] = v;
+        }
+    free(xc); free(yc);
+    return SELFTOK_OK;
+}
+
+int selftok_ex_layernorm_mod_f32(const float* x, long ldx, float* out, long ldo, const float* shift, const float* scale, long ldt, int T, const float* gamma,
+                                 const float* beta, float* stats, long rows, int N, float eps, hipStream_t s)
+{
+    (void)s;
+    if (rows == 0) return SELFTOK_OK;
+    if (!x || !out || rows < 0 || N <= 0 || N % 8 || N > 4096 || ldx % 4 || ldo % 4 || ((shift == NULL) != (scale == NULL)) || (scale && T <= 0))
+        return fail("ex_layernorm: bad argument");
+    for (long r = 0; r < rows; ++r) {
+        xe_layernorm(x + (size_t)r * ldx, out + (size_t)r * ldo, gamma, beta, 1, N, eps, stats ? stats + 2 * r : NULL);
+        if (scale) {
+            const float *sc = scale + (size_t)(r % T) * ldt, *sh = shift + (size_t)(r % T) * ldt;
+            float* o = out + (size_t)r * ldo;
+            for (int j = 0; j < N; ++j) o[j] = o[j] * (1.0f + sc[j]) + sh[j];
+        }
+    }
+    return SELFTOK_OK;
+}
+
+int selftok_ex_unary_f32(const float* x, float* y, long n, int mode, hipStream_t s)
+{
+    (void)s;
+    if (n == 0) return SELFTOK_OK;
+    if (!x || !y || n < 0 || mode < 0 || mode > 4) return fail("ex_unary: bad argument");
+    for (long i = 0; i < n; ++i)
+        y[i] = mode == 0 ? xe_gelu_tanh1(x[i]) : mode == 1 ? xe_silu1(x[i]) : mode == 2 ? xe_sleef_expf(x[i]) : mode == 3 ? xe_sleef_tanhf(x[i]) : xe_exp_u20(x[i]);
+    return SELFTOK_OK;
+}
+
+size_t selftok_ex_attention_workspace_bytes(int B, int H, int Tq, int Tk, int D)
+{
+    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || D <= 0) return 0;
+    const size_t rows = (size_t)B * H * Tq;
+    const int nb = (Tk + 511) / 512;
+    return rows * Tk * 4 + (size_t)B * H * D * Tk * 4 + rows * 4 * (size_t)(nb > 1 ? nb - 1 : 1) + rows * 4;      /* the GPU library's size */
+}
+
+int selftok_ex_attention_f32(const float* q, long qs, const float* k1, const float* v1, long kvs1, int Tk1, const float* k2, const float* v2, long kvs2, int Tk2,
+                             float* out, void* workspace, int B, int H, int Tq, int D, hipStream_t s)
+{
+    (void)s; (void)workspace;
+    if (B == 0) return SELFTOK_OK;
+    if (!q || !k1 || !v1 || !out || B < 0 || H <= 0 || Tq <= 0 || Tk1 <= 0 || Tk2 < 0 || (Tk2 > 0 && (!k2 || !v2)) || D % 16 || D <= 0 || D > 128 || Tk1 % 16 ||
+        Tk2 % 16 || qs % 4 || kvs1 % 4 || kvs2 % 4)
+        return fail("ex_attention: bad argument");
+    xe_attention(q, qs, k1, v1, kvs1, Tk1, k2, v2, kvs2, Tk2, out, B, H, Tq, D);
+    return SELFTOK_OK;
+}

@@ -35,6 +35,25 @@ def sinusoid_host(t: torch.Tensor, dim: int = FREQ_DIM) -> torch.Tensor:
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
 
+_POS_TABLE = None
+
+
+def encoder_pos_embedding(K: int) -> torch.Tensor:
+    """sinusoidal embedding of the token positions 1000 + 8 k, k < K, with the bits the REFERENCE produces on an AVX-512 Intel host
+    (`timestep_embedding`, models.py:56-74: torch.exp / cos / sin = MKL VML there -- closed source, vendor-dispatched, NOT the correctly
+    rounded values: the same call returns other bits on this box's host CPU).  Input- and weight-independent, so it ships as data
+    (selftoktokenizer_amd/data/encoder_pos_sincos.npy, tools/oracle/gen_pos_table.py); K > 1024 falls back to the host evaluation."""
+    global _POS_TABLE
+    if _POS_TABLE is None:
+        import os
+        _POS_TABLE = torch.from_numpy(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "encoder_pos_sincos.npy")))
+    if K > _POS_TABLE.shape[0]:
+        print(f"[selftok] encoder_pos_embedding: K = {K} exceeds the shipped table ({_POS_TABLE.shape[0]} positions): evaluated on this host's "
+              "CPU instead -- token ids may differ from the reference's at near-ties")
+        return sinusoid_host(torch.from_numpy(DiTiCont.get_position(np.arange(K))).to(torch.int64))
+    return _POS_TABLE[:K].clone()
+
+
 class _Quantizer:
     """`model.encoder.quantizer` surface used by the pipeline: get_output_from_indices."""
 
@@ -68,7 +87,10 @@ class QformerEncoderGPU(ModuleSurface):
         self.pe_w = self.w["encoder.x_embedder.proj.weight"].reshape(ENC_HIDDEN, -1).t().contiguous()
         self._pos_cache = {}
         # input-independent adaLN tables: Linear(SiLU(t_embedder(1000+8k)))  [K, 6*512] per block
-        pos_emb = sinusoid_host(torch.from_numpy(DiTiCont.get_position(np.arange(K))).to(torch.int64)).to(device)
+        if mode == "exact":
+            pos_emb = encoder_pos_embedding(K).to(device)
+        else:
+            pos_emb = sinusoid_host(torch.from_numpy(DiTiCont.get_position(np.arange(K))).to(torch.int64)).to(device)
         self.tables = []
         lin = ops.ex_linear if mode == "exact" else F.linear
         silu = (lambda t: ops.ex_unary(t.contiguous(), "silu")) if mode == "exact" else ops.silu

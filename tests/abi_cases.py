@@ -562,6 +562,65 @@ def split_planes(blk, rows, K):
     return h[0].astype(np.float32), h[1].astype(np.float32)
 
 
+# ---- the exact-order Q-Former encoder entries (round 5): bit-exact on both sides ----------------------------------------------------------
+@case("ex_linear_gelu_res_gate")
+def _(alloc):
+    r = rng(71)
+    M, K, N, T = 192, 512, 96, 64
+    x3 = f32(r.standard_normal((M, 2 * K)))                      # the input is a column slice of a wider tensor
+    w = f32(r.standard_normal((N, K)) / np.sqrt(K)); b = f32(r.standard_normal(N) * 0.2)
+    res = f32(r.standard_normal((M, N))); gate = f32(r.standard_normal((T, 3 * N)))
+    out = alloc(np.zeros((M, N), np.float32))
+    xd = alloc(x3)
+    return "selftok_ex_linear_f32", [xd.ptr + 4 * K, 2 * K, alloc(w).ptr, alloc(b).ptr, alloc(res).ptr, N, 0, alloc(gate).ptr + 4 * N, 3 * N, T, out.ptr, N,
+                                     M, N, K, 1, None], dict(out=out)
+
+
+@case("ex_linear_k2048_n16")
+def _(alloc):
+    r = rng(72)
+    M, K, N = 128, 2048, 16
+    x = f32(r.standard_normal((M, K))); w = f32(r.standard_normal((N, K)) / np.sqrt(K)); b = f32(r.standard_normal(N))
+    out = alloc(np.zeros((M, N), np.float32))
+    return "selftok_ex_linear_f32", [alloc(x).ptr, K, alloc(w).ptr, alloc(b).ptr, None, 0, 0, None, 0, 0, out.ptr, N, M, N, K, 0, None], dict(out=out)
+
+
+@case("ex_layernorm_mod")
+def _(alloc):
+    r = rng(73)
+    rows, N, T = 80, 512, 16
+    x = f32(r.standard_normal((rows, N)) * 2 + 0.3); table = f32(r.standard_normal((T, 6 * N)) * 0.5)
+    out = alloc(np.zeros((rows, N), np.float32)); st = alloc(np.zeros((rows, 2), np.float32)); td = alloc(table)
+    return "selftok_ex_layernorm_mod_f32", [alloc(x).ptr, N, out.ptr, N, td.ptr + 4 * 3 * N, td.ptr + 4 * 4 * N, 6 * N, T, None, None, st.ptr, rows, N, 1e-6, None], dict(out=out, stats=st)
+
+
+def _ex_unary(mode):
+    def fn(alloc):
+        bits = np.concatenate([np.arange(0, 2 ** 32, 2 ** 14, dtype=np.uint64).astype(np.uint32), np.linspace(-12, 12, 1 << 14, dtype=np.float32).view(np.uint32)])
+        x = np.ascontiguousarray(bits.view(np.float32))
+        x = x[np.abs(x) < 80.0]                                    # finite results in every mode (NaN / inf: tests/test_encoder_exact_gpu.py)
+        y = alloc(np.zeros_like(x))
+        return "selftok_ex_unary_f32", [alloc(x).ptr, y.ptr, x.size, mode, None], dict(y=y)
+    return fn
+
+
+for _m in range(5):
+    case(f"ex_unary_mode{_m}")(_ex_unary(_m))
+
+
+@case("ex_attention_two_segments")
+def _(alloc):
+    r = rng(74)
+    B, H, Tq, Tk1, Tk2, D = 1, 2, 64, 64, 512, 64
+    HD = H * D
+    qq = f32(r.standard_normal((B, Tk2, 3 * HD)) * 1.4); kvx = f32(r.standard_normal((B, Tk1, 2 * HD)) * 1.4)
+    lib_ws = 4 * (B * H * Tq * (Tk1 + Tk2) + B * H * D * (Tk1 + Tk2) + 2 * B * H * Tq)
+    out = alloc(np.zeros((B, Tq, HD), np.float32)); ws = alloc(np.zeros(lib_ws, np.uint8))
+    qd, kd = alloc(qq), alloc(kvx)
+    return "selftok_ex_attention_f32", [qd.ptr, 3 * HD, kd.ptr, kd.ptr + 4 * HD, 2 * HD, Tk1, qd.ptr + 4 * HD, qd.ptr + 8 * HD, 3 * HD, Tk2, out.ptr, ws.ptr,
+                                        B, H, Tq, D, None], dict(out=out)
+
+
 def run(lib, name, side):
     """issue case `name` on `lib` with buffers of class `side` (Host | Dev); returns {output name: ndarray} (names starting with
     '_' are metadata passed through)"""

@@ -53,6 +53,32 @@ def test_ids_16_images_exact_mode_equals_the_reference_bit_for_bit(pipe):
     flips = int((ids != g["tokens"].astype(np.int64)).sum())
     print(f"\ne2e ids vs the reference pipeline, {B} images, exact-order VAE encoder: {ids.size - flips} / {ids.size}")
     assert flips == 0
+    # round 5: the Q-Former encoder runs in torch-CPU's orders too (csrc/encoder_exact.hip) -- the pre-quantizer FEATURES are the reference's bits
+    z = pipe.model.encoder.features(pipe.encode_latents(imgs)).cpu().numpy()
+    assert pipe.model.encoder.mode == "exact" and int((z.view(np.uint32) != g["z"].view(np.uint32)).sum()) == 0
+
+
+def test_ids_64_images_one_batch_equal_the_reference_and_do_not_depend_on_the_batching(pipe):
+    """BASELINE configs[1]'s encode leg: the reference's `encoding` on 64 images IN ONE BATCH (tests/golden/encode_b64.npz,
+    SelftokPipeline.py:210-225): latents bit-equal, pre-quantizer features bit-equal, ids 32768 / 32768 -- including the 18 tokens whose two
+    best codes are less than 1e-5 apart -- and IDENTICAL ids when the same 64 images are encoded as 4 x 16, 8 x 8 or 64 x 1"""
+    g = np.load(os.path.join(os.path.dirname(GOLD), "encode_b64.npz"))
+    imgs = synth.synthetic_images(64, device="cuda")
+    x0 = pipe.encode_latents(imgs)
+    ref_x0 = torch.from_numpy(g["x0_bf16"]).view(torch.bfloat16).float()
+    assert torch.equal(x0.cpu(), ref_x0)
+    z = pipe.model.encoder.features(x0).cpu().numpy()
+    assert int((z.view(np.uint32) != g["z"].view(np.uint32)).sum()) == 0
+    ids = pipe.encoding(imgs)
+    ref = g["tokens"].astype(np.int64)
+    mism = ids.cpu().numpy() != ref
+    for b, k in np.argwhere(mism):
+        print(f"flip: image {b} token {k}: reference {ref[b, k]} (gap {g['gap'][b, k]:.3e}, runner-up {g['id2'][b, k]}) -> {int(ids[b, k])}")
+    print(f"\ne2e ids vs the reference's B = 64 run: {mism.size - int(mism.sum())} / {mism.size}; tokens with a reference gap below 1e-5: {int((g['gap'] < 1e-5).sum())}, smallest gap {g['gap'].min():.2e}")
+    assert int(mism.sum()) == 0
+    for gsz in (16, 8, 1):
+        split = torch.cat([pipe.encoding(imgs[i:i + gsz]) for i in range(0, 64, gsz)])
+        assert torch.equal(split, ids), f"ids depend on the batching ({64 // gsz} x {gsz}): {int((split != ids).sum())} differ"
 
 
 def test_ids_16_images_vs_reference(pipe):
@@ -150,8 +176,8 @@ def test_psnr_16_images_vs_reference(pipe, gemm):
     assert lat_err < 2e-5                                        # measured 2.9e-6 in both arithmetics
     # the north star's 1e-3 dB where only OUR path differs: met on average with a wide margin; the maximum over 16 images sits at the
     # metric's own floor (see d_floor: latents that differ by 3e-6 already reach ~1e-3 dB on single images)
-    assert d_same.mean() < 5e-4 and d_same.max() < 2e-3, (d_same.mean(), d_same.max())
+    assert d_same.mean() < 5e-4 and d_same.max() < 1e-3, (d_same.mean(), d_same.max())      # the north star's 1e-3 dB on every image (measured max 6.3e-4)
     # end to end the delta is the bf16 decoder's implementation noise: it stays inside the spread between two CPU implementations of
     # the same decoder on the same latents (second CPU implementation vs reference: mean 3.9e-4, max 1.09e-3 dB; measured here: mean 2.9e-4, max 8.8e-4;
     # rounds 1-2, separate bias add + solver search: mean 6.1e-3)
-    assert d_e2e.mean() < 1e-3 and d_e2e.mean() <= 1.5 * d_or.mean() and d_e2e.max() <= 2.0 * d_or.max(), (d_e2e.mean(), d_e2e.max(), d_or.mean(), d_or.max())
+    assert d_e2e.mean() < 5e-4 and d_e2e.max() < 1e-3, (d_e2e.mean(), d_e2e.max(), d_or.mean(), d_or.max())   # north star: 1e-3 dB, every image (measured mean 2.5e-4, max 8.4e-4)
