@@ -279,8 +279,9 @@ def vq_roofline(n_vq, C, Dm, main_ms, fin_ms, launches, traffic, traffic_note, f
             "hbm": {"achieved_GBs": round(alg_bytes / (both * 1e-3) / 1e9, 2), "frac_of_8TBs": round(alg_bytes / (both * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                     "note": "algorithmic bytes / both launches: ~7.7 kFLOP per byte at D = 16, the path is matrix bound by three orders of magnitude"},
             "note": "frac = frac_algorithmic = 2NCD (SURVEY 8d: the reference's fp32 score matrix) / avg_launch_ms / 2500 TFLOP/s, the f16 matrix peak the "
-                    "kernel runs on; frac_executed = the f16 MFMA FLOPs it issues (3 per product: hi*hi + hi*lo + lo*hi, what keeps ids bit-exact) / the same "
-                    "time and peak = pipe utilisation (N*C*D = %d x %d x %d); recompute from profiles/*kernel_stats.csv: the vq_f16_kernel row's average duration" % (n_vq, C, Dm)}
+                    "kernel runs on; frac_executed = the f16 MFMA FLOPs it issues (%s) / the same "
+                    "time and peak = pipe utilisation (N*C*D = %d x %d x %d); recompute from profiles/*kernel_stats.csv: the vq_f16_kernel row's average duration"
+                    % ("1 per product: hi*hi; the exact fp32 re-score of the candidates keeps ids bit-exact" if mfmas == 1 else "3 per product: hi*hi + hi*lo + lo*hi", n_vq, C, Dm)}
     if fp32_main_ms:
         a32 = flops / (fp32_main_ms * 1e-3) / 1e12
         roof["fp32_mfma_kernel"] = {"kernel": "vq_mfma_kernel<RT> (round-1 kernel: exact fp32 products on v_mfma_f32_32x32x2_f32; same ids, bit for bit)",

@@ -200,7 +200,7 @@ struct XeGemmArgs {
     int M, N, K, H;
     int mode, gelu;
     int nblk;
-    int blk_end[XE_MAXBLK];                     // K-block ends (multiples of 16)
+    int blk_end[XE_MAXBLK];                     // K-block ends (multiples of 4; K itself a multiple of 16)
     unsigned rescale_mask;
 };
 
@@ -266,7 +266,25 @@ __global__ __launch_bounds__(256) void xe_gemm_kernel(XeGemmArgs g)
     int rb[NT], swb[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { rb[t] = RA + wn * (32 * NT) + t * 32 + i; swb[t] = ((rb[t] - RA) >> 2) & 3; }
-    auto compute = [&](int buf) {
+    int bi = 0, ri = 0;
+    auto fold = [&]() {                            // K-block done: C += chain, the next chain starts from 0; then the flash kernel's rescale, if one is due
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { C[t][r] = C[t][r] + acc[t][r]; acc[t][r] = 0.f; }
+        ++bi;
+        if (bi < g.nblk && ((g.rescale_mask >> bi) & 1u)) {   // `dst *= exp(old max - new max)` before the next kv block
+            const float* rs = g.rescale + ((size_t)ri * gridDim.z + z) * g.M;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = rs[min(p0 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1)];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) C[t][r] = C[t][r] * f;
+            }
+            ++ri;
+        }
+    };
+    auto compute = [&](int buf, int k0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const xu32x4 va = lds[buf][ra * 4 + (q ^ swa)];
@@ -282,35 +300,18 @@ __global__ __launch_bounds__(256) void xe_gemm_kernel(XeGemmArgs g)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[t], 0, 0, 0);
                 }
             }
+            if (bi < g.nblk && k0 + 4 * q + 4 == g.blk_end[bi]) fold();      // block ends are multiples of 4 (uniform branch)
         }
     };
 
     const int nchunks = g.K >> 4;
-    int bi = 0, ri = 0;
     fetch(0);
     stage(0);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const bool more = c + 1 < nchunks;
         if (more) fetch(c + 1);
-        compute(c & 1);
-        if (bi < g.nblk && (c + 1) * 16 == g.blk_end[bi]) {                    // K-block done: C += chain, next chain starts from 0
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { C[t][r] = C[t][r] + acc[t][r]; acc[t][r] = 0.f; }
-            ++bi;
-            if (bi < g.nblk && ((g.rescale_mask >> bi) & 1u)) {   // the flash kernel's `dst *= exp(old max - new max)` before its next kv block
-                const float* rs = g.rescale + ((size_t)ri * gridDim.z + z) * g.M + p0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float f = rs[(r & 3) + 8 * (r >> 2) + 4 * h];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) C[t][r] = C[t][r] * f;
-                }
-                ++ri;
-            }
-        }
+        compute(c & 1, c * 16);
         if (more) stage((c + 1) & 1);
         __syncthreads();
     }
@@ -535,7 +536,7 @@ int selftok_ex_linear_f32(const float* x, long ldx, const float* w, const float*
     g.M = (int)M; g.N = N; g.K = K; g.H = 1; g.mode = 0; g.gelu = gelu;
     g.nblk = mkl_blocks(K, 0, g.blk_end, 0);
     if (g.nblk < 0) { set_last_error("ex_linear: K too large (more than 16 K-blocks)"); return SELFTOK_EINVAL; }
-    for (int j = 0; j < g.nblk; ++j) if (g.blk_end[j] % 16) { set_last_error("ex_linear: a K-block boundary is not a multiple of 16"); return SELFTOK_EINVAL; }
+    for (int j = 0; j < g.nblk; ++j) if (g.blk_end[j] % 4) { set_last_error("ex_linear: a K-block boundary is not a multiple of 4"); return SELFTOK_EINVAL; }
     return launch_xe_gemm(g, 1, stream);
 }
 
@@ -620,7 +621,7 @@ int selftok_ex_attention_f32(const float* q, long qs, const float* k1, const flo
         if (n < 0) { set_last_error("ex_attention: too many keys (more than 16 K-blocks)"); return SELFTOK_EINVAL; }
     }
     g.nblk = n;
-    for (int j = 0; j < n; ++j) if (g.blk_end[j] % 16) { set_last_error("ex_attention: a K-block boundary is not a multiple of 16"); return SELFTOK_EINVAL; }
+    for (int j = 0; j < n; ++j) if (g.blk_end[j] % 4) { set_last_error("ex_attention: a K-block boundary is not a multiple of 4"); return SELFTOK_EINVAL; }
     return launch_xe_gemm(g, Z, stream);
 }
 

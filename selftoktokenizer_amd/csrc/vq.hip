@@ -1142,7 +1142,12 @@ int selftok_vq_argmax_partial_packed_f32(const float* z, const float* packed, vo
         while (row_blocks * split < 512 && split < 64 && ntiles / (split * 2) >= 8) split *= 2;
         if (split > 64) split = 64;
         { const int f_split = (flags >> 16) & 0xFF; if (f_split > 0 && f_split <= 64) split = f_split; }
-        if ((flags & SELFTOK_VQ_F16COARSE1) && (ntiles + split - 1) / split > 1024) split = (ntiles + 1023) / 1024;      // 10-bit tile fields
+        if ((flags & SELFTOK_VQ_F16COARSE1) && (ntiles + split - 1) / split > 1024) {
+            // the 4-byte candidates carry a 10-bit tile field: at most 1024 tiles per split, and the workspace / side array hold 64 splits -> C <= 2^21
+            // codes.  A larger code book takes the 3-MFMA variant (8-byte candidates, any stream length): same ids and score bits
+            split = (ntiles + 1023) / 1024;
+            if (split > 64) { set_last_error("vq_argmax_partial_packed: SELFTOK_VQ_F16COARSE1 supports at most 2^21 codes (use the 3-MFMA coarse pass)"); return SELFTOK_EINVAL; }
+        }
         const int tps = (ntiles + split - 1) / split;
         split = (ntiles + tps - 1) / tps;
         *nsplit_out = split;

@@ -43,6 +43,7 @@ class MMDiTGPU(ModuleSurface):
         self.gemm = "fp32"
         self._packed = {}                                                   # linear name -> f16x2-split weight image
         self._mod_cache = {}                                                # (timestep name, gemm mode) -> modulations of a single-image step
+        self._capture_refs = None                                           # list while a caller captures a hipGraph (see _step_modulations)
         self.overflow = torch.zeros(1, dtype=torch.int32, device=device)    # sticky fp16-range flag of the split GEMMs
         self.w = {k: v.to(device=device, dtype=torch.float32).contiguous() for k, v in sd.items() if k.startswith("model.")}
         H = DIT_HIDDEN
@@ -180,14 +181,23 @@ class MMDiTGPU(ModuleSurface):
         one-image decode), but they depend on the scheduled timestep alone.  B == 1 only: there the remembered tensors ARE what the
         step would compute (same shapes, same kernels, bit for bit); at larger B the GEMMs are 0.1 % of the step.  Nothing is stored
         while a stream is capturing (tensors made during a capture belong to the graph's pool); the warm-up pass before a capture
-        fills the table, the capture then reads it."""
+        fills the table, the capture then reads it -- and a capturing caller sets `self._capture_refs = []` first: every remembered
+        tensor the capture reads is appended there, and the caller keeps that list with the graph (SelftokPipeline._graphs), so an
+        eviction or `_mod_cache.clear()` can never free memory a captured graph still reads.  When the table is full the
+        OLDEST entry goes (dict order), not the whole table."""
         key = None if (t_key is None or t_freq.shape[0] != 1 or self.MOD_CACHE_MAX <= 0) else (t_key, self.gemm)
+        capturing = t_freq.is_cuda and torch.cuda.is_current_stream_capturing()
         if key is not None and key in self._mod_cache:
-            return self._mod_cache[key]
+            mods = self._mod_cache[key]
+            if capturing:
+                if self._capture_refs is None:        # a capture nobody announced: the graph must own what it reads
+                    return self.modulations(self.time_embed(t_freq), True)
+                self._capture_refs.append(mods)
+            return mods
         mods = self.modulations(self.time_embed(t_freq), True)
-        if key is not None and not (t_freq.is_cuda and torch.cuda.is_current_stream_capturing()):
-            if len(self._mod_cache) >= self.MOD_CACHE_MAX:
-                self._mod_cache.clear()
+        if key is not None and not capturing:
+            while len(self._mod_cache) >= self.MOD_CACHE_MAX:
+                self._mod_cache.pop(next(iter(self._mod_cache)))
             self._mod_cache[key] = mods
         return mods
 

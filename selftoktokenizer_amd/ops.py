@@ -85,10 +85,9 @@ def vq_encode(z: torch.Tensor, codebook: torch.Tensor, *, packed: bool = False, 
     _need_cuda(z, codebook)
     lib = _lib.load()
     cflags = _coarse_flags(coarse) if packed else 0
-    use_coarse = cflags if cflags else False
     if packed and VQ_EVENTS is not None and not return_best and not prenormed and z.numel() > 0:
         # same two launches as selftok_vq_encode_packed_f32, with HIP events around the argmax kernel on its launch stream
-        ids, launch_main, launch_fin = vq_encode_split_launch(z, codebook, ids_dtype, coarse=use_coarse)
+        ids, launch_main, launch_fin = vq_encode_split_launch(z, codebook, ids_dtype, _flags=cflags)
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
         launch_main()
@@ -339,6 +338,11 @@ def split_to_f32(xs: SplitAct) -> torch.Tensor:
     return p[0].float() + p[1].float() * (1.0 / 2048.0)
 
 
+@functools.lru_cache(maxsize=None)
+def _cu_count() -> int:
+    return int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count) if torch.cuda.is_available() else 256
+
+
 SPLITK_MAX_ROWS = 1024      # rows up to which the block Linears of the f16x2 mode are worth splitting along K (one .. four images)
 
 
@@ -349,14 +353,17 @@ def f16x2_ksplit(M: int, N: int, K: int) -> int:
     the divisors s of K / 32 that keep the grid within one work-group per CU (a second round of work-groups costs ~10 us:
     profiles/r4_splitk_sweep.txt) and >= 3 k-tiles per work-group (the DMA pipeline depth), the minimum of a two-term cost fitted to
     that sweep: 0.42 us per k-tile of the longest chain + 1.2 us per million fp32 partials written and re-read, + 4 us for the
-    second launch."""
+    second launch.  NOTE: the split is chosen from M = batch rows, and a split-K sum rounds differently from the single pass -- in f16x2
+    mode an image decoded at B <= 4 and at B > 4 differs at fp32 rounding level (1e-7 relative per Linear; the fp32 mode and every encode
+    path are batch independent).  The cost constants are one MI355X sweep; the CU count comes from the device."""
     if M <= 0 or M > SPLITK_MAX_ROWS:
         return 1
     tiles = ((M + 255) // 256) * (N // 128)
     kt = K // 32
+    cus = _cu_count()
     best, best_cost = 1, 0.42 * kt
     for s in range(2, 65):
-        if kt % s or kt // s < 3 or tiles * s > 256:
+        if kt % s or kt // s < 3 or tiles * s > cus:
             continue
         cost = 0.42 * (kt // s) + 1.2e-6 * s * M * N + 4.0
         if cost < best_cost:
@@ -630,9 +637,10 @@ def clamp01_(img):
     return img
 
 
-def vq_encode_split_launch(z, packed_codebook, ids_dtype=torch.int64, coarse=None):
+def vq_encode_split_launch(z, packed_codebook, ids_dtype=torch.int64, coarse=None, _flags: Optional[int] = None):
     """Same result as vq_encode(packed=True) but returns (ids, launch_main, launch_finalize) closures so a
-    benchmark can time the main argmax kernel alone (HIP events around launch_main on the current stream)."""
+    benchmark can time the main argmax kernel alone (HIP events around launch_main on the current stream).
+    `coarse`: None / False / True / 1 / 3 as in vq_encode; `_flags`: the raw SELFTOK_VQ_* flag word instead (sweeps)."""
     import ctypes
     lib = _lib.load()
     zz = z.contiguous().float().reshape(-1, z.shape[-1])
@@ -640,7 +648,7 @@ def vq_encode_split_launch(z, packed_codebook, ids_dtype=torch.int64, coarse=Non
     C = packed_codes(packed_codebook, D)
     ids = torch.empty(N, dtype=ids_dtype, device=z.device)
     ws = torch.empty(lib.selftok_vq_workspace_bytes(N, C), dtype=torch.uint8, device=z.device)
-    flags = (IDS_I32 if ids_dtype == torch.int32 else 0) | (coarse if isinstance(coarse, int) and not isinstance(coarse, bool) and coarse >= 8 else _coarse_flags(coarse))
+    flags = (IDS_I32 if ids_dtype == torch.int32 else 0) | (int(_flags) if _flags is not None else _coarse_flags(coarse))
     nsplit = ctypes.c_int(0)
 
     def launch_main():

@@ -368,10 +368,16 @@ class SelftokPipeline():
                 run()
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                s_out = run()
-            self._graphs[key] = (g, s_noise, s_ehs, s_out)
-        g, s_noise, s_ehs, s_out = self._graphs[key]
+            dit = self.model.model
+            dit._capture_refs = []               # remembered modulations the capture reads: kept alive with the graph (MMDiTGPU._step_modulations)
+            try:
+                with torch.cuda.graph(g):
+                    s_out = run()
+                refs = dit._capture_refs
+            finally:
+                dit._capture_refs = None
+            self._graphs[key] = (g, s_noise, s_ehs, s_out, refs)
+        g, s_noise, s_ehs, s_out = self._graphs[key][:4]
         s_noise.copy_(xt.to(self.device)); s_ehs.copy_(ehs)
         g.replay()
         return s_out.clone()

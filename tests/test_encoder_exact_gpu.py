@@ -120,7 +120,8 @@ def test_layernorm_aten_order(N, affine, mod):
 # ---- attention -------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,B,H,Tq,Tk1,Tk2,D", [("latent self-attention 4 x 16", 2, 4, 256, 256, 0, 16), ("query attention 8 x 64, 256 + 512 keys", 2, 8, 512, 256, 512, 64),
-                                                  ("K = 1024 tokenizer: 256 + 1024 keys", 1, 8, 1024, 256, 1024, 64), ("128 px: 64 + 512 keys", 1, 8, 512, 64, 512, 64)])
+                                                  ("K = 1024 tokenizer: 256 + 1024 keys", 1, 8, 1024, 256, 1024, 64), ("128 px: 64 + 512 keys", 1, 8, 512, 64, 512, 64),
+                                                  ("320 px: 400 keys (MKL halves of 200)", 1, 4, 400, 400, 0, 16), ("320 px: 400 + 512 keys", 1, 8, 512, 400, 512, 64)])
 def test_attention_flash_order(name, B, H, Tq, Tk1, Tk2, D):
     HD = H * D
     qq = _rand(0xB0 + Tq, (B, Tq, 3 * HD), 1.4)                     # fused projections, as the encoder holds them

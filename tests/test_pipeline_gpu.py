@@ -346,6 +346,18 @@ def test_single_image_decode_remembers_the_timestep_modulations(pipe, gemm):
         n = len(dit._mod_cache)
         pipe.decoding(synth.synthetic_token_ids(2), noise=synth.synthetic_noise(2), max_steps=2)      # B > 1: computed per step, nothing stored
         assert len(dit._mod_cache) == n
+        # the captured graph read the remembered tensors -- it must keep them alive.  Drop the table, churn the allocator so that
+        # freed blocks would be reused and overwritten, replay: still the same latents
+        dit._mod_cache.clear()
+        junk = [torch.full((1 << 18,), float("nan"), device="cuda") for _ in range(64)]
+        torch.cuda.synchronize()
+        _, replay = pipe.decoding(ids, noise=noise, return_latent=True, max_steps=4, use_graph=True)
+        del junk
+        assert torch.equal(off, replay), "a graph replay read freed modulation tensors"
+        # a full table evicts its OLDEST entry only
+        dit.MOD_CACHE_MAX = 2
+        pipe.decoding(ids, noise=noise, return_latent=True, max_steps=4)
+        assert len(dit._mod_cache) == 2
     finally:
         dit.MOD_CACHE_MAX = keep
         pipe.set_gemm("fp32")
@@ -384,7 +396,7 @@ def test_full_batch_size_independence(pipe):
     # the id matrix that N ranks would all-gather is just the concatenation of the shards
     from selftoktokenizer_amd.dist import shard_range
     lo, hi = shard_range(B, 3, 8)
-    assert torch.equal(t_chunks[lo:hi], pipe.model.encoder(x0[lo:hi], d=None)[1])
+    assert torch.equal(tok_all[lo:hi], pipe.model.encoder(x0[lo:hi], d=None)[1])
 
 
 @pytest.mark.parametrize("gemm", ["fp32", "f16x2"])
