@@ -66,7 +66,13 @@ def parse(argv=None):
     ap.add_argument("--no-token-check", action="store_true")
     ap.add_argument("--no-kernel-roofs", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 eager / hipGraph latency leg")
+    ap.add_argument("--no-parity16", action="store_true", help="skip the 16-image parity leg against the reference pipeline's run")
     ap.add_argument("--no-other-gemm", action="store_true", help="skip the second measurement on the other GEMM arithmetic")
+    ap.add_argument("--encoder", default=None, choices=["exact", "fast"], help="Q-Former encoder arithmetic; default: the pipeline's (exact: the reference's torch-CPU orders)")
+    ap.add_argument("--all-legs", action="store_true", help="N > 1: also run the second-arithmetic / kernel-roofline / parity / latency legs (default at N > 1: only the "
+                    "timed steps -- rank 0 would otherwise work for minutes after the other ranks have left the group)")
+    ap.add_argument("--force-collective", action="store_true", help="N = 1 under torchrun: create the RCCL group for the one rank and take the all-gather's device path "
+                    "(communicator bound to the GPU, int32 cast, side stream, event join) exactly as an N-rank run does -- the 8-GPU line minus the xGMI transport")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="no GPU work: initialise the ranks, all-gather synthetic ids, print the JSON skeleton (CPU test of the N>1 entry)")
     return ap.parse_args(argv)
@@ -475,15 +481,18 @@ def kernel_roofs(pipe, B, K, k_table):
     return out
 
 
-def token_match(pipe, images, tokens_gpu, sd_gpu, vsd_gpu, K, n_check=2):
-    """token-id exact match of the timed batch (rank 0's shard) against the CPU oracle:
+def token_match(pipe, images, tokens_gpu, sd_gpu, vsd_gpu, K, n_check=2, first_index=0):
+    """token-id exact match of the timed batch (rank 0's shard):
+       vs_reference    : against the REFERENCE's own `encoding` of the same 64 images in one batch (tests/golden/encode_b64.npz; present when the timed
+                         batch is that batch: K = 512, images 0..63) -- ALL images of the batch, every flip listed with the reference's gap;
        kernel_boundary : the HIP VQ kernel vs the C oracle on the SAME features, every row of the batch (must be 1.0);
-       e2e_same_latents: GPU encoder+VQ vs oracle encoder+VQ from the same fp32 latents (fp32 GEMM library differences only);
-       e2e_vs_oracle   : from pixels, i.e. incl. the bf16 VAE (the CPU checker's VAE = oracle/vae_exact.c = the reference's run bit for
-                         bit; 1.0 in the default `exact` VAE mode up to fp32 GEMM noise in the tokenizer), first n_check images."""
+       e2e_same_latents: GPU encoder+VQ vs the bit-exact CPU twin (oracle/encoder_exact.c) from the same fp32 latents, first n_check images: the
+                         FEATURES must be equal bit for bit (`features_bits_differing` 0);
+       e2e_vs_oracle   : from pixels, i.e. incl. the bf16 VAE (oracle/vae_exact.c = the reference's run bit for bit), first n_check images."""
     import numpy as np
     import torch
-    from oracle import clib, model as OM
+    from oracle import clib, model as OM, encoder_exact as EX
+    from selftoktokenizer_amd.encoder import encoder_pos_embedding
     torch.set_num_threads(host_cores())
     enc = pipe.model.encoder
     with torch.no_grad():
@@ -493,32 +502,51 @@ def token_match(pipe, images, tokens_gpu, sd_gpu, vsd_gpu, K, n_check=2):
         cb = enc.codebook.cpu().numpy()
         ids_c, _ = clib.vq_encode_mt(z.reshape(-1, 16).cpu().numpy(), cb)          # every row, threaded over row chunks
         kb = float((ids_c.reshape(ids_gpu.shape) == ids_gpu).mean())
+        ref = None
+        gold = os.path.join(ROOT, "tests", "golden", "encode_b64.npz")
+        if K == 512 and first_index == 0 and ids_gpu.shape[0] <= 64 and os.path.exists(gold):
+            g = np.load(gold)
+            n = ids_gpu.shape[0]
+            rt = g["tokens"][:n].astype(np.int64)
+            mism = rt != ids_gpu
+            x0_ref = torch.from_numpy(g["x0_bf16"][:n]).view(torch.bfloat16).float()
+            ref = {"images_checked": int(n), "tokens": int(rt.size), "equal": int(rt.size - mism.sum()), "match": round(float(1.0 - mism.mean()), 8),
+                   "flips": [{"image": int(b), "token": int(k), "reference_id": int(rt[b, k]), "ours": int(ids_gpu[b, k]), "reference_gap": float(g["gap"][b, k]),
+                              "reference_runner_up": int(g["id2"][b, k])} for b, k in np.argwhere(mism)[:32]],
+                   "latents_bits_differing": int((x0.cpu() != x0_ref).sum()),
+                   "features_bits_differing": int((z.cpu().numpy().view(np.uint32) != g["z"][:n].view(np.uint32)).sum()),
+                   "reference_tokens_with_gap_below_1e-5": int((g["gap"][:n] < 1e-5).sum()), "smallest_reference_gap": float(g["gap"][:n].min()),
+                   "source": "tests/golden/encode_b64.npz = mimogpt.infer.SelftokPipeline.encoding on these 64 images in ONE batch (CPU, build container; "
+                             "tools/oracle/gen_golden.py encode64)"}
         sd = {k: v.detach().cpu() for k, v in sd_gpu.items() if k.startswith("encoder.")}
         vsd = {k: v.detach().cpu() for k, v in vsd_gpu.items() if k.startswith("encoder.") or k.startswith("quant_conv")}
-        tables = OM.encoder_tables(sd, K)
-        z_o = OM.encoder_features(sd, x0[:n_check].cpu(), tables)
-        ids_same = OM.vq_ids(sd, z_o).numpy()
+        pos = encoder_pos_embedding(K).numpy()
+        tables = EX.encoder_tables(sd, K, pos)
+        z_o = EX.encoder_features(sd, x0[:n_check].cpu().numpy(), pos, tables=tables)
+        feat_diff = int((z_o.view(np.uint32) != z[:n_check].cpu().numpy().view(np.uint32)).sum())
+        ids_same = OM.vq_ids(sd, torch.from_numpy(z_o)).numpy()
         # the VAE of the CPU checker: oracle/vae_exact.c, the bit-for-bit restatement of the reference's torch-CPU run (host independent --
         # torch's own bf16 convolution sums in another order on a host without AMX); ~10 s per image on 8 cores
         from oracle import vae_exact as VX
         mom = VX.encode_moments(VX.pack_weights(vsd), VX.bf16_bits(images[:n_check].cpu().to(torch.bfloat16).permute(0, 2, 3, 1)))
         x0_e2e = OM.process_in(VX.bits_to_torch(mom[..., :16]).permute(0, 3, 1, 2).contiguous()).to(torch.float32)
-        z_e2e = OM.encoder_features(sd, x0_e2e, tables)                       # = OM.pipeline_encode, keeping the features for the gaps
+        z_e2e = torch.from_numpy(EX.encoder_features(sd, x0_e2e.numpy(), pos, tables=tables))
         ids_e2e = OM.vq_ids(sd, z_e2e).numpy()
 
         def gaps(ids_o, z_feat):
             mism = ids_o != ids_gpu[:n_check]
             if not mism.any():
                 return []
-            xn = torch.nn.functional.normalize(z_feat.reshape(-1, 16), dim=-1)[torch.from_numpy(mism.reshape(-1))]
+            xn = torch.nn.functional.normalize(torch.as_tensor(z_feat).reshape(-1, 16), dim=-1)[torch.from_numpy(mism.reshape(-1))]
             top2 = (xn @ torch.from_numpy(cb).T).topk(2, dim=-1).values
             return sorted(round(float(g), 8) for g in (top2[:, 0] - top2[:, 1]))
-    return {"kernel_boundary": kb, "kernel_boundary_rows": int(ids_gpu.size),
-            "e2e_same_latents": round(float((ids_same == ids_gpu[:n_check]).mean()), 6), "mismatch_gaps_same_latents": gaps(ids_same, z_o),
+    return {"vs_reference": ref, "kernel_boundary": kb, "kernel_boundary_rows": int(ids_gpu.size),
+            "e2e_same_latents": round(float((ids_same == ids_gpu[:n_check]).mean()), 6), "features_bits_differing": feat_diff, "mismatch_gaps_same_latents": gaps(ids_same, z_o),
             "e2e_vs_oracle": round(float((ids_e2e == ids_gpu[:n_check]).mean()), 6), "mismatch_gaps_e2e": gaps(ids_e2e, z_e2e), "images_checked": n_check,
-            "note": "gap = oracle top-1 minus top-2 cosine score of each mismatching token (a flip needs an upstream difference larger than the gap); "
-                    "e2e_vs_oracle additionally carries the bf16 VAE encoder (vae mode '%s' vs oracle/vae_exact.c, the bit-for-bit restatement of the "
-                    "reference's torch-CPU run)" % pipe.vae.mode}
+            "encoder_mode": enc.mode, "vae_mode": pipe.vae.mode,
+            "note": "vs_reference covers EVERY image of the timed batch against the reference's own run; the CPU-twin legs (oracle/encoder_exact.c + oracle/vae_exact.c: "
+                    "bit-for-bit restatements of the reference's torch-CPU arithmetic, ~13 s per image on 8 cores) re-derive the first images_checked images on this box. "
+                    "gap = oracle top-1 minus top-2 cosine score of each mismatching token"}
 
 
 def main(argv=None):
@@ -535,7 +563,9 @@ def main(argv=None):
     backend_req = os.environ.get("SELFTOK_DIST_BACKEND", "gloo" if args.selftest_dist else "nccl")
     if one_gpu:
         os.environ["LOCAL_RANK"] = "0"
-    rank, world, local = D.init_from_env(backend_req)
+    rank, world, local = D.init_from_env(backend_req, single_rank_group=args.force_collective)
+    if args.force_collective:
+        D.force_single_rank(True)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)"
     backend = D.backend_name()
     if world > 1 and not args.selftest_dist and os.environ.get("SELFTOK_DIST_BACKEND") is None:
@@ -569,7 +599,9 @@ def main(argv=None):
     sd = W.synthetic_state_dict(W.expected_shapes(K, renderer=renderer), device=dev)
     vsd = W.synthetic_vae_state_dict(device=dev)
     pipe = SelftokPipeline(cfg, None, None, device=dev, state_dict=sd, vae_state_dict=vsd, verbose=False, gemm=args.gemm, vae_mode=args.vae,
-                           tune_gemm=bool(args.tune_gemm))
+                           tune_gemm=bool(args.tune_gemm), encoder_mode=args.encoder)
+    if world > 1 and not args.all_legs:                # the N > 1 line = the timed steps + the cheap checks; the deep dives belong to the N = 1 line
+        args.no_other_gemm = args.no_kernel_roofs = args.no_latency = args.no_parity16 = True
     gemm_main = pipe.model.model.gemm
     if args.tune_gemm and gemm_main == "fp32":
         pipe.tune_linears(B, renderer=renderer)       # explicit, outside the timed region (~4 s): nothing is measured inside a decoding() call
@@ -648,14 +680,16 @@ def main(argv=None):
         "config": {"workload": "BASELINE configs[%d]: batch %d x 256x256 per GPU, %d-token encode + %s decode"
                                % (3 if renderer else (2 if K == 1024 else 1), B, K, "one-step renderer" if renderer else "50-step diffusion"),
                    "global_batch": world * B, "tokens": K, "decode_steps": 1 if renderer else (args.decode_steps or 50),
-                   "gemm": gemm_main, "arithmetic": arith[gemm_main], "vae": pipe.vae.mode,
+                   "gemm": gemm_main, "arithmetic": arith[gemm_main], "vae": pipe.vae.mode, "encoder": pipe.model.encoder.mode,
+                   "tune_gemm": bool(args.tune_gemm), "tune_gemm_note": "opt-in extension of the pipeline (default off there): hipBLASLt's kernel per Linear shape family chosen by a "
+                                                                        "~4 s measurement before the warm-up; --tune-gemm 0 measures hipBLASLt's own choice",
                    "fp32_linear_kernels": (None if not pipe.gemm_tune_report else {f"{n}x{k}": {"kernel": b or "hipBLASLt default", "ms_default": t0, "ms_chosen": t1}
                                                                                        for (n, k), (b, t0, t1) in pipe.gemm_tune_report.items()}),
                    "parallelism": "batch-shard x%d" % world,
                    "api": "pipe.encoding(images) -> id all-gather -> pipe.decoding(ids.cpu().numpy()) (noise from the CPU generator, as the reference)",
                    "weights": "hash-generated, architecture of tokenizer_512_ckpt"},
-        "ranks": world, "backend": backend if world > 1 else None,
-        "allgather_bytes": ag["bytes"], "allgather_ms": round(float(np.mean(ag["ms"])), 4) if world > 1 and ag["ms"] else None,
+        "ranks": world, "backend": backend if (world > 1 or args.force_collective) else None,
+        "allgather_bytes": ag["bytes"], "allgather_ms": round(float(np.mean(ag["ms"])), 4) if (world > 1 or args.force_collective) and ag["ms"] else None,
         "roofline": roof,
     }
     fl_img = fp32_flops_per_image(K, pipe.k_table[: (args.decode_steps or 50)], renderer)
@@ -674,8 +708,8 @@ def main(argv=None):
     if not args.no_kernel_roofs and not renderer:
         line["roofline_kernels"] = kernel_roofs(pipe, B, K, pipe.k_table)
     if not args.no_token_check:
-        line["token_match"] = token_match(pipe, images, last["tokens"], sd, vsd, K)
-        if K == 512 and os.path.exists(GOLD16):
+        line["token_match"] = token_match(pipe, images, last["tokens"], sd, vsd, K, first_index=rank * B)
+        if K == 512 and os.path.exists(GOLD16) and not args.no_parity16:
             line["parity_16"] = parity_16(pipe)
     if not args.no_latency and not renderer:
         line["latency_b1"] = latency_b1(pipe)

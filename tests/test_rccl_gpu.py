@@ -99,3 +99,26 @@ def test_codebook_training_step_over_rccl(rccl_single_rank):
     for name in ("embed", "embed_avg"):                                           # fp32 scatter-adds (atomics): order noise between two runs
         torch.testing.assert_close(getattr(with_group, name), getattr(alone, name), rtol=0, atol=2e-6)
     assert np.isfinite(float(with_group.delta_embed))
+
+
+def test_bench_under_torchrun_one_rank_takes_the_rccl_path():
+    """the command the driver issues for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`), with the ONE rank a test
+    box has: torchrun's env is read, the RCCL group is created (`backend: "nccl"`), every step issues its all-gather on the device path
+    (`allgather_ms` non-null) and rank 0 prints the JSON line.  What an 8-GPU run adds is the xGMI transport inside ncclAllGather."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4", "--decode-steps", "2", "--force-collective",
+           "--no-cpu-baseline", "--no-token-check", "--no-kernel-roofs", "--no-latency", "--no-other-gemm", "--tune-gemm", "0"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    print("\n[bench under torchrun, 1 rank, RCCL path forced]", {k: line[k] for k in ("n_gpus", "ranks", "backend", "allgather_bytes", "allgather_ms", "ms_per_step", "value")})
+    assert line["n_gpus"] == 1 and line["ranks"] == 1 and line["backend"] == "nccl"
+    assert line["allgather_bytes"] == 4 * 512 * 4 and line["allgather_ms"] is not None and 0.0 < line["allgather_ms"] < 1000.0
+    assert line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0 and "INVALID" in line["config"]     # --decode-steps: a debug line, marked as such
