@@ -277,7 +277,12 @@ int selftok_groupnorm_silu_nhwc_bf16(const void* x, const void* weight, const vo
  * F.pad(x, (0,1,0,1)) + stride-2 convolution.  residual: out = bf16(bf16(conv + bias) + residual).
  * order = the chunk order of oneDNN's kernel for that layer: 0: 32-channel chunks in (kh, kw, channel-block) order; 3: channel-block
  * major, every block's 9 taps summed privately and then added to the total (the 128- and 256-channel Downsample layers);
- * 2: conv_in (Cin = 3): one chunk of 27 elements in (kw, kh, ic) order.  Cin % 32 == 0, Cout % 32 == 0, B*Ho*Wo % 128 == 0 (orders 0, 3). */
+ * 2: conv_in (Cin = 3): one chunk of 27 elements in (kw, kh, ic) order.  Cin % 32 == 0, Cout % 32 == 0, B*Ho*Wo % 128 == 0 (orders 0, 3).
+ * order | SELFTOK_VX_UPSAMPLE2X (round 5, the decoder's Upsample: F.interpolate(nearest, x2) + 3x3 convolution, sd3_impls.py:308-311): x is
+ * [B, H/2, W/2, Cin] in memory and is read as its nearest-2x upsampled view of size H x W (H, W even, stride 1).  The decoder's layers all
+ * use order 0 (tools/probe_cpu_bf16/check_decoder_convs.py); its conv_in (16 channels: one 16-channel chunk per tap) and conv_out (3 output
+ * channels) are issued with zero-padded channels (a zero product leaves a chain's bits unchanged). */
+#define SELFTOK_VX_UPSAMPLE2X 8
 int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const void* residual, void* out, int B, int H, int W, int ldx, int Cin, int Cout,
                            int ksize, int stride, int order, hipStream_t stream);
 /* GroupNorm(groups, eps, affine) [+ SiLU] with ATen's statistics (Welford in 8 fp32 lanes over 16-element vectors, chunks of 16

@@ -892,6 +892,9 @@ int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const
     (void)s;
     if (B == 0) return SELFTOK_OK;
     if (!x || !w || !bias || !out || B < 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (stride == 2 && ksize != 3)) return fail("vx_conv2d: bad argument");
+    const int up = (order & SELFTOK_VX_UPSAMPLE2X) ? 1 : 0;
+    order &= ~SELFTOK_VX_UPSAMPLE2X;
+    if (up && (stride != 1 || ((H | W) & 1) || ldx != Cin)) return fail("vx_conv2d: SELFTOK_VX_UPSAMPLE2X needs stride 1 and even H, W");
     if (order == 2 ? (Cin != 3 || ksize != 3 || stride != 1 || residual) : ((order != 0 && order != 3) || Cin % 32 || ldx != Cin || Cout % 32))
         return fail("vx_conv2d: need Cin % 32 == 0, Cout % 32 == 0, order 0 / 2 / 3");
     const int OH = stride == 2 ? H / 2 : H, OW = stride == 2 ? W / 2 : W;
@@ -900,6 +903,13 @@ int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const
     if (ldx != Cin) {                                   /* conv_in reads the first 3 of ldx channels */
         tmp = (uint16_t*)malloc((size_t)B * H * W * Cin * 2);
         for (size_t p = 0; p < (size_t)B * H * W; ++p) for (int c = 0; c < Cin; ++c) tmp[p * Cin + c] = xs[p * ldx + c];
+        xs = tmp;
+    }
+    if (up) {                                           /* materialise the nearest-2x view (a copy: F.interpolate(mode="nearest")) */
+        tmp = (uint16_t*)malloc((size_t)B * H * W * Cin * 2);
+        if (!tmp) return fail("vx_conv2d: out of memory");
+        for (int b = 0; b < B; ++b) for (int y = 0; y < H; ++y) for (int xx = 0; xx < W; ++xx)
+            memcpy(tmp + (((size_t)b * H + y) * W + xx) * Cin, xs + (((size_t)b * (H / 2) + y / 2) * (W / 2) + xx / 2) * Cin, (size_t)Cin * 2);
         xs = tmp;
     }
     const int rc = vx_conv2d_nhwc(xs, (const uint16_t*)w, (const uint16_t*)bias, (const uint16_t*)residual, (uint16_t*)out, B, H, W, Cin, Cout, ksize, ksize, stride,

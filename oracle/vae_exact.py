@@ -112,7 +112,7 @@ def pack_weights(vsd):
     import torch
     out = {}
     for k, v in vsd.items():
-        if not k.startswith("encoder."):
+        if not (k.startswith("encoder.") or k.startswith("decoder.")):
             continue
         t = v.detach().cpu().to(torch.bfloat16)
         if t.dim() == 4:
@@ -161,3 +161,50 @@ def encode_moments(pw, img_bits, trace=None):
     h = conv(p + ".to_out.0", a, pad=0, residual=h)
     h = res("encoder.mid_block.resnets.1", h)
     return conv("encoder.conv_out", gn("encoder.conv_norm_out", h))
+
+
+def upsample2x(x):
+    """F.interpolate(scale_factor=2, mode='nearest') on an NHWC array (Upsample, sd3_impls.py:308-311): a copy"""
+    return np.ascontiguousarray(np.repeat(np.repeat(x, 2, axis=1), 2, axis=2))
+
+
+def decode(pw, z_bits, trace=None):
+    """pw = pack_weights(vsd) (incl. the decoder.* keys); z_bits [B,32,32,16] uint16 (NHWC bf16 latents after process_out) -> pixels
+    [B,256,256,3] uint16, before norm_ip: `VAEDecoder.forward` (sd3_impls.py:427-444) in the summation orders of the reference's torch-CPU run.
+    Every convolution of the decoder -- incl. the three that read a nearest-upsampled input, conv_in (16 channels: one 16-channel chunk per
+    tap) and conv_out (3 output channels) -- sums its chunks in (kh, kw, channel-block) order (tools/probe_cpu_bf16/check_decoder_convs.py,
+    fprev_conv_ic16.py: 0 mismatches against F.conv2d on every layer shape); GroupNorm / SiLU / attention as in the encoder."""
+    tab = silu_table()
+
+    def conv(name, x, **kw):
+        y = conv2d(x, pw[name + ".weight"], pw[name + ".bias"], order=0, **kw)
+        if trace is not None:
+            trace.append((name, y))
+        return y
+
+    def gn(name, x, act=True):
+        y = group_norm(x, pw[name + ".weight"], pw[name + ".bias"], silu=tab if act else None)
+        if trace is not None:
+            trace.append((name, y))
+        return y
+
+    def res(p, x):
+        h = conv(p + ".conv1", gn(p + ".norm1", x))
+        sc = conv(p + ".conv_shortcut", x, pad=0) if (p + ".conv_shortcut.weight") in pw else x
+        return conv(p + ".conv2", gn(p + ".norm2", h), residual=sc)
+
+    h = conv("decoder.conv_in", z_bits)
+    h = res("decoder.mid_block.resnets.0", h)
+    p = "decoder.mid_block.attentions.0"
+    B, H, W, Cn = h.shape
+    n = gn(p + ".group_norm", h, act=False)
+    q, k, v = (conv(p + s, n, pad=0).reshape(B, H * W, Cn) for s in (".to_q", ".to_k", ".to_v"))
+    a = attention(q, k, v).reshape(B, H, W, Cn)
+    h = conv(p + ".to_out.0", a, pad=0, residual=h)
+    h = res("decoder.mid_block.resnets.1", h)
+    for lvl in range(4):
+        for j in range(3):
+            h = res(f"decoder.up_blocks.{lvl}.resnets.{j}", h)
+        if lvl != 3:
+            h = conv(f"decoder.up_blocks.{lvl}.upsamplers.0.conv", upsample2x(h))
+    return conv("decoder.conv_out", gn("decoder.conv_norm_out", h))

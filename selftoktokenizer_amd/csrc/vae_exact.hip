@@ -62,6 +62,7 @@ struct XConvArgs {
     float out_scale;              // mode 1: y = C * out_scale
     int H, W, IC, OC, KH, KW, stride, pad, OH, OW;
     int split, mode;
+    int up;                       // 1: the convolution reads a nearest-2x upsampled view of x ([B][H/2][W/2][IC] in memory; H, W = the upsampled size)
     long x_bs, w_bs, y_bs, v_bs;
 };
 
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
         const int rem = (int)(pa - (long)b * ohw);
         const int oy = rem / a.OW, ox = rem - oy * a.OW;
         aiy0[j] = oy * a.stride - a.pad; aix0[j] = ox * a.stride - a.pad;
-        arow[j] = x + (size_t)b * H * W * IC + q * 8;
+        arow[j] = x + (size_t)b * (H >> a.up) * (W >> a.up) * IC + q * 8;
         aslot[j] = row * 4 + (q ^ ((row >> 2) & 3));
     }
     const unsigned short* brow[NPB];
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
             const int iy = aiy0[j] + kh, ix = aix0[j] + kw;
             const bool ok = aon[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             const u32x4 zero = {0u, 0u, 0u, 0u};
-            const u32x4 v = *reinterpret_cast<const u32x4*>(arow[j] + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * IC + icb * 32);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(arow[j] + ((size_t)((ok ? iy : 0) >> a.up) * (W >> a.up) + ((ok ? ix : 0) >> a.up)) * IC + icb * 32);
             sa[j] = ok ? v : zero;
         }
         const size_t woff = (size_t)(kh * KW + kw) * IC + icb * 32;
@@ -588,13 +589,16 @@ int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const
                            (const unsigned short*)w, (const unsigned short*)bias, (unsigned short*)out, B, H, W, ldx, Cout);
         return check_launch("xconv_in_kernel");
     }
+    const int up = (order & SELFTOK_VX_UPSAMPLE2X) ? 1 : 0;
+    order &= ~SELFTOK_VX_UPSAMPLE2X;
+    if (up && (stride != 1 || ((H | W) & 1))) { set_last_error("vx_conv2d: SELFTOK_VX_UPSAMPLE2X needs stride 1 and even H, W (the upsampled size)"); return SELFTOK_EINVAL; }
     if ((order != 0 && order != 3) || Cin % 32 || ldx != Cin || Cout % 32 || P % 128 || (stride == 2 && ((H | W) & 1))) {
         set_last_error("vx_conv2d: need Cin % 32 == 0, Cout % 32 == 0, B*Ho*Wo % 128 == 0, order 0 / 2 / 3"); return SELFTOK_EINVAL;
     }
     XConvArgs a{};
     a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.bias = (const unsigned short*)bias; a.res = (const unsigned short*)residual; a.y = out;
     a.H = H; a.W = W; a.IC = Cin; a.OC = Cout; a.KH = a.KW = ksize; a.stride = stride; a.pad = (ksize == 3 && stride == 1) ? 1 : 0; a.OH = OH; a.OW = OW;
-    a.split = -1; a.mode = 0;
+    a.split = -1; a.mode = 0; a.up = up;
     return launch_xconv(a, P, 1, order == 3, stream);
 }
 

@@ -663,15 +663,22 @@ def vq_encode_split_launch(z, packed_codebook, ids_dtype=torch.int64, coarse=Non
 
 
 # ---- the exact-order SD3-VAE encoder kernels (csrc/vae_exact.hip) -------------------------------------------------------------------
+VX_UPSAMPLE2X = 8
+
+
 def vx_conv2d(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, stride: int = 1, residual: Optional[torch.Tensor] = None, order: int = 0,
-              cin: Optional[int] = None) -> torch.Tensor:
+              cin: Optional[int] = None, upsample: bool = False) -> torch.Tensor:
     """x [B,H,W,ldx] bf16 channels-last, w [Cout,k,k,Cin] bf16 (the checkpoint's tensor permuted), bias [Cout] bf16 -> [B,Ho,Wo,Cout] bf16 with the
-    summation order of the reference's CPU convolution (oneDNN AMX chunks; include/selftok_hip.h).  `order`: 0 / 3 / 2 (conv_in, cin = 3)."""
+    summation order of the reference's CPU convolution (oneDNN AMX chunks; include/selftok_hip.h).  `order`: 0 / 3 / 2 (conv_in, cin = 3).
+    `upsample`: the convolution reads the nearest-2x upsampled view of x (the decoder's Upsample layer; output [B,2H,2W,Cout])."""
     _need_cuda(x, w, bias, residual)
     assert x.dtype == w.dtype == bias.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous() and x.dim() == 4 and w.dim() == 4
     B, H, W, ldx = x.shape
     Cout, k, k2, Cin = w.shape
     assert k == k2 and (cin is None or cin == Cin)
+    if upsample:
+        assert stride == 1
+        H, W, order = 2 * H, 2 * W, order | VX_UPSAMPLE2X
     Ho, Wo = (H // 2, W // 2) if stride == 2 else (H, W)
     out = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device=x.device)
     if residual is not None:

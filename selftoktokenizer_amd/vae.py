@@ -144,9 +144,18 @@ class AutoencoderKLGPU(ModuleSurface):
             # 'exact': the whole encoder; both modes: the mid-block attention of encoder AND decoder (AttnBlock, sd3_impls.py:274-284)
             # runs on these kernels -- GroupNorm, q / k / v / out projections and the flash-kernel row pass in the reference's order
             for k, v in self.w.items():
-                if k.endswith(".weight") and v.dim() in (2, 4) and (".attentions." in k or (mode == "exact" and k.startswith("encoder."))):
+                if k.endswith(".weight") and v.dim() in (2, 4) and (".attentions." in k or mode == "exact"):
                     v4 = v.reshape(v.shape[0], v.shape[1], 1, 1) if v.dim() == 2 else v
                     self.xw[k[:-len(".weight")]] = v4.permute(0, 2, 3, 1).contiguous()
+            if mode == "exact":
+                # the decoder's two odd layers on the 32-channel-chunk kernel: conv_in (16 input channels = one 16-channel chunk per tap in
+                # oneDNN) with zero input channels 16..31, conv_out (3 output channels) with 29 zero output channels -- a zero product
+                # leaves an fp32 chain's bits unchanged, so the padded layers compute the unpadded layers' bits
+                wi = self.xw["decoder.conv_in"]                                               # [512,3,3,16]
+                self.xw["decoder.conv_in"] = F.pad(wi, (0, 32 - wi.shape[3])).contiguous()
+                wo = self.xw["decoder.conv_out"]                                              # [3,3,3,128]
+                self.xw["decoder.conv_out"] = F.pad(wo, (0, 0, 0, 0, 0, 0, 0, 32 - wo.shape[0])).contiguous()
+                self.xb_out = F.pad(self.w["decoder.conv_out.bias"], (0, 32 - wo.shape[0])).contiguous()
             self.silu_table = ops.vx_silu_table(device)
         if mode in ("parity", "exact"):
             for k, v in self.w.items():
@@ -210,9 +219,10 @@ class AutoencoderKLGPU(ModuleSurface):
             return 2
         return 3 if (stride == 2 and cin in (128, 256)) else 0
 
-    def _x_conv(self, name, x, stride=1, residual=None):
+    def _x_conv(self, name, x, stride=1, residual=None, upsample=False, bias=None):
         w = self.xw[name]
-        return ops.vx_conv2d(x, w, self.w[name + ".bias"], stride=stride, residual=residual, order=self._x_order(w.shape[3], stride))
+        order = 0 if name.startswith("decoder.") else self._x_order(w.shape[3], stride)       # every decoder layer: (kh, kw, channel-block) chunks
+        return ops.vx_conv2d(x, w, self.w[name + ".bias"] if bias is None else bias, stride=stride, residual=residual, order=order, upsample=upsample)
 
     def _x_gn(self, name, x, act=True):
         return ops.vx_groupnorm(x, self.w[name + ".weight"], self.w[name + ".bias"], silu_table=self.silu_table if act else None, groups=32, eps=1e-6)
@@ -239,6 +249,26 @@ class AutoencoderKLGPU(ModuleSurface):
         h = self._x_res("encoder.mid_block.resnets.1", h)
         h = self._x_conv("encoder.conv_out", self._x_gn("encoder.conv_norm_out", h))
         return h.permute(0, 3, 1, 2).contiguous()
+
+    def _x_decode(self, z):
+        """`VAEDecoder.forward` (sd3_impls.py:427-444) with every reduction in the reference's torch-CPU order (round 5): pixels equal the
+        reference's decode of the same latents bit for bit (tests/golden/decode_b16.npz, vae_b1.npz; CPU twin oracle/vae_exact.py decode)"""
+        if tuple(z.shape[-2:]) != (32, 32):
+            raise NotImplementedError("vae_mode='exact' reproduces oneDNN's summation orders as probed for the decoder's layer shapes at 256 x 256; "
+                                      "use vae_mode='parity' for other resolutions")
+        h = z.to(self.device, self.dtype).permute(0, 2, 3, 1)
+        h = F.pad(h, (0, 32 - h.shape[-1])).contiguous()                               # 16 -> 32 channels (zeros): one chunk per tap
+        h = self._x_conv("decoder.conv_in", h)
+        h = self._x_res("decoder.mid_block.resnets.0", h)
+        h = self._n_attn("decoder.mid_block.attentions.0", h)
+        h = self._x_res("decoder.mid_block.resnets.1", h)
+        for lvl in range(4):
+            for j in range(3):
+                h = self._x_res(f"decoder.up_blocks.{lvl}.resnets.{j}", h)
+            if lvl != 3:
+                h = self._x_conv(f"decoder.up_blocks.{lvl}.upsamplers.0.conv", h, upsample=True)
+        h = self._x_conv("decoder.conv_out", self._x_gn("decoder.conv_norm_out", h), bias=self.xb_out)     # [B,H,W,32], channels 3.. are padding
+        return h[..., :3].permute(0, 3, 1, 2).contiguous()
 
     def _n_decode(self, z):
         h = z.to(self.device, self.dtype).permute(0, 2, 3, 1).contiguous()
@@ -356,6 +386,8 @@ class AutoencoderKLGPU(ModuleSurface):
 
     @torch.no_grad()
     def decode(self, z, return_dict=False):
+        if self.mode == "exact" and tuple(z.shape[-2:]) == (32, 32):
+            return (self._x_decode(z),)
         if self.mode in ("parity", "exact"):
             return (self._n_decode(z),)
         with self._flags():

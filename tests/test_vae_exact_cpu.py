@@ -164,3 +164,35 @@ def test_cpu_twin_exports_the_exact_entries_with_the_declared_signatures():
     assert twin.selftok_vx_expf_f32(xs.ctypes.data, ys.ctypes.data, 3, None) == 0
     assert np.array_equal(ys.view(np.uint32), np.array([VX.expf(float(v)) for v in xs], dtype=np.float32).view(np.uint32))
     assert twin.selftok_vx_attention_workspace_bytes(2, 1024, 512) == 2 * 1024 * 1024 * 6 + 2 * 1024 * 512 * 2 + 2 * 2 * 1024 * 4
+
+
+# ---- round 5: the decoder ---------------------------------------------------------------------------------------------------------------
+DEC_SHAPES = [("conv_in 16->512 @32", 16, 512, 32, 3, False), ("up 512->512 @32->64", 512, 512, 32, 3, True), ("shortcut 512->256 1x1 @128", 512, 256, 128, 1, False),
+              ("conv_out 128->3 @256", 128, 3, 256, 3, False)]
+
+
+@needs_amx
+@pytest.mark.parametrize("name,cin,cout,H,k,up", DEC_SHAPES, ids=[s[0] for s in DEC_SHAPES])
+def test_decoder_conv_order_equals_onednn(name, cin, cout, H, k, up):
+    """the decoder's own layer shapes (the big 3x3 ones: tools/probe_cpu_bf16/check_decoder_convs.py, profiles/r5_cpu_bf16_decoder_orders.txt):
+    chunks in (kh, kw, channel-block) order everywhere, also behind a nearest-2x upsample, with 16 input channels, with 3 output channels"""
+    x = _rand(0x70 + cin + H, (1, cin, H, H), 1.2, 0.05)
+    w = _rand(0x71 + cout, (cout, cin, k, k), (1.0 / (cin * k * k)) ** 0.5)
+    b = _rand(0x72, (cout,), 0.1)
+    with torch.no_grad():
+        xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+        ref = F.conv2d(xin, w, b, padding=k // 2)
+    xb = _nhwc_bits(x)
+    mine = VX.conv2d(VX.upsample2x(xb) if up else xb, VX.bf16_bits(w.permute(0, 2, 3, 1)), VX.bf16_bits(b), pad=k // 2, order=0)
+    assert int((mine != _nhwc_bits(ref)).sum()) == 0
+
+
+def test_whole_decoder_equals_the_reference_pixels():
+    """oracle/vae_exact.py decode against the REFERENCE's decoder output (tests/golden/vae_b1.npz, the in-repo mirror the pipeline run executes):
+    0 of 196608 bf16 pixels differ.  Host independent (plain C)."""
+    vsd = W.synthetic_vae_state_dict()
+    g = np.load(os.path.join(GOLD, "vae_b1.npz"))
+    z = synth.synthetic_latents(1).to(torch.bfloat16)
+    px = VX.decode(VX.pack_weights(vsd), VX.bf16_bits(z.permute(0, 2, 3, 1)))
+    ref = VX.bf16_bits(torch.from_numpy(g["rec"]).to(torch.bfloat16).permute(0, 2, 3, 1))
+    assert int((px != ref).sum()) == 0

@@ -132,3 +132,64 @@ def test_encoder_latents_equal_the_reference_pipeline_bit_for_bit():
     assert torch.equal(pipe.encode_latents(imgs[3:4]), x0[3:4])
     big = pipe.encode_latents(synth.synthetic_images(64, device="cuda"))
     assert torch.equal(big[:16], x0)
+
+
+# ---- round 5: the DECODER in the reference's orders ---------------------------------------------------------------------------------
+# (name, Cin, Cout, H of the convolution's input view, ksize, upsample, B)
+DEC_CONVS = [("conv_in 16(+16 zeros)->512 @32", 16, 512, 32, 3, False, 2), ("up 512->512 @32->64", 512, 512, 32, 3, True, 2), ("up 512->512 @64->128", 512, 512, 64, 3, True, 1),
+             ("512->256 @128", 512, 256, 128, 3, False, 1), ("shortcut 512->256 1x1 @128", 512, 256, 128, 1, False, 1), ("up 256->256 @128->256", 256, 256, 128, 3, True, 1),
+             ("256->128 @256", 256, 128, 256, 3, False, 1), ("shortcut 256->128 1x1 @256", 256, 128, 256, 1, False, 1), ("conv_out 128->3(+29 zeros) @256", 128, 3, 256, 3, False, 1)]
+
+
+@pytest.mark.parametrize("name,cin,cout,H,k,up,B", DEC_CONVS, ids=[c[0] for c in DEC_CONVS])
+def test_decoder_conv_exact_order(name, cin, cout, H, k, up, B):
+    """every convolution shape the decoder adds to the encoder's: nearest-2x upsampling as input addressing, conv_in's 16-channel chunks and
+    conv_out's 3 output channels through zero padding -- bit-equal to oracle/vae_exact.c, which is bit-equal to F.conv2d on the reference host"""
+    x = _rand_bf16(0xD0 + cin + H, (B, H, H, cin), 1.3, 0.1)
+    w = _rand_bf16(0xD1 + cout, (cout, k, k, cin), (1.0 / (cin * k * k)) ** 0.5)
+    b = _rand_bf16(0xD2, (cout,), 0.1)
+    ref = VX.conv2d(VX.upsample2x(_bits(x)) if up else _bits(x), _bits(w), _bits(b), pad=1 if k == 3 else 0, order=0)
+    xg, wg, bg = x.cuda(), w.cuda(), b.cuda()
+    if cin % 32:
+        xg, wg = torch.nn.functional.pad(xg, (0, 32 - cin)).contiguous(), torch.nn.functional.pad(wg, (0, 32 - cin)).contiguous()
+    if cout % 32:
+        wg, bg = torch.nn.functional.pad(wg, (0, 0, 0, 0, 0, 0, 0, 32 - cout)).contiguous(), torch.nn.functional.pad(bg, (0, 32 - cout)).contiguous()
+    out = ops.vx_conv2d(xg, wg, bg, order=0, upsample=up)[..., :cout].contiguous()
+    torch.cuda.synchronize()
+    _same(out, ref, name)
+
+
+@pytest.mark.parametrize("B,C,H", [(1, 512, 128), (1, 256, 256)])
+def test_groupnorm_exact_decoder_shapes(B, C, H):
+    x = _rand_bf16(0xE8 + C + H, (B, H, H, C), 1.7, 0.3)
+    g = (synth.hash_uniform(0xE1, (C,), 0.9, 1.1)).to(torch.bfloat16)
+    b = _rand_bf16(0xE2, (C,), 0.1)
+    ref, st = VX.group_norm(_bits(x), _bits(g), _bits(b), silu=VX.silu_table(), want_stats=True)
+    out, st_g = ops.vx_groupnorm(x.cuda(), g.cuda(), b.cuda(), silu_table=ops.vx_silu_table("cuda"), want_stats=True)
+    assert np.array_equal(st_g.cpu().numpy().view(np.uint32), st.view(np.uint32)), "mean / rstd bits differ from ATen's"
+    _same(out, ref, f"GroupNorm + SiLU C={C} H={H}")
+
+
+def test_decoder_pixels_equal_the_reference_bit_for_bit():
+    """the REFERENCE's VAE decode (tests/golden/vae_b1.npz: one synthetic latent; decode_b16.npz: the final latents of its 16-image pipeline
+    run, crc32 of every image's bf16 pixels after norm_ip): our `vae.decode` gives the same bits on all 17 images, at any batch size"""
+    import zlib
+    from selftoktokenizer_amd.vae import AutoencoderKLGPU
+    from selftoktokenizer_amd import pipeline as P
+    vae = AutoencoderKLGPU(W.synthetic_vae_state_dict(device="cuda"), torch.device("cuda", torch.cuda.current_device()), mode="exact")
+    g1 = np.load(os.path.join(GOLD, "vae_b1.npz"))
+    z1 = synth.synthetic_latents(1).to(torch.bfloat16).cuda()
+    rec = vae.decode(z1)[0]
+    ref = torch.from_numpy(g1["rec"]).to(torch.bfloat16)
+    bad = int((rec.cpu().view(torch.int16) != ref.view(torch.int16)).sum())
+    assert bad == 0, f"{bad} of {ref.numel()} pixels differ from the reference decoder's"
+    g16 = np.load(os.path.join(GOLD, "decode_b16.npz"))
+    lat = torch.from_numpy(np.load(os.path.join(GOLD, "pipeline_b16.npz"))["lat"]).cuda()
+    z = ops.latent_process_out(lat, P.SD3_SHIFT, P.SD3_SCALE)
+    px = P.norm_ip(vae.decode(z)[0].contiguous())
+    bits = px.cpu().view(torch.int16).numpy().view(np.uint16)
+    crc = np.array([zlib.crc32(np.ascontiguousarray(bits[i]).tobytes()) for i in range(16)], dtype=np.uint32)
+    assert np.array_equal(bits.reshape(16, -1)[:, :256], g16["head"]), "first pixels differ"
+    assert np.array_equal(crc, g16["crc"]), f"images whose pixels differ from the reference's: {np.nonzero(crc != g16['crc'])[0].tolist()}"
+    # batch independence by construction
+    assert torch.equal(P.norm_ip(vae.decode(z[5:6])[0].contiguous()), px[5:6])

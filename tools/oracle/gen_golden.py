@@ -463,6 +463,36 @@ def stage_encode64(B=64):
                         gap=gap.numpy(), x0_bf16=x0.to(torch.bfloat16).view(torch.int16).numpy(), z=z.numpy())
 
 
+def stage_decode16():
+    """the REFERENCE's VAE decode (the in-repo mirror the pipeline run executes, `self.vae.decode(z)[0]` + norm_ip, SelftokPipeline.py:285-292) of
+    the 16 final latents stored in pipeline_b16.npz, in one batch as the pipeline does: a crc32 of every image's bf16 pixels (pixels themselves
+    would be 6 MB) + their mean, so that a decoder can be checked for BIT equality with the reference's on 16 images."""
+    import zlib
+    H.install()
+    import mimogpt.infer.SelftokPipeline as SP
+    vae = _MirrorVAE.from_pretrained(None)
+    g = np.load(os.path.join(GOLD, "pipeline_b16.npz"))
+    lat = torch.from_numpy(g["lat"])
+    from mimogpt.models.selftok.sd3.sd3_impls import SD3LatentFormat
+    z = SD3LatentFormat().process_out(lat).to(torch.bfloat16)
+    rec = vae.decode(z)[0]
+    SP.norm_ip(rec, -1, 1)                                                              # in place, as the pipeline (:135-137, 292)
+    bits = rec.contiguous().view(torch.int16).numpy().view(np.uint16)
+    crc = np.array([zlib.crc32(np.ascontiguousarray(bits[i]).tobytes()) for i in range(bits.shape[0])], dtype=np.uint32)
+    orig = (synth.synthetic_images(16) + 1.0) / 2.0
+    mse = ((rec.float() - orig) ** 2).reshape(16, -1).double().mean(dim=1)
+    psnr = (10.0 * torch.log10(1.0 / mse)).numpy()
+    assert np.allclose(psnr, g["psnr_ref"], atol=1e-9), (psnr, g["psnr_ref"])          # the same pixels the pipeline run produced
+    vsd = W.synthetic_vae_state_dict()
+    from oracle import vae_exact as VX
+    px = VX.decode(VX.pack_weights(vsd), VX.bf16_bits(z[:2].permute(0, 2, 3, 1)))
+    mine = OM.norm_ip(VX.bits_to_torch(px).permute(0, 3, 1, 2).contiguous())
+    ok = bool(torch.equal(mine, rec[:2]))
+    report("decode16", images=16, oracle_vae_exact_decode_equals_reference_first2=ok, pixel_mean=float(rec.float().mean()))
+    np.savez_compressed(os.path.join(GOLD, "decode_b16.npz"), crc=crc, mean=rec.float().reshape(16, -1).double().mean(dim=1).numpy(),
+                        head=bits.reshape(16, -1)[:, :256].copy())
+
+
 def stage_renderer():
     cfg, model, sd = tokenizer(CFG_RND)
     ids = torch.from_numpy(synth.synthetic_token_ids(1, first_index=7))
@@ -742,7 +772,7 @@ def stage_rmsnorm_rotary():
     report("rmsnorm_rotary", arrays=sorted(out), rms_absmax=float(np.abs(out["rms_affine"]).max()), rot_absmax=float(np.abs(out["rot_full"]).max()))
 
 
-STAGES = dict(encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
+STAGES = dict(decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
               vae=stage_vae, pipeline=stage_pipeline, pipeline16=stage_pipeline16, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024, vqtrain=stage_vqtrain)
 
 if __name__ == "__main__":
