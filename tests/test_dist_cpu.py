@@ -249,3 +249,62 @@ def test_codebook_update_is_data_parallel_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _eval_worker(rank, world, port, q):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import numpy as np
+    import torch
+    from selftoktokenizer_amd import dist as D, evaluate as E
+    D.init_from_env("gloo")
+
+    class FakePipe:                                            # the harness only needs .device, .encoding, .decoding
+        device = torch.device("cpu")
+
+        def encoding(self, imgs, device=None):
+            return (imgs.reshape(imgs.shape[0], -1)[:, :8] * 1000).long()
+
+        def decoding(self, ids, device=None, noise=None):
+            return ((self._last + 1.0) / 2.0 * 0.9).to(torch.bfloat16)
+
+    pipe = FakePipe()
+
+    def load(lo, hi):
+        g = torch.Generator().manual_seed(123)
+        allx = torch.rand(11, 3, 8, 8, generator=g) * 2 - 1
+        pipe._last = allx[lo:hi]
+        return allx[lo:hi]
+    res = E.evaluate(pipe, load, 11, batch=2, seed=None)
+    q.put((rank, res))
+    D.shutdown()
+
+
+def test_eval_harness_shards_and_gathers_over_ranks():
+    """evaluate(): 11 images over 2 gloo ranks (shards of 6 and 5, batches of 2) = the single-process per-image PSNR list, on every rank"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    q1 = ctx.Queue()
+    p1 = ctx.Process(target=_eval_worker, args=(0, 1, _free_port(), q1))
+    p1.start()
+    single = q1.get(timeout=300)[1]
+    p1.join(timeout=60)
+    assert got[0]["shard"] == [0, 6] and got[1]["shard"] == [6, 11] and got[0]["ranks"] == 2
+    assert got[0]["diffusion"]["psnr_each_dB"] == got[1]["diffusion"]["psnr_each_dB"] == single["diffusion"]["psnr_each_dB"]
+    assert len(single["diffusion"]["psnr_each_dB"]) == 11

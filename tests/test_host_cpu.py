@@ -365,3 +365,28 @@ def test_gemm_tune_row_counts_and_file_format(tmp_path):
         assert on is False
     src = open(os.path.join(ROOT, "selftoktokenizer_amd", "pipeline.py")).read()
     assert "os.environ" not in src and "self.tune_gemm = bool(tune_gemm)" in src        # opt-in by constructor argument only; the pipeline reads no environment variable
+
+
+def test_default_config_equals_the_reference_yamls():
+    """tests/golden/config_hotpath.json = the hot-path keys of the reference's two shipped YAMLs as ITS parse_args_from_yaml returns them
+    (tools/oracle/gen_golden.py config): `default_config` must carry the same values, key for key; a key the YAML leaves out must carry
+    the default the reference's code applies (context_see_xt: kwargs.get(..., False), image_tokenizer.py:158)"""
+    import json
+    from selftoktokenizer_amd.config import default_config
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config_hotpath.json")))
+
+    def check(ref, mine, where, absent):
+        for k, v in mine.items():
+            if where + k in absent:
+                continue
+            assert k in ref, where + k
+            if isinstance(v, dict):
+                check(ref[k], v, where + k + ".", absent)
+            else:
+                assert ref[k] == v, (where + k, ref[k], v)
+    for name, rnd in (("k512", False), ("renderer", True)):
+        absent = gold["absent_in_the_reference_yaml"].get(name, [])
+        check(gold[name], json.loads(json.dumps(default_config(512, renderer=rnd))), "", absent)
+        assert absent == ([] if not rnd else ["tokenizer.params.context_see_xt"])
+    assert default_config(512, renderer=True).tokenizer.params.context_see_xt is False
+    assert gold["k512"]["tokenizer"]["params"]["decoder_config"]["time_adaln"] == "pos_emb" and gold["k512"]["tokenizer"]["params"]["k"] == 512

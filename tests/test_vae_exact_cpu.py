@@ -167,7 +167,7 @@ def test_cpu_twin_exports_the_exact_entries_with_the_declared_signatures():
 
 
 # ---- round 5: the decoder ---------------------------------------------------------------------------------------------------------------
-DEC_SHAPES = [("conv_in 16->512 @32", 16, 512, 32, 3, False), ("up 512->512 @32->64", 512, 512, 32, 3, True), ("shortcut 512->256 1x1 @128", 512, 256, 128, 1, False),
+DEC_SHAPES = [("conv_in 16->512 @32", 16, 512, 32, 3, False), ("up 512->512 @16->32 (the Upsample layers at a quarter of their smallest size: the real sizes are in the profile)", 512, 512, 16, 3, True), ("shortcut 512->256 1x1 @128", 512, 256, 128, 1, False),
               ("conv_out 128->3 @256", 128, 3, 256, 3, False)]
 
 

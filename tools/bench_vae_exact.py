@@ -24,9 +24,10 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     sd = W.synthetic_vae_state_dict()
     img = synth.synthetic_images(B).to(torch.bfloat16).cuda()
+    z = synth.synthetic_latents(B).to(torch.bfloat16).cuda()
     for mode in ("exact", "parity"):
         vae = AutoencoderKLGPU(sd, torch.device("cuda"), mode=mode)
-        print(f"vae[{mode:6s}] B={B}: encode {ms(lambda: vae.encode(img)[0].mode()):8.1f} ms", flush=True)
+        print(f"vae[{mode:6s}] B={B}: encode {ms(lambda: vae.encode(img)[0].mode()):8.1f} ms   decode {ms(lambda: vae.decode(z)[0]):8.1f} ms", flush=True)
     print("selftok_vx_conv2d_bf16 alone (fp32 MFMA, AMX chunk order):")
     tot_fl = tot_t = 0.0
     for (name, cin, cout, H, k, stride, order, count) in (("128->128 3x3 @256", 128, 128, 256, 3, 1, 0, 4), ("Downsample 128", 128, 128, 256, 3, 2, 3, 1), ("128->256 @128", 128, 256, 128, 3, 1, 0, 1),

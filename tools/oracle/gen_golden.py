@@ -493,6 +493,34 @@ def stage_decode16():
                         head=bits.reshape(16, -1)[:, :256].copy())
 
 
+def stage_config():
+    """the hot-path keys of the reference's two shipped YAMLs (configs/res256/256-eval.yml, configs/renderer/renderer-eval.yml) as the REFERENCE's own
+    `parse_args_from_yaml` (infer_utils.py:165-168) returns them: the values `selftoktokenizer_amd.config.default_config` must reproduce (VERDICT r4
+    item 2).  Only the keys default_config carries are stored (values, not YAML text)."""
+    H.install()
+    from mimogpt.infer.infer_utils import parse_args_from_yaml
+    from selftoktokenizer_amd.config import default_config
+
+    absent = {}
+
+    def pick(ref, mine, where, name):
+        out = {}
+        for k, v in mine.items():
+            if k not in ref:                              # a key the YAML leaves to the code's default (e.g. context_see_xt: kwargs.get(..., False), image_tokenizer.py:158)
+                absent.setdefault(name, []).append(where + k)
+                continue
+            out[k] = pick(ref[k], v, where + k + ".", name) if isinstance(v, dict) else ref[k]
+        return out
+    out = {}
+    for name, path, rnd in (("k512", CFG_256, False), ("renderer", CFG_RND, True)):
+        ref = parse_args_from_yaml(path)
+        out[name] = pick(ref, default_config(512, renderer=rnd), "", name)
+    out["absent_in_the_reference_yaml"] = absent
+    with open(os.path.join(GOLD, "config_hotpath.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    report("config", absent=absent)
+
+
 def stage_renderer():
     cfg, model, sd = tokenizer(CFG_RND)
     ids = torch.from_numpy(synth.synthetic_token_ids(1, first_index=7))
@@ -772,7 +800,7 @@ def stage_rmsnorm_rotary():
     report("rmsnorm_rotary", arrays=sorted(out), rms_absmax=float(np.abs(out["rms_affine"]).max()), rot_absmax=float(np.abs(out["rot_full"]).max()))
 
 
-STAGES = dict(decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
+STAGES = dict(config=stage_config, decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
               vae=stage_vae, pipeline=stage_pipeline, pipeline16=stage_pipeline16, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024, vqtrain=stage_vqtrain)
 
 if __name__ == "__main__":
