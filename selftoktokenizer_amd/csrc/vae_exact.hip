@@ -66,13 +66,20 @@ struct XConvArgs {
     long x_bs, w_bs, y_bs, v_bs;
 };
 
+typedef float xf32x2 __attribute__((ext_vector_type(2)));
+
 template <int NT, int WM, int WN, bool PARTIAL>
 __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
 {
-    // workgroup tile: RA = 32 WM pixel rows x RB = 32 NT WN output channels; one chunk = 64 bytes (32 bf16 channels) of every row
+    // workgroup tile: RA = 32 WM pixel rows x RB = 32 NT WN output channels; one chunk = 32 bf16 channels of every row, staged as fp32:
+    // round 5 -- the bf16 -> fp32 expansion happens ONCE per staged element (a shift / a mask on the packed pair, by the thread that copies it to
+    // LDS) instead of once per reading lane (v_perm per MFMA operand: 24 per 32 x 32 tile and chunk), and a row's chunk is laid out as
+    // [16 even elements | 16 odd elements] so that a lane reads the 16 operands of ITS chain (block 0: even, block 1: odd) as four ds_read_b128.
+    // fp32-input MFMAs and VALU instructions share the issue slot (tools/microbench/mfma_valu.hip: 0 / 4 / 9 VALU per MFMA -> 151 / 125 / 93 TF),
+    // so the kernel's rate is set by the VALU instructions beside its MFMAs: 3.5 per MFMA before, 1.75 now (with the packed fold below).
     constexpr int RA = 32 * WM, RB = 32 * NT * WN;
-    constexpr int NPA = (RA * 4 + 255) / 256, NPB = (RB * 4 + 255) / 256;          // 16-byte pieces per thread
-    __shared__ u32x4 lds[2][(RA + RB) * 4];
+    constexpr int NPA = (RA * 4 + 255) / 256, NPB = (RB * 4 + 255) / 256;          // 16-byte (8 x bf16) global pieces per thread
+    __shared__ u32x4 lds[2][(RA + RB) * 8];                                        // 128 bytes per row: 8 pieces of 4 fp32
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int i = lane & 31, h = lane >> 5;
@@ -85,12 +92,12 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
     const int n0 = nwg + wn * (32 * NT);
     const unsigned short* x = a.x + (size_t)z * a.x_bs;
     const unsigned short* w = a.w + (size_t)z * a.w_bs;
-    const uint32_t sel = h ? 0x03020c0cu : 0x01000c0cu;       // v_perm: high half kept / low half moved up = the bf16 as fp32
 
-    // what this thread stages: piece (row, q) -> lds[(row * 4 + (q ^ ((row >> 2) & 3)))]: the XOR spreads the rows of a 16-lane read
-    // group over all 64 banks (rows are 64 bytes = 16 banks apart)
+    // what this thread stages: global piece (row, q) = elements 8 q .. 8 q + 7 of the row's chunk -> even elements 4 q .. 4 q + 3 of the even half
+    // (LDS piece q) and of the odd half (LDS piece 4 + q); piece p of row r lives at lds[r * 8 + (p ^ ((r >> 1) & 7))]: the XOR spreads the 16 rows of a
+    // ds_read_b128 phase over all 64 banks (rows are 128 bytes = 32 banks apart)
     const unsigned short* arow[NPA];
-    int aiy0[NPA], aix0[NPA], aslot[NPA];
+    int aiy0[NPA], aix0[NPA], aslot[NPA], asw[NPA];
     bool aon[NPA];
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
@@ -103,17 +110,19 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
         const int oy = rem / a.OW, ox = rem - oy * a.OW;
         aiy0[j] = oy * a.stride - a.pad; aix0[j] = ox * a.stride - a.pad;
         arow[j] = x + (size_t)b * (H >> a.up) * (W >> a.up) * IC + q * 8;
-        aslot[j] = row * 4 + (q ^ ((row >> 2) & 3));
+        asw[j] = (row >> 1) & 7;
+        aslot[j] = row * 8 + q;
     }
     const unsigned short* brow[NPB];
-    int bslot[NPB];
+    int bslot[NPB], bsw[NPB];
     bool bon[NPB];
 #pragma unroll
     for (int j = 0; j < NPB; ++j) {
         const int idx = tid + 256 * j, row = idx >> 2, q = idx & 3;
         bon[j] = idx < RB * 4;
         brow[j] = w + (size_t)(nwg + (bon[j] ? row : 0)) * KT * IC + q * 8;
-        bslot[j] = (RA + row) * 4 + (q ^ ((row >> 2) & 3));
+        bsw[j] = ((RA + row) >> 1) & 7;
+        bslot[j] = (RA + row) * 8 + q;
     }
 
     float C[NT][16], S[PARTIAL ? NT : 1][16];
@@ -139,41 +148,58 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
         if (!PARTIAL) { if (++icb == nicb) { icb = 0; if (++kw == KW) { kw = 0; ++kh; } } }
         else { if (++kw == KW) { kw = 0; if (++kh == KH) { kh = 0; ++icb; } } }
     };
+    auto expand = [&](const u32x4& v, u32x4& ev, u32x4& od) {      // 4 packed bf16 pairs -> their low halves and their high halves as fp32 bit patterns
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ev[e] = v[e] << 16; od[e] = v[e] & 0xFFFF0000u; }
+    };
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < NPA; ++j) if (aon[j]) lds[buf][aslot[j]] = sa[j];
+        for (int j = 0; j < NPA; ++j) if (aon[j]) {
+            u32x4 ev, od; expand(sa[j], ev, od);
+            const int base = aslot[j] & ~7, q = aslot[j] & 7;
+            lds[buf][base + (q ^ asw[j])] = ev;
+            lds[buf][base + ((4 + q) ^ asw[j])] = od;
+        }
 #pragma unroll
-        for (int j = 0; j < NPB; ++j) if (bon[j]) lds[buf][bslot[j]] = sb[j];
+        for (int j = 0; j < NPB; ++j) if (bon[j]) {
+            u32x4 ev, od; expand(sb[j], ev, od);
+            const int base = bslot[j] & ~7, q = bslot[j] & 7;
+            lds[buf][base + (q ^ bsw[j])] = ev;
+            lds[buf][base + ((4 + q) ^ bsw[j])] = od;
+        }
     };
-    const int ra = wm * 32 + i, swa = (ra >> 2) & 3;
+    const int ra = wm * 32 + i, swa = (ra >> 1) & 7;
     int rb[NT], swb[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { rb[t] = RA + wn * (32 * NT) + t * 32 + i; swb[t] = ((rb[t] - RA) >> 2) & 3; }
+    for (int t = 0; t < NT; ++t) { rb[t] = RA + wn * (32 * NT) + t * 32 + i; swb[t] = (rb[t] >> 1) & 7; }
     auto compute = [&](int buf) {
         f32x32 acc[NT];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const u32x4 va = lds[buf][ra * 4 + (q ^ swa)];
+            const u32x4 va = lds[buf][ra * 8 + ((4 * h + q) ^ swa)];          // 4 consecutive operands of this lane's chain (h = 0: even, 1: odd)
             u32x4 vb[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) vb[t] = lds[buf][rb[t] * 4 + (q ^ swb[t])];
+            for (int t = 0; t < NT; ++t) vb[t] = lds[buf][rb[t] * 8 + ((4 * h + q) ^ swb[t])];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float fa = __uint_as_float(__builtin_amdgcn_perm(va[e], va[e], sel));
+                const float fa = __uint_as_float(va[e]);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const float fb = __uint_as_float(__builtin_amdgcn_perm(vb[t][e], vb[t][e], sel));
+                    const float fb = __uint_as_float(vb[t][e]);
                     if (q == 0 && e == 0) { const f32x32 zero = {0}; acc[t] = __builtin_amdgcn_mfma_f32_32x32x1f32(fa, fb, zero, 0, 0, 0); }
                     else acc[t] = __builtin_amdgcn_mfma_f32_32x32x1f32(fa, fb, acc[t], 0, 0, 0);
                 }
             }
         }
+        // chunk = even chain + odd chain, C += chunk: two values per v_pk_add_f32 (each component rounds like v_add_f32)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float c = acc[t][r] + acc[t][16 + r];      // chunk = even chain + odd chain
-                if (PARTIAL) S[t][r] = S[t][r] + c; else C[t][r] = C[t][r] + c;
+            for (int r = 0; r < 16; r += 2) {
+                const xf32x2 ev = {acc[t][r], acc[t][r + 1]}, od = {acc[t][16 + r], acc[t][17 + r]};
+                const xf32x2 c = ev + od;
+                if (PARTIAL) { xf32x2 s2 = {S[t][r], S[t][r + 1]}; s2 = s2 + c; S[t][r] = s2[0]; S[t][r + 1] = s2[1]; }
+                else { xf32x2 c2 = {C[t][r], C[t][r + 1]}; c2 = c2 + c; C[t][r] = c2[0]; C[t][r + 1] = c2[1]; }
             }
     };
 
