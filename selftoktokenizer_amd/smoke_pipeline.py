@@ -24,7 +24,9 @@ def run():
         x0 = pipe.encode_latents(synth.synthetic_images(1, device="cuda")).cpu()
         assert torch.equal(x0, torch.from_numpy(g["x0_bf16"][:1]).view(torch.bfloat16).float()), "VAE latents differ from the reference pipeline's"
         assert np.array_equal(tokens.cpu().numpy(), g["tokens"][:1].astype(np.int64)), "token ids from pixels differ from the reference pipeline's"
-        print("[smoke] exact-order VAE encoder: latents bit-equal to the reference pipeline's run, 512 / 512 token ids from pixels")
+        z = pipe.model.encoder.features(x0.cuda()).cpu().numpy()
+        assert pipe.model.encoder.mode == "exact" and int((z.view(np.uint32) != g["z"][:1].view(np.uint32)).sum()) == 0, "Q-Former features differ from the reference's"
+        print("[smoke] exact-order VAE encoder + Q-Former encoder: latents and pre-quantizer features bit-equal to the reference pipeline's run, 512 / 512 token ids from pixels")
     rec = pipe.decoding(tokens.cpu().numpy(), device="cuda", noise=synth.synthetic_noise(1), max_steps=2)
     assert tuple(rec.shape) == (1, 3, 256, 256) and rec.dtype == torch.bfloat16
     assert bool(torch.isfinite(rec.float()).all()) and float(rec.min()) >= 0.0 and float(rec.max()) <= 1.0
