@@ -310,23 +310,31 @@ int selftok_vx_expf_f32(const float* x, float* y, long n, hipStream_t stream);
  *
  * selftok_ex_linear_f32: out[m][n] = bias[n] + sum_k x[m][k] w[n][k]   (modules.py:109,186-199,293 ...; F.linear)
  *   x rows at stride ldx (a column slice of a fused projection is fine; 16-byte aligned), w [N][K] contiguous, K % 16 == 0.
- *   gelu != 0: out = GELU_tanh(out) (timm Mlp fc1 -> act).  res != NULL: out = res[m % res_mod][n] + (gate ? gate[m % gate_mod][n] * out : out)
- *   with the product and the sum rounded separately (`x + attn`, `q + gate(q_attn, g)`, modules.py:322-326); res_mod / gate_mod 0 = no modulo.
+ *   flags (`gelu`): bit 0: out = GELU_tanh(out) (timm Mlp fc1 -> act); bit 1 (SELFTOK_EX_BIAS_LAST): out = (sum of the K-blocks) + bias instead of
+ *   ((bias + c0) + c1) + ... -- what at::linear computes for a NON-CONTIGUOUS input (matmul on a copy, then add_(bias)): the attention projections of the
+ *   MMDiT's joint block read slices of the concatenated attention output (sd3/mmdit.py:537-541, 298-299).  res != NULL: out = res[row(m, res_mod)][n] + (gate ? gate[row(m, gate_mod)][n] * out : out)
+ *   with the product and the sum rounded separately (`x + attn`, `q + gate(q_attn, g)`, modules.py:322-326); row(m, d) = m % d for d > 0 (per-token
+ *   tables), m / -d for d < 0 (per-sample tables: -d rows per sample, sd3/mmdit.py:485-496 't_emb'), m for d == 0.
  *   out may alias res. */
+#define SELFTOK_EX_GELU 1
+#define SELFTOK_EX_BIAS_LAST 2
 int selftok_ex_linear_f32(const float* x, long ldx, const float* w, const float* bias, const float* res, long ldr, int res_mod, const float* gate,
                           long ldg, int gate_mod, float* out, long ldo, long M, int N, int K, int gelu, hipStream_t stream);
 /* nn.LayerNorm(N, eps) [affine gamma / beta or NULL] followed, when shift / scale are given, by the reference's modulate
- * `x * (1 + scale[tok]) + shift[tok]` (modules.py:29-32), tok = row % T, table rows at stride ldt.  stats (may be NULL): [rows][2] mean, rstd. */
+ * `x * (1 + scale[tok]) + shift[tok]` (modules.py:29-32), tok = row % T (T > 0) or row / -T (T < 0: per-sample tables), table rows at stride ldt.  stats (may be NULL): [rows][2] mean, rstd. */
 int selftok_ex_layernorm_mod_f32(const float* x, long ldx, float* out, long ldo, const float* shift, const float* scale, long ldt, int T, const float* gamma,
                                  const float* beta, float* stats, long rows, int N, float eps, hipStream_t stream);
 /* element-wise: mode 0 GELU(tanh) (ATen GeluKernelImpl), 1 SiLU, and the building blocks 2 Sleef expf_u10, 3 Sleef tanhf_u10, 4 ATen exp_u20 */
 int selftok_ex_unary_f32(const float* x, float* y, long n, int mode, hipStream_t stream);
-/* F.scaled_dot_product_attention (no mask) as ATen's fp32 flash kernel evaluates it.  q [B][Tq][..] rows at stride qs, head h = columns
- * h*D .. h*D+D-1; keys / values [B][Tk1][..] at stride kvs1 and an optional second segment (Tk2 rows, stride kvs2) that follows the first
- * (`torch.cat([k, query_k], dim=2)`, modules.py:250-251); out [B][Tq][H*D].  workspace >= selftok_ex_attention_workspace_bytes. */
+/* F.scaled_dot_product_attention as ATen's fp32 flash kernel evaluates it.  q [B][Tq][..] rows at stride qs, head h = columns h*D .. h*D+D-1;
+ * first key / value segment: Tk1 key SLOTS of which the first valid1 are visible, held in k1 / v1 [B][rows1][..] at stride kvs1 (rows1 >= valid1; the
+ * encoder: valid1 == rows1 == Tk1 -- no mask; the MMDiT's prefix-visibility mask `arange(K) <= k`, sd3/mmdit.py:1041-1094: Tk1 = K, valid1 = k + 1 --
+ * masked keys keep their position in the kv blocks of 512 and in MKL's K-blocks, contribute exp = 0 and 0 * v, and are never read); optional second
+ * segment (Tk2 rows, stride kvs2) that follows the first (`torch.cat([k, query_k], dim=2)`, modules.py:250-251; the image tokens of the joint
+ * attention, sd3/mmdit.py:519-536); out [B][Tq][H*D].  workspace >= selftok_ex_attention_workspace_bytes(B, H, Tq, Tk1 + Tk2, D). */
 size_t selftok_ex_attention_workspace_bytes(int B, int H, int Tq, int Tk, int D);
-int selftok_ex_attention_f32(const float* q, long qs, const float* k1, const float* v1, long kvs1, int Tk1, const float* k2, const float* v2, long kvs2, int Tk2,
-                             float* out, void* workspace, int B, int H, int Tq, int D, hipStream_t stream);
+int selftok_ex_attention_f32(const float* q, long qs, const float* k1, const float* v1, long kvs1, int Tk1, int valid1, int rows1, const float* k2, const float* v2,
+                             long kvs2, int Tk2, float* out, void* workspace, int B, int H, int Tq, int D, hipStream_t stream);
 
 #ifdef __cplusplus
 }

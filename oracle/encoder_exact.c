@@ -308,8 +308,18 @@ float xe_expf(float x) {                             /* glibc 2.35 expf = std::e
 /* q [B][Tq][*] with row stride qs, head h at column h*D; k, v likewise with Tk rows; a second key/value segment (k2, v2: Tk2 rows, may
  * be NULL) follows the first (`torch.cat([k, query_k], dim=2)`, modules.py:250-251).  out [B][Tq][H*D] (the transpose(1,2).reshape of
  * the reference).  kv blocks of 512 run across the concatenation. */
+void xe_attention_masked(const float* Q, long qs, const float* K1, const float* V1, long kvs1, int Tk1, int valid1, int rows1, const float* K2, const float* V2, long kvs2,
+                          int Tk2, float* O, int B, int H, int Tq, int D);
 void xe_attention(const float* Q, long qs, const float* K1, const float* V1, long kvs1, int Tk1, const float* K2, const float* V2, long kvs2,
                   int Tk2, float* O, int B, int H, int Tq, int D) {
+    xe_attention_masked(Q, qs, K1, V1, kvs1, Tk1, Tk1, Tk1, K2, V2, kvs2, Tk2, O, B, H, Tq, D);
+}
+/* ... with a key mask on the first segment: keys valid1 .. Tk1-1 are masked out (`attn_mask`: a bool mask becomes 0 / -inf added to the scaled scores,
+ * the MMDiT's prefix-visibility mask, sd3/mmdit.py:1041-1094).  Masked keys keep their POSITION: they contribute exp = 0 to the lane sums and 0 * v to
+ * the P V chains (bit-neutral), but the kv blocks of 512 and MKL's K-blocks inside them are those of the full key sequence -- dropping the
+ * masked keys instead changes the result's bits (probed).  K1 / V1 hold rows1 >= valid1 rows per batch; rows at and beyond valid1 are never read. */
+void xe_attention_masked(const float* Q, long qs, const float* K1, const float* V1, long kvs1, int Tk1, int valid1, int rows1, const float* K2, const float* V2, long kvs2,
+                         int Tk2, float* O, int B, int H, int Tq, int D) {
     const float scale = (float)(1.0 / sqrt((double)D));
     const int Tk = Tk1 + Tk2, kvsplit = 512;
 #pragma omp parallel for collapse(3) schedule(dynamic, 8)
@@ -318,19 +328,22 @@ void xe_attention(const float* Q, long qs, const float* K1, const float* V1, lon
             for (int i = 0; i < Tq; i++) {
                 const float* q = Q + ((size_t)b * Tq + i) * qs + h * D;
                 float s[512], p[512], dst[128];
+                for (int d = 0; d < D; d++) dst[d] = 0.f;
                 float m_old = -INFINITY, sum_old = 0.f;
                 for (int n0 = 0; n0 < Tk; n0 += kvsplit) {
                     const int nb = Tk - n0 < kvsplit ? Tk - n0 : kvsplit;
                     float bm = -INFINITY;
                     for (int j = 0; j < nb; j++) {
                         const int t = n0 + j;
-                        const float* kr = t < Tk1 ? K1 + ((size_t)b * Tk1 + t) * kvs1 + h * D : K2 + ((size_t)b * Tk2 + (t - Tk1)) * kvs2 + h * D;
+                        if (t >= valid1 && t < Tk1) { s[j] = -INFINITY; continue; }
+                        const float* kr = t < Tk1 ? K1 + ((size_t)b * rows1 + t) * kvs1 + h * D : K2 + ((size_t)b * Tk2 + (t - Tk1)) * kvs2 + h * D;
                         float c = 0.f;
                         for (int k = 0; k < D; k++) c = fmaf(q[k], kr[k], c);
                         s[j] = c * scale;
                         if (s[j] > bm) bm = s[j];
                     }
                     const float m_new = m_old > bm ? m_old : bm;
+                    if (m_new == -INFINITY) continue;          /* every key so far masked: ATen zero-fills the probabilities, max / sum / accumulator stay (dst from a previous block: none yet) */
                     float lane[16];
                     for (int l = 0; l < 16; l++) lane[l] = 0.f;
                     for (int j = 0; j < nb; j++) { float e = xe_exp_u20(s[j] - m_new); lane[j % 16] += e; p[j] = e; }
@@ -345,7 +358,8 @@ void xe_attention(const float* Q, long qs, const float* K1, const float* V1, lon
                             float acc = 0.f;
                             for (int j = j0; j < j0 + kb; j++) {
                                 const int t = n0 + j;
-                                const float vv = t < Tk1 ? V1[((size_t)b * Tk1 + t) * kvs1 + h * D + d] : V2[((size_t)b * Tk2 + (t - Tk1)) * kvs2 + h * D + d];
+                                const float vv = t < Tk1 ? (t < valid1 ? V1[((size_t)b * rows1 + t) * kvs1 + h * D + d] : 0.0f)
+                                                         : V2[((size_t)b * Tk2 + (t - Tk1)) * kvs2 + h * D + d];
                                 acc = fmaf(p[j], vv, acc);
                             }
                             c = c + acc;

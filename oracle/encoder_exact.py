@@ -76,7 +76,8 @@ def patch_embed(x, w, b, bias_first=0):
     return y
 
 
-def attention(q, k1, v1, heads, k2=None, v2=None):
+def attention(q, k1, v1, heads, k2=None, v2=None, valid1=None, slots1=None):
+    """`valid1` / `slots1`: the first segment occupies slots1 key positions of which the first valid1 are visible (k1 / v1 hold >= valid1 rows)"""
     """q [B,Tq,H*D] (a strided view of a fused projection is fine: last dim contiguous), k1/v1 [B,Tk1,H*D], optional second segment"""
     def rs(a):
         assert a.strides[-1] == 4 and a.strides[0] == a.shape[1] * a.strides[1], "rows must be equally strided"
@@ -84,8 +85,9 @@ def attention(q, k1, v1, heads, k2=None, v2=None):
     B, Tq, HD = q.shape; D = HD // heads
     out = np.empty((B, Tq, HD), np.float32)
     Tk2 = 0 if k2 is None else k2.shape[1]
-    lib().xe_attention(_p(q), C.c_long(rs(q)), _p(k1), _p(v1), C.c_long(rs(k1)), k1.shape[1], _p(k2), _p(v2), C.c_long(rs(k2) if k2 is not None else 0), Tk2,
-                       _p(out), B, heads, Tq, D)
+    slots = k1.shape[1] if slots1 is None else int(slots1)
+    lib().xe_attention_masked(_p(q), C.c_long(rs(q)), _p(k1), _p(v1), C.c_long(rs(k1)), slots, k1.shape[1] if valid1 is None else int(valid1), k1.shape[1],
+                              _p(k2), _p(v2), C.c_long(rs(k2) if k2 is not None else 0), Tk2, _p(out), B, heads, Tq, D)
     return out
 
 

@@ -968,8 +968,8 @@ int selftok_vx_expf_f32(const float* x, float* y, long n, hipStream_t s)
 /* ---- the exact-order Q-Former encoder entries (include/selftok_hip.h, round 5): the CPU twin IS oracle/encoder_exact.c ------------ */
 void xe_linear(const float* x, const float* w, const float* bias, float* out, long M, int N, int K);
 void xe_layernorm(const float* X, float* Y, const float* gamma, const float* beta, long rows, int N, float eps, float* stats);
-void xe_attention(const float* Q, long qs, const float* K1, const float* V1, long kvs1, int Tk1, const float* K2, const float* V2, long kvs2, int Tk2, float* O,
-                  int B, int H, int Tq, int D);
+void xe_attention_masked(const float* Q, long qs, const float* K1, const float* V1, long kvs1, int Tk1, int valid1, int rows1, const float* K2, const float* V2, long kvs2,
+                         int Tk2, float* O, int B, int H, int Tq, int D);
 float xe_gelu_tanh1(float v);
 float xe_silu1(float v);
 float xe_sleef_expf(float v);
@@ -986,11 +986,12 @@ int selftok_ex_linear_f32(const float* x, long ldx, const float* w, const float*
     float* yc = (float*)malloc((size_t)M * N * sizeof(float));
     if (!xc || !yc) { free(xc); free(yc); return fail("ex_linear: out of memory"); }
     for (long m = 0; m < M; ++m) memcpy(xc + (size_t)m * K, x + (size_t)m * ldx, (size_t)K * sizeof(float));
-    xe_linear(xc, w, bias, yc, M, N, K);
+    xe_linear(xc, w, (gelu & 2) ? NULL : bias, yc, M, N, K);
     for (long m = 0; m < M; ++m)
         for (int n = 0; n < N; ++n) {
             float v = yc[(size_t)m * N + n];
-            if (gelu) v = xe_gelu_tanh1(v);
+            if ((gelu & 2) && bias) v = v + bias[n];
+            if (gelu & 1) v = xe_gelu_tanh1(v);
             if (gate) v = gate[(size_t)(gate_mod ? m % gate_mod : m) * ldg + n] * v;
             if (res) v = res[(size_t)(res_mod ? m % res_mod : m) * ldr + n] + v;
             out[(size_t)m * ldo + n] = v;
@@ -1035,14 +1036,14 @@ size_t selftok_ex_attention_workspace_bytes(int B, int H, int Tq, int Tk, int D)
     return rows * Tk * 4 + (size_t)B * H * D * Tk * 4 + rows * 4 * (size_t)(nb > 1 ? nb - 1 : 1) + rows * 4;      /* the GPU library's size */
 }
 
-int selftok_ex_attention_f32(const float* q, long qs, const float* k1, const float* v1, long kvs1, int Tk1, const float* k2, const float* v2, long kvs2, int Tk2,
-                             float* out, void* workspace, int B, int H, int Tq, int D, hipStream_t s)
+int selftok_ex_attention_f32(const float* q, long qs, const float* k1, const float* v1, long kvs1, int Tk1, int valid1, int rows1, const float* k2, const float* v2,
+                             long kvs2, int Tk2, float* out, void* workspace, int B, int H, int Tq, int D, hipStream_t s)
 {
     (void)s; (void)workspace;
     if (B == 0) return SELFTOK_OK;
-    if (!q || !k1 || !v1 || !out || B < 0 || H <= 0 || Tq <= 0 || Tk1 <= 0 || Tk2 < 0 || (Tk2 > 0 && (!k2 || !v2)) || D % 16 || D <= 0 || D > 128 || Tk1 % 16 ||
-        Tk2 % 16 || qs % 4 || kvs1 % 4 || kvs2 % 4)
+    if (!q || !out || B < 0 || H <= 0 || Tq <= 0 || Tk1 <= 0 || Tk2 < 0 || valid1 < 0 || valid1 > Tk1 || rows1 < valid1 || (valid1 > 0 && (!k1 || !v1)) ||
+        (Tk2 > 0 && (!k2 || !v2)) || D % 16 || D <= 0 || D > 128 || Tk1 % 16 || Tk2 % 16 || qs % 4 || kvs1 % 4 || kvs2 % 4 || (valid1 == 0 && Tk2 == 0))
         return fail("ex_attention: bad argument");
-    xe_attention(q, qs, k1, v1, kvs1, Tk1, k2, v2, kvs2, Tk2, out, B, H, Tq, D);
+    xe_attention_masked(q, qs, k1, v1, kvs1, Tk1, valid1, rows1, k2, v2, kvs2, Tk2, out, B, H, Tq, D);
     return SELFTOK_OK;
 }

@@ -192,13 +192,13 @@ struct XeGemmArgs {
     const float* b; long ldb, b_bs, b_hs;      // B[z][n][k]
     float* c; long ldc, c_bs, c_hs;            // C[z][m][n]
     const float* bias;                          // mode 0: [N] or null
-    const float* res; long ldr; int res_mod;    // mode 0: y = res[m % res_mod (0: m)][n] + (gate ? gate * y : y)
-    const float* gate; long ldg; int gate_mod;  //         gate[m % gate_mod][n]
+    const float* res; long ldr; int res_mod;    // mode 0: y = res[row(m, res_mod)][n] + (gate ? gate * y : y); row(m, d) = m % d (d > 0: per-token table), m / -d (d < 0: per-sample), m (0)
+    const float* gate; long ldg; int gate_mod;  //         gate[row(m, gate_mod)][n]
     const float* rescale;                       // mode 2: [nres][Z * M]: C *= rescale[i][z M + m] before K-block j (bit j of rescale_mask; i = its rank)
     const float* rowscale;                      // mode 2: [Z * M]: out = C * rowscale
     float out_scale;                            // mode 1: out = C * out_scale
     int M, N, K, H;
-    int mode, gelu;
+    int mode, gelu;                             // gelu: bit 0 GELU(tanh) epilogue, bit 1 bias added after the K-blocks instead of before
     int nblk;
     int blk_end[XE_MAXBLK];                     // K-block ends (multiples of 4; K itself a multiple of 16)
     unsigned rescale_mask;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void xe_gemm_kernel(XeGemmArgs g)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = n0 + t * 32 + i;
-        const float b0 = (g.mode == 0 && g.bias != nullptr && n < g.N) ? g.bias[n] : 0.f;
+        const float b0 = (g.mode == 0 && g.bias != nullptr && n < g.N && !(g.gelu & 2)) ? g.bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { C[t][r] = b0; acc[t][r] = 0.f; }
     }
@@ -330,9 +330,10 @@ __global__ __launch_bounds__(256) void xe_gemm_kernel(XeGemmArgs g)
             if (g.mode == 1) v = v * g.out_scale;
             else if (g.mode == 2) v = v * g.rowscale[(size_t)z * g.M + m];
             else {
-                if (g.gelu) v = xe_gelu_tanh1(v);
-                if (g.gate != nullptr) v = g.gate[(size_t)(g.gate_mod ? m % g.gate_mod : m) * g.ldg + n] * v;
-                if (g.res != nullptr) v = g.res[(size_t)(g.res_mod ? m % g.res_mod : m) * g.ldr + n] + v;
+                if ((g.gelu & 2) && g.bias != nullptr) v = v + g.bias[n];          // bias LAST: at::linear on a non-contiguous input = matmul, then add_(bias)
+                if (g.gelu & 1) v = xe_gelu_tanh1(v);
+                if (g.gate != nullptr) v = g.gate[(size_t)(g.gate_mod > 0 ? m % g.gate_mod : (g.gate_mod < 0 ? m / -g.gate_mod : m)) * g.ldg + n] * v;
+                if (g.res != nullptr) v = g.res[(size_t)(g.res_mod > 0 ? m % g.res_mod : (g.res_mod < 0 ? m / -g.res_mod : m)) * g.ldr + n] + v;
             }
             Cout[(size_t)m * g.ldc + n] = v;
         }
@@ -450,8 +451,9 @@ __global__ __launch_bounds__(256) void xe_ln_kernel(const float* __restrict__ x,
     if (stats != nullptr && l == 0) { stats[2 * row] = m1; stats[2 * row + 1] = rstd; }
     const float nmean = -m1;
     float* yr = y + (size_t)row * ldy;
-    const float* sh = shift != nullptr ? shift + (size_t)(row % T) * ldt : nullptr;
-    const float* sc = scale != nullptr ? scale + (size_t)(row % T) * ldt : nullptr;
+    const long tok = T > 0 ? row % T : row / -T;                       // T > 0: per-token tables (row % T); T < 0: per-sample (row / -T)
+    const float* sh = shift != nullptr ? shift + (size_t)tok * ldt : nullptr;
+    const float* sc = scale != nullptr ? scale + (size_t)tok * ldt : nullptr;
     for (int e0 = l * 4; e0 < N; e0 += 32) {       // 8 threads x 16 bytes = one 128-byte line per step
         const float4 v = *reinterpret_cast<const float4*>(xr + e0);
         float o[4] = {v.x, v.y, v.z, v.w};
@@ -472,7 +474,8 @@ __global__ __launch_bounds__(256) void xe_ln_kernel(const float* __restrict__ x,
 // s [rows][Tk] scaled scores -> p (in place) un-normalised probabilities, each kv block of 512 relative to the running maximum after it;
 // rescale [nb - 1][rows] = expf(max before block j - max after block j) for j >= 1; rowscale [rows] = 1 / sum.  16 threads per row:
 // lane = key mod 16 sums its probabilities sequentially, then the 8 / 4 / 2 / 1 fold of vec_reduce_all.  Tk % 16 == 0.
-__global__ __launch_bounds__(256) void xe_softmax_kernel(float* __restrict__ s, float* __restrict__ rescale, float* __restrict__ rowscale, long rows, int Tk)
+// keys mlo .. mhi-1 are masked out (never computed, never read): score -inf, probability 0 written.
+__global__ __launch_bounds__(256) void xe_softmax_kernel(float* __restrict__ s, float* __restrict__ rescale, float* __restrict__ rowscale, long rows, int Tk, int mlo, int mhi)
 {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long row = gid >> 4;
@@ -486,10 +489,20 @@ __global__ __launch_bounds__(256) void xe_softmax_kernel(float* __restrict__ s, 
         float v[32];
         float bm = -__builtin_inff();
 #pragma unroll
-        for (int k = 0; k < 32; ++k) if (k < cnt) { v[k] = sr[n0 + 16 * k + l]; bm = fmaxf(bm, v[k]); }
+        for (int k = 0; k < 32; ++k) if (k < cnt) {
+            const int key = n0 + 16 * k + l;
+            v[k] = (key >= mlo && key < mhi) ? -__builtin_inff() : sr[key];
+            bm = fmaxf(bm, v[k]);
+        }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o, WAVE));
         const float m_new = m_old > bm ? m_old : bm;
+        if (m_new == -__builtin_inff()) {          // every key so far masked: ATen zero-fills the block's probabilities and leaves max / sum / accumulator alone
+#pragma unroll
+            for (int k = 0; k < 32; ++k) if (k < cnt) sr[n0 + 16 * k + l] = 0.f;
+            if (jb > 0 && l == 0) rescale[(size_t)(jb - 1) * rows + row] = 1.0f;
+            continue;
+        }
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 32; ++k) if (k < cnt) { const float e = xe_exp_u20(v[k] - m_new); acc += e; sr[n0 + 16 * k + l] = e; }
@@ -504,14 +517,15 @@ __global__ __launch_bounds__(256) void xe_softmax_kernel(float* __restrict__ s, 
 }
 
 // v [B][T][*] (row stride vs, head h at column h D) -> vt [B][H][D][Tk] at key offset t_off: the P V product reads V as [d][key]
-__global__ void xe_transpose_v_kernel(const float* __restrict__ v, long vs, float* __restrict__ vt, int T, int H, int D, int Tk, int t_off)
+// T = key slots of this segment, `valid` of them present (rows valid .. T-1 are masked keys: zeros, never read), `rows` = rows per batch in v
+__global__ void xe_transpose_v_kernel(const float* __restrict__ v, long vs, float* __restrict__ vt, int T, int valid, int rows, int H, int D, int Tk, int t_off)
 {
     __shared__ float tile[32][33];
     const int z = blockIdx.z, b = z / H, h = z - b * H;
     const int t0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int r = ty; r < 32; r += 8)
-        if (t0 + r < T && d0 + tx < D) tile[r][tx] = v[((size_t)b * T + t0 + r) * vs + h * D + d0 + tx];
+        if (t0 + r < T && d0 + tx < D) tile[r][tx] = (t0 + r < valid) ? v[((size_t)b * rows + t0 + r) * vs + h * D + d0 + tx] : 0.0f;
     __syncthreads();
     for (int r = ty; r < 32; r += 8)
         if (d0 + r < D && t0 + tx < T) vt[((size_t)z * D + d0 + r) * Tk + t_off + t0 + tx] = tile[tx][r];
@@ -544,11 +558,11 @@ int selftok_ex_layernorm_mod_f32(const float* x, long ldx, float* out, long ldo,
                                  const float* beta, float* stats, long rows, int N, float eps, hipStream_t stream)
 {
     if (rows == 0) return SELFTOK_OK;
-    if (!x || !out || rows < 0 || N <= 0 || N % 8 || N > 4096 || ldx % 4 || ldo % 4 || ((shift == nullptr) != (scale == nullptr)) || (scale && T <= 0)) {
+    if (!x || !out || rows < 0 || N <= 0 || N % 8 || N > 4096 || ldx % 4 || ldo % 4 || ((shift == nullptr) != (scale == nullptr)) || (scale && T == 0)) {
         set_last_error("ex_layernorm: need N % 8 == 0, N <= 4096, 16-byte aligned rows, shift and scale together"); return SELFTOK_EINVAL;
     }
     const long threads = rows * 8;
-    hipLaunchKernelGGL(xe_ln_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, ldx, out, ldo, shift, scale, ldt, T > 0 ? T : 1, gamma, beta,
+    hipLaunchKernelGGL(xe_ln_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, ldx, out, ldo, shift, scale, ldt, T != 0 ? T : 1, gamma, beta,
                        rows, N, eps, stats);
     return check_launch("xe_ln_kernel");
 }
@@ -569,16 +583,18 @@ size_t selftok_ex_attention_workspace_bytes(int B, int H, int Tq, int Tk, int D)
     return rows * Tk * 4 + (size_t)B * H * D * Tk * 4 + rows * 4 * (size_t)(nb > 1 ? nb - 1 : 1) + rows * 4;
 }
 
-/* q [B][Tq][..] row stride qs; k1 / v1 [B][Tk1][..] row stride kvs1; optional second key / value segment k2 / v2 [B][Tk2][..] row stride kvs2
- * (`torch.cat([k, query_k], dim=2)`); head h at column h D of every row; out [B][Tq][H D] contiguous. */
-int selftok_ex_attention_f32(const float* q, long qs, const float* k1, const float* v1, long kvs1, int Tk1, const float* k2, const float* v2, long kvs2, int Tk2,
-                             float* out, void* workspace, int B, int H, int Tq, int D, hipStream_t stream)
+/* q [B][Tq][..] row stride qs; k1 / v1 [B][rows1][..] row stride kvs1 holding the first valid1 of the segment's Tk1 key slots (valid1 == rows1 == Tk1: no
+ * mask); optional second key / value segment k2 / v2 [B][Tk2][..] row stride kvs2 (`torch.cat([k, query_k], dim=2)`); head h at column h D of every row;
+ * out [B][Tq][H D] contiguous. */
+int selftok_ex_attention_f32(const float* q, long qs, const float* k1, const float* v1, long kvs1, int Tk1, int valid1, int rows1, const float* k2, const float* v2,
+                             long kvs2, int Tk2, float* out, void* workspace, int B, int H, int Tq, int D, hipStream_t stream)
 {
     if (B == 0) return SELFTOK_OK;
     const int Tk = Tk1 + Tk2;
-    if (!q || !k1 || !v1 || !out || !workspace || B < 0 || H <= 0 || Tq <= 0 || Tk1 <= 0 || Tk2 < 0 || (Tk2 > 0 && (!k2 || !v2)) || D % 16 || D <= 0 || D > 128 ||
-        Tk1 % 16 || Tk2 % 16 || qs % 4 || kvs1 % 4 || kvs2 % 4) {
-        set_last_error("ex_attention: need head_dim % 16 == 0 (<= 128), key counts % 16 == 0, 16-byte aligned rows"); return SELFTOK_EINVAL;
+    if (!q || !out || !workspace || B < 0 || H <= 0 || Tq <= 0 || Tk1 <= 0 || Tk2 < 0 || valid1 < 0 || valid1 > Tk1 || rows1 < valid1 || (valid1 > 0 && (!k1 || !v1)) ||
+        (Tk2 > 0 && (!k2 || !v2)) || D % 16 || D <= 0 || D > 128 || Tk1 % 16 || Tk2 % 16 || qs % 4 || kvs1 % 4 || kvs2 % 4 || (valid1 == 0 && Tk2 == 0)) {
+        set_last_error("ex_attention: need head_dim % 16 == 0 (<= 128), key slot counts % 16 == 0, 16-byte aligned rows, 0 <= valid1 <= Tk1 <= ..., at least one visible key");
+        return SELFTOK_EINVAL;
     }
     const int Z = B * H;
     const size_t rows = (size_t)Z * Tq;
@@ -587,28 +603,29 @@ int selftok_ex_attention_f32(const float* q, long qs, const float* k1, const flo
     float* vt = s + rows * Tk;
     float* rescale = vt + (size_t)Z * D * Tk;
     float* rowscale = rescale + rows * (size_t)(nb > 1 ? nb - 1 : 1);
-    // scores, one launch per key segment: rows = queries, columns = keys, one chain over head_dim, * 1/sqrt(D)
+    // scores, one launch per key segment: rows = queries, columns = keys, one chain over head_dim, * 1/sqrt(D); masked keys are not computed
     for (int seg = 0; seg < (Tk2 > 0 ? 2 : 1); ++seg) {
+        if (seg == 0 && valid1 == 0) continue;
         XeGemmArgs g{};
         g.a = q; g.lda = qs; g.a_bs = (long)Tq * qs; g.a_hs = D;
-        g.b = seg ? k2 : k1; g.ldb = seg ? kvs2 : kvs1; g.b_bs = (long)(seg ? Tk2 : Tk1) * g.ldb; g.b_hs = D;
+        g.b = seg ? k2 : k1; g.ldb = seg ? kvs2 : kvs1; g.b_bs = (long)(seg ? Tk2 : rows1) * g.ldb; g.b_hs = D;
         g.c = s + (seg ? Tk1 : 0); g.ldc = Tk; g.c_bs = (long)H * Tq * Tk; g.c_hs = (long)Tq * Tk;
-        g.M = Tq; g.N = seg ? Tk2 : Tk1; g.K = D; g.H = H; g.mode = 1; g.out_scale = (float)(1.0 / sqrt((double)D));
+        g.M = Tq; g.N = seg ? Tk2 : valid1; g.K = D; g.H = H; g.mode = 1; g.out_scale = (float)(1.0 / sqrt((double)D));
         g.nblk = mkl_blocks(D, 0, g.blk_end, 0);
         int rc = launch_xe_gemm(g, Z, stream);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(xe_softmax_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, stream, s, rescale, rowscale, (long)rows, Tk);
+    hipLaunchKernelGGL(xe_softmax_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, stream, s, rescale, rowscale, (long)rows, Tk, valid1, Tk1);
     int rc = check_launch("xe_softmax_kernel");
     if (rc) return rc;
     for (int seg = 0; seg < (Tk2 > 0 ? 2 : 1); ++seg) {
         const int T = seg ? Tk2 : Tk1;
-        hipLaunchKernelGGL(xe_transpose_v_kernel, dim3((T + 31) / 32, (D + 31) / 32, Z), dim3(256), 0, stream, seg ? v2 : v1, seg ? kvs2 : kvs1, vt, T, H, D, Tk,
-                           seg ? Tk1 : 0);
+        hipLaunchKernelGGL(xe_transpose_v_kernel, dim3((T + 31) / 32, (D + 31) / 32, Z), dim3(256), 0, stream, seg ? v2 : v1, seg ? kvs2 : kvs1, vt, T, seg ? Tk2 : valid1,
+                           seg ? Tk2 : rows1, H, D, Tk, seg ? Tk1 : 0);
         rc = check_launch("xe_transpose_v_kernel");
         if (rc) return rc;
     }
-    // P V: reduction over the keys; every kv block of 512 is one MKL call (K = block length -> its own K-blocks), C *= rescale between them
+    // P V: reduction over the key SLOTS; every kv block of 512 is one MKL call (K = block length -> its own K-blocks), C *= rescale between them
     XeGemmArgs g{};
     g.a = s; g.lda = Tk; g.a_bs = (long)H * Tq * Tk; g.a_hs = (long)Tq * Tk;
     g.b = vt; g.ldb = Tk; g.b_bs = (long)H * D * Tk; g.b_hs = (long)D * Tk;

@@ -129,7 +129,11 @@ class QformerEncoderGPU(ModuleSurface):
         return F.layer_norm(codes, (16,), self.w["encoder.final_layer_norm3.weight"], self.w["encoder.final_layer_norm3.bias"], 1e-6)
 
     def codes_ln(self, ids: torch.Tensor) -> torch.Tensor:
-        """fused codebook[ids] -> final_layer_norm3 (SelftokPipeline.py:236-240)"""
+        """fused codebook[ids] -> final_layer_norm3 (SelftokPipeline.py:236-240).  exact mode: the gather is a copy, the LayerNorm(16) runs in ATen's
+        arithmetic (csrc/encoder_exact.hip) -- the fused kernel's own LayerNorm is within 7e-7 of it, which is the decoder's conditioning"""
+        if self.mode == "exact":
+            codes = self.codebook[ids.reshape(-1).long()].reshape(*ids.shape, -1).contiguous()
+            return ops.ex_layernorm_mod(codes, gamma=self.w["encoder.final_layer_norm3.weight"], beta=self.w["encoder.final_layer_norm3.bias"])
         return ops.code_gather_ln(ids, self.codebook, self.w["encoder.final_layer_norm3.weight"], self.w["encoder.final_layer_norm3.bias"])
 
     def get_encoder_mask(self, x, d, single_token=False):

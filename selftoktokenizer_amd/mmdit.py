@@ -34,7 +34,7 @@ from .weights import DIT_DEPTH, DIT_HEADS, DIT_HIDDEN, POS_MAX_DIT
 
 class MMDiTGPU(ModuleSurface):
     _sd_prefix = "model."
-    GEMM_MODES = ("fp32", "f16x2")
+    GEMM_MODES = ("fp32", "f16x2", "exact")
     PRESPLIT = True     # f16x2 mode: producers (LN-modulate, attention, fc1+GELU) hand the next Linear its input already split
     SPLITK = True       # f16x2 mode, <= ops.SPLITK_MAX_ROWS rows (one .. four images): several work-groups per output tile (ops.f16x2_ksplit)
 
@@ -44,6 +44,7 @@ class MMDiTGPU(ModuleSurface):
         self._packed = {}                                                   # linear name -> f16x2-split weight image
         self._mod_cache = {}                                                # (timestep name, gemm mode) -> modulations of a single-image step
         self._capture_refs = None                                           # list while a caller captures a hipGraph (see _step_modulations)
+        self._trace = None                                                  # tests: a list that receives the image stream after every joint block
         self.overflow = torch.zeros(1, dtype=torch.int32, device=device)    # sticky fp16-range flag of the split GEMMs
         self.w = {k: v.to(device=device, dtype=torch.float32).contiguous() for k, v in sd.items() if k.startswith("model.")}
         H = DIT_HIDDEN
@@ -61,6 +62,7 @@ class MMDiTGPU(ModuleSurface):
             h = self.lin(p + ".t_embedder.mlp.2", ops.silu(h))
             self.ctx_tables.append(self.lin(p + ".adaLN_modulation.1", ops.silu(h)).contiguous())
         self.context_pos_embed = self.w["model.context_pos_embed"][0].contiguous()                    # [K,H]
+        self._tables_fast, self._tables_exact = self.ctx_tables, None
         if gemm != "fp32":
             self.set_gemm(gemm)
 
@@ -74,6 +76,9 @@ class MMDiTGPU(ModuleSurface):
         call by the pipeline, which then recomputes in 'fp32').  Returns the mode in force."""
         if mode not in self.GEMM_MODES:
             raise ValueError(f"gemm mode {mode!r}: expected one of {self.GEMM_MODES}")
+        if mode == "exact":
+            self._build_exact()
+        self.ctx_tables = self._tables_exact if mode == "exact" else self._tables_fast
         if mode == "f16x2" and not self._packed:
             flag = torch.zeros(1, dtype=torch.int32, device=self.device)
             packed = {}
@@ -90,10 +95,38 @@ class MMDiTGPU(ModuleSurface):
         self.gemm = mode
         return mode
 
+    # ---- 'exact': every Linear / LayerNorm / GELU / SiLU / attention as the sequence of fp32 operations torch-CPU executes for the reference ----
+    def _build_exact(self):
+        """the input-independent pieces of the exact mode, once: the context adaLN tables through the exact Linear / SiLU from the reference's
+        position table (selftoktokenizer_amd/data), the PatchEmbed convolution as a Linear over the (kh, kw, ic)-ordered patch"""
+        if self._tables_exact is not None or self.renderer:
+            if self.renderer:
+                raise NotImplementedError("gemm='exact' covers MMDiT.forward (the 50-step decode); the renderer keeps fp32 / f16x2")
+            return
+        from .encoder import encoder_pos_embedding
+        pos_emb = encoder_pos_embedding(self.K).to(self.device)
+        w = self.w
+        ex = lambda n, t: ops.ex_linear(t, w[n + ".weight"], w[n + ".bias"])
+        silu = lambda t: ops.ex_unary(t.contiguous(), "silu")
+        tabs = []
+        for i in range(DIT_DEPTH - 1):
+            p = f"model.joint_blocks.{i}.context_block"
+            h = ex(p + ".t_embedder.mlp.2", silu(ex(p + ".t_embedder.mlp.0", pos_emb)))
+            tabs.append(ex(p + ".adaLN_modulation.1", silu(h)).contiguous())
+        self._tables_exact = tabs
+        self.pe_w_exact = w["model.x_embedder.proj.weight"].permute(0, 2, 3, 1).reshape(DIT_HIDDEN, -1).contiguous()
+        self._pe_perm = torch.arange(64, device=self.device).reshape(16, 2, 2).permute(1, 2, 0).reshape(-1)
+
+    def _silu(self, t):
+        return ops.ex_unary(t.contiguous(), "silu") if self.gemm == "exact" else ops.silu(t)
+
     def lin(self, name, x, gelu: bool = False, out_split: bool = False):
         """x fp32 [..., K], or a split activation (ops.SplitAct) when `self._pre(name)`; out_split: return the split form for the
         next Linear (only with a split input)."""
         w, b = self.w[name + ".weight"], self.w[name + ".bias"]
+        if self.gemm == "exact":
+            assert not out_split and not isinstance(x, ops.SplitAct)
+            return ops.ex_linear(x, w, b, gelu=gelu)
         if isinstance(x, ops.SplitAct):
             assert name in self._packed, f"split activation handed to Linear {name!r}, which has no f16x2-split weight (set_gemm('f16x2') packs the block Linears)"
             return ops.linear_f16x2_split(x, self._packed[name], b, w.shape[0], gelu=gelu, overflow=self.overflow, out_split=out_split,
@@ -114,12 +147,23 @@ class MMDiTGPU(ModuleSurface):
 
     def _ln(self, consumer, x, **kw):
         """residual_ln_mod whose normalised output feeds Linear `consumer`: split form if that Linear takes it"""
+        if self.gemm == "exact":
+            return x, ops.ex_layernorm_mod(x, shift=kw.get("shift"), scale=kw.get("scale"), per_sample=bool(kw.get("per_sample", False)))
         return ops.residual_ln_mod(x, split=self._pre(consumer), overflow=self.overflow, **kw)
 
     def _res_ln(self, consumer, x, lin_name, lin_in, *, gate, gate_per_sample, split=None, **ln_kw):
         """x' = x + gate * Linear(lin_in);  n = LN(x') * (1 + scale) + shift  ->  (x', n).
         With a split input the residual update rides in the Linear's epilogue (one [B,T,H] fp32 round trip less) and the LN kernel
         only normalises; otherwise residual_ln_mod does both from the stored Linear output.  Same bits either way."""
+        if self.gemm == "exact":
+            # x' = x + gate * Linear(lin_in): the product and the sum rounded separately in the Linear's epilogue (`x + gate.unsqueeze(..) * post_attention(attn)`,
+            # sd3/mmdit.py:485-496); a per-token gate table is indexed by row % tokens, a per-sample one by row / tokens
+            wl, bl = self.w[lin_name + ".weight"], self.w[lin_name + ".bias"]
+            rows = x.shape[1]
+            # attn.proj reads a SLICE of the concatenated attention output in the reference (non-contiguous -> at::linear = matmul + add_(bias): bias last)
+            x = ops.ex_linear(lin_in, wl, bl, res=x, gate=gate, gate_mod=(-rows if gate_per_sample else rows), bias_last=lin_name.endswith(".attn.proj"))
+            n = ops.ex_layernorm_mod(x, shift=ln_kw.get("shift"), scale=ln_kw.get("scale"), per_sample=bool(ln_kw.get("per_sample", False)))
+            return x, n
         split = self._pre(consumer) if split is None else split
         if isinstance(lin_in, ops.SplitAct):
             assert lin_name in self._packed, f"split activation handed to Linear {lin_name!r}, which has no f16x2-split weight"
@@ -151,7 +195,7 @@ class MMDiTGPU(ModuleSurface):
     def time_embed(self, t_freq: torch.Tensor) -> torch.Tensor:
         """c = t_embedder.mlp(sinusoid)  (sd3/mmdit.py:177-183, 1022) ; t_freq [B,256]"""
         h = self.lin("model.t_embedder.mlp.0", t_freq)
-        return self.lin("model.t_embedder.mlp.2", ops.silu(h))
+        return self.lin("model.t_embedder.mlp.2", self._silu(h))
 
     # ---- the 24 joint blocks + final layer ---------------------------------------------------------
     @torch.no_grad()
@@ -167,7 +211,7 @@ class MMDiTGPU(ModuleSurface):
     def modulations(self, c: torch.Tensor, has_ctx: bool = True):
         """the 26 adaLN_modulation Linears of one model evaluation (sd3/mmdit.py:430-470, 641-645): functions of c = t_embedder(t) alone.
         -> ([24 x [B,6H]] image stream, [B,2H] last context block or None, [B,2H] final layer)"""
-        sc = ops.silu(c)                                     # every adaLN_modulation starts with SiLU(c)
+        sc = self._silu(c)                                   # every adaLN_modulation starts with SiLU(c)
         mods_x = [self.lin(f"model.joint_blocks.{i}.x_block.adaLN_modulation.1", sc) for i in range(DIT_DEPTH)]   # [B,6H]
         mods_c_last = self.lin(f"model.joint_blocks.{DIT_DEPTH - 1}.context_block.adaLN_modulation.1", sc) if has_ctx else None  # [B,2H]
         mods_f = self.lin("model.final_layer.adaLN_modulation.1", sc)                                              # [B,2H]
@@ -230,9 +274,25 @@ class MMDiTGPU(ModuleSurface):
             pc, px = f"model.joint_blocks.{i}.context_block", f"model.joint_blocks.{i}.x_block"
             last = i == DIT_DEPTH - 1
             xqkv = self.lin(px + ".attn.qkv", xn)                                  # [B,nx,3H]
-            ox = attn_out(nx, px + ".attn.proj")
+            if self.gemm == "exact":
+                # the joint attention as ATen's fp32 flash kernel evaluates `attention(q, k, v, heads, mask)` (sd3/other_impls.py:37-45) on the
+                # FULL key sequence [K context slots | image tokens] with the prefix mask: the n live context keys keep their positions (kv blocks
+                # of 512, MKL's K-blocks of 256 inside), the masked ones contribute exact zeros -- the same bits, not the truncated sequence's
+                assert kvis is None, "gemm='exact': one visibility prefix per call (the sampler's case)"
+                xk, xv = xqkv[..., H:2 * H], xqkv[..., 2 * H:]
+                if has_ctx:
+                    cqkv = cqkv0[:, :n].contiguous() if (i == 0 and cqkv0 is not None) else self.lin(pc + ".attn.qkv", cn)
+                    ck, cv = cqkv[..., H:2 * H], cqkv[..., 2 * H:]
+                    if not last:
+                        oc = ops.ex_attention(cqkv[..., :H], ck, cv, NH, xk if seg0_sees_seg1 else None, xv if seg0_sees_seg1 else None, slots1=self.K)
+                    ox = ops.ex_attention(xqkv[..., :H], ck, cv, NH, xk, xv, slots1=self.K)
+                else:
+                    ox = ops.ex_attention(xqkv[..., :H], None, None, NH, xk, xv, slots1=self.K)        # cfg_inference: every context key masked
+            ox = ox if self.gemm == "exact" else attn_out(nx, px + ".attn.proj")
             seg1 = (xqkv[..., :H], xqkv[..., H:2 * H], xqkv[..., 2 * H:], ox)
-            if has_ctx:
+            if self.gemm == "exact":
+                pass
+            elif has_ctx:
                 # [B,n,3H]; block 0's is step-invariant and may come precomputed (a strided [:, :n] view is fine)
                 cqkv = cqkv0[:, :n] if (i == 0 and cqkv0 is not None) else self.lin(pc + ".attn.qkv", cn)
                 if last:   # pre_only context block: keys/values only, its attention output is discarded (sd3/mmdit.py:544-547)
@@ -269,6 +329,8 @@ class MMDiTGPU(ModuleSurface):
             else:          # FinalLayer: LN + modulate(shift, scale = adaLN(c).chunk(2)) + Linear (sd3/mmdit.py:641-645); its Linear takes fp32
                 x, xn = self._res_ln(None, x, px + ".mlp.fc2", h, gate=mx[:, 5 * H:6 * H], gate_per_sample=True, split=False,
                                      shift=mods_f[:, 0:H], scale=mods_f[:, H:2 * H], per_sample=True)
+            if self._trace is not None:
+                self._trace.append(x.clone())
         return self.lin("model.final_layer.linear", xn)
 
     # ---- reference-shaped entry points ---------------------------------------------------------------
@@ -276,8 +338,19 @@ class MMDiTGPU(ModuleSurface):
     def embed_image(self, x: torch.Tensor) -> torch.Tensor:
         """x_embedder(x) + cropped_pos_embed (sd3/mmdit.py:1000)"""
         B, _, Hh, Ww = x.shape
+        if self.gemm == "exact":       # conv k2 s2 = ONE 64-tap chain in (kh, kw, ic) order + bias, then + pos (two roundings): oracle/encoder_exact.c
+            patch = ops.patchify(x)[..., self._pe_perm].contiguous()
+            return ops.ex_linear(patch, self.pe_w_exact, self.w["model.x_embedder.proj.bias"], res=self._pos_only(Hh // 2, Ww // 2), res_mod=patch.shape[1])
         xe = torch.matmul(ops.patchify(x), self.pe_w)
         return ops.add_rows_(xe, self._pos_bias(Hh // 2, Ww // 2))
+
+    def _pos_only(self, h: int, w: int) -> torch.Tensor:
+        key = ("pos", h, w)
+        if key not in self._pos_cache:
+            pe = self.w["model.pos_embed"]
+            top, left = (POS_MAX_DIT - h) // 2, (POS_MAX_DIT - w) // 2
+            self._pos_cache[key] = pe.reshape(POS_MAX_DIT, POS_MAX_DIT, -1)[top:top + h, left:left + w].reshape(h * w, -1).contiguous()
+        return self._pos_cache[key]
 
     @torch.no_grad()
     def velocity_tokens(self, x, t_freq, ctx0, n_live: int, context_see_xt: bool = True, cqkv0=None, tables=None, t_key=None):

@@ -754,9 +754,10 @@ def _rows2d(t: torch.Tensor):
 
 
 def ex_linear(x: torch.Tensor, weight: torch.Tensor, bias=None, *, gelu: bool = False, res=None, res_mod: int = 0, gate=None, gate_mod: int = 0,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, bias_last: bool = False) -> torch.Tensor:
     """F.linear in MKL sgemm's summation order (bit-equal to torch-CPU's nn.Linear for M >= 512 rows), optional exact GELU(tanh),
-    optional `res + gate * y` epilogue (res / gate rows taken modulo res_mod / gate_mod when non-zero: per-token tables)."""
+    optional `res + gate * y` epilogue (res / gate rows taken modulo res_mod / gate_mod when positive: per-token tables; divided by
+    -mod when negative: per-sample tables).  bias_last: (sum of the K-blocks) + bias, what at::linear computes for a non-contiguous input."""
     _need_cuda(x, weight, bias, res, gate)
     N, K = weight.shape
     assert weight.dtype == torch.float32 and weight.is_contiguous() and x.shape[-1] == K
@@ -768,12 +769,13 @@ def ex_linear(x: torch.Tensor, weight: torch.Tensor, bias=None, *, gelu: bool = 
     ldr = _rows2d(res)[1] if res is not None else 0
     ldg = _rows2d(gate)[1] if gate is not None else 0
     _lib.check(_lib.load().selftok_ex_linear_f32(_p(x), ldx, _p(weight), _p(bias), _p(res), ldr, int(res_mod), _p(gate), ldg, int(gate_mod), _p(out), ldo,
-                                                 M, N, K, int(gelu), _stream()), "selftok_ex_linear_f32")
+                                                 M, N, K, int(bool(gelu)) | (2 if bias_last else 0), _stream()), "selftok_ex_linear_f32")
     return out
 
 
-def ex_layernorm_mod(x: torch.Tensor, shift=None, scale=None, gamma=None, beta=None, eps: float = 1e-6, want_stats: bool = False):
-    """nn.LayerNorm in ATen's arithmetic, then `* (1 + scale[tok]) + shift[tok]` (tok = row % T; shift / scale [T, N] views, equal row stride)"""
+def ex_layernorm_mod(x: torch.Tensor, shift=None, scale=None, gamma=None, beta=None, eps: float = 1e-6, want_stats: bool = False, per_sample: bool = False):
+    """nn.LayerNorm in ATen's arithmetic, then `* (1 + scale[tok]) + shift[tok]` (tok = row % T; shift / scale [T, N] views, equal row stride;
+    per_sample: x [B, rows, N] with tables [B, N], tok = the sample)"""
     _need_cuda(x, shift, scale, gamma, beta)
     N = x.shape[-1]
     rows, ldx = _rows2d(x)
@@ -782,6 +784,9 @@ def ex_layernorm_mod(x: torch.Tensor, shift=None, scale=None, gamma=None, beta=N
     if shift is not None:
         assert scale is not None and shift.dim() == 2 and shift.shape == scale.shape and shift.stride(0) == scale.stride(0) and shift.stride(1) == 1 == scale.stride(1)
         T, ldt = shift.shape[0], shift.stride(0)
+        if per_sample:
+            assert x.dim() == 3 and shift.shape[0] == x.shape[0]
+            T = -x.shape[1]
     stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if want_stats else None
     _lib.check(_lib.load().selftok_ex_layernorm_mod_f32(_p(x), ldx, _p(out), N, _p(shift), _p(scale), ldt, T, _p(gamma), _p(beta), _p(stats), rows, N, float(eps),
                                                         _stream()), "selftok_ex_layernorm_mod_f32")
@@ -799,16 +804,23 @@ def ex_unary(x: torch.Tensor, kind: str) -> torch.Tensor:
     return y
 
 
-def ex_attention(q: torch.Tensor, k1: torch.Tensor, v1: torch.Tensor, heads: int, k2=None, v2=None) -> torch.Tensor:
-    """F.scaled_dot_product_attention (no mask) as ATen's fp32 CPU flash kernel evaluates it.  q [B,Tq,H*D], k1 / v1 [B,Tk1,H*D] and an
-    optional second key / value segment that follows the first; all may be column slices of fused projections.  -> [B,Tq,H*D]"""
+def ex_attention(q: torch.Tensor, k1, v1, heads: int, k2=None, v2=None, slots1: Optional[int] = None) -> torch.Tensor:
+    """F.scaled_dot_product_attention as ATen's fp32 CPU flash kernel evaluates it.  q [B,Tq,H*D], k1 / v1 [B,Tk1,H*D] and an
+    optional second key / value segment that follows the first; all may be column slices of fused projections.  -> [B,Tq,H*D].
+    `slots1`: the first segment occupies slots1 >= Tk1 key positions of which only the Tk1 given ones are visible (a prefix mask: the
+    masked keys keep their place in the kv blocks, see include/selftok_hip.h); k1 = v1 = None with slots1: none of them is visible."""
     _need_cuda(q, k1, v1, k2, v2)
     B, Tq, HD = q.shape
     D = HD // heads
     _, qs = _rows2d(q)
-    _, ks1 = _rows2d(k1)
-    assert _rows2d(v1)[1] == ks1 and k1.shape == v1.shape
-    Tk1 = k1.shape[1]
+    rows1, ks1 = 0, 0
+    if k1 is not None:
+        _, ks1 = _rows2d(k1)
+        assert _rows2d(v1)[1] == ks1 and k1.shape == v1.shape
+        rows1 = k1.shape[1]
+    else:
+        assert slots1 is not None and k2 is not None
+    Tk1 = rows1 if slots1 is None else int(slots1)
     Tk2, ks2 = 0, 0
     if k2 is not None:
         Tk2, ks2 = k2.shape[1], _rows2d(k2)[1]
@@ -818,6 +830,6 @@ def ex_attention(q: torch.Tensor, k1: torch.Tensor, v1: torch.Tensor, heads: int
     if B == 0:
         return out
     ws = torch.empty(lib.selftok_ex_attention_workspace_bytes(B, heads, Tq, Tk1 + Tk2, D), dtype=torch.uint8, device=q.device)
-    _lib.check(lib.selftok_ex_attention_f32(_p(q), qs, _p(k1), _p(v1), ks1, Tk1, _p(k2), _p(v2), ks2, Tk2, _p(out), _p(ws), B, heads, Tq, D, _stream()),
+    _lib.check(lib.selftok_ex_attention_f32(_p(q), qs, _p(k1), _p(v1), ks1, Tk1, rows1, rows1, _p(k2), _p(v2), ks2, Tk2, _p(out), _p(ws), B, heads, Tq, D, _stream()),
                "selftok_ex_attention_f32")
     return out

@@ -77,6 +77,13 @@ class _Flow(FlowSchedule):
         # cfg_inference embeds floor(t*1000).int().clamp(0,999) instead (sd3/mmdit.py:1126)
         t_unc = torch.floor(torch.from_numpy(self.scheduled_t) * 1000).int().clamp(0, 999)
         self.t_freq_uncond = sinusoid_host(t_unc).to(device)
+        # gemm='exact': the reference's own bits of these two tables (torch.cos / sin = MKL VML there: host dependent, shipped as data for the
+        # default schedule -- 50 steps from t = 1; tools/oracle/gen_pos_table.py).  Another schedule falls back to this host's evaluation.
+        self.t_freq_exact = self.t_freq_uncond_exact = None
+        if num_steps == 50 and float(start) == 1.0:
+            import os
+            tab = torch.from_numpy(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "flow50_t_sincos.npy")))
+            self.t_freq_exact, self.t_freq_uncond_exact = tab[0].to(device).contiguous(), tab[1].to(device).contiguous()
 
     def resolve_super_mask(self, super_mask, K: int):
         """[K] (or batch-uniform [B,K]) visibility pattern -> (device int64 index of the visible tokens, their positions as numpy)"""
@@ -118,7 +125,8 @@ class _Flow(FlowSchedule):
                 n_live = min(n_live, int(prefix_k))
             if vis_pos is not None:                                           # visible tokens at positions < n_live: a prefix of the gathered list
                 n_live = int(np.searchsorted(vis_pos, n_live, side="left"))
-            tf = self.t_freq[i:i + 1].expand(B, -1).contiguous()
+            exact = dit.gemm == "exact" and self.t_freq_exact is not None
+            tf = (self.t_freq_exact if exact else self.t_freq)[i:i + 1].expand(B, -1).contiguous()
             t_name = float(self.scheduled_t[i])                               # names the embedded timestep (MMDiTGPU._step_modulations)
             if uncond_scale == 1.0:
                 y = dit.velocity_tokens(x, tf, ctx0, n_live, context_see_xt, cqkv0, tables, t_key=("t", t_name))
@@ -127,7 +135,7 @@ class _Flow(FlowSchedule):
                 # CFG branch (rectified_flow.py:280-289): the conditional call omits context_see_xt (-> False) and
                 # the unconditional one sees no context token at all
                 y = dit.velocity_tokens(x, tf, ctx0, n_live, False, cqkv0, tables, t_key=("t", t_name))
-                tfu = self.t_freq_uncond[i:i + 1].expand(B, -1).contiguous()
+                tfu = (self.t_freq_uncond_exact if exact else self.t_freq_uncond)[i:i + 1].expand(B, -1).contiguous()
                 yu = dit.velocity_tokens(x, tfu, ctx0, 0, False, t_key=("floor", t_name))   # cfg_inference: no context key visible at all
             if self.parameterization == "x0":
                 # the model output is the clean latent: x_prev = v + a_prev (x - v) / a_t  (euler_step, rectified_flow.py:305-307);

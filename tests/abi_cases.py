@@ -617,8 +617,22 @@ def _(alloc):
     lib_ws = 4 * (B * H * Tq * (Tk1 + Tk2) + B * H * D * (Tk1 + Tk2) + 2 * B * H * Tq)
     out = alloc(np.zeros((B, Tq, HD), np.float32)); ws = alloc(np.zeros(lib_ws, np.uint8))
     qd, kd = alloc(qq), alloc(kvx)
-    return "selftok_ex_attention_f32", [qd.ptr, 3 * HD, kd.ptr, kd.ptr + 4 * HD, 2 * HD, Tk1, qd.ptr + 4 * HD, qd.ptr + 8 * HD, 3 * HD, Tk2, out.ptr, ws.ptr,
+    return "selftok_ex_attention_f32", [qd.ptr, 3 * HD, kd.ptr, kd.ptr + 4 * HD, 2 * HD, Tk1, Tk1, Tk1, qd.ptr + 4 * HD, qd.ptr + 8 * HD, 3 * HD, Tk2, out.ptr, ws.ptr,
                                         B, H, Tq, D, None], dict(out=out)
+
+
+@case("ex_attention_prefix_mask")
+def _(alloc):
+    """the MMDiT's joint attention: 512 context key slots of which 300 are visible (held as 300 rows), then 64 image keys"""
+    r = rng(75)
+    B, H, Tq, slots, valid, Tk2, D = 1, 2, 64, 512, 300, 64, 64
+    HD = H * D
+    cq = f32(r.standard_normal((B, valid, 3 * HD)) * 1.4); xq = f32(r.standard_normal((B, Tk2, 3 * HD)) * 1.4)
+    lib_ws = 4 * (B * H * Tq * (slots + Tk2) + B * H * D * (slots + Tk2) + 2 * B * H * Tq)
+    out = alloc(np.zeros((B, Tq, HD), np.float32)); ws = alloc(np.zeros(lib_ws, np.uint8))
+    cd, xd = alloc(cq), alloc(xq)
+    return "selftok_ex_attention_f32", [xd.ptr, 3 * HD, cd.ptr + 4 * HD, cd.ptr + 8 * HD, 3 * HD, slots, valid, valid, xd.ptr + 4 * HD, xd.ptr + 8 * HD, 3 * HD, Tk2,
+                                        out.ptr, ws.ptr, B, H, Tq, D, None], dict(out=out)
 
 
 def run(lib, name, side):

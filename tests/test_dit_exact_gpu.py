@@ -1,0 +1,138 @@
+"""-m gpu: the exact-order MMDiT mode (`gemm="exact"`, round 5): every Linear / LayerNorm / GELU / SiLU / attention of `MMDiT.forward`
+(sd3/mmdit.py:992-1101) as the sequence of fp32 operations torch-CPU executes for the reference.  Kernels against the C twin
+(oracle/encoder_exact.c: the masked joint attention, per-sample tables), one forward against the reference's own (tests/golden/dit_forward_b16.npz:
+crc32 of the image stream after every joint block and of the velocity), and the 16-image pipeline run end to end: final latents, pixels and PSNR
+EQUAL to the reference's, bit for bit."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder_exact as EX
+from selftoktokenizer_amd import ops, synth, weights as W
+from selftoktokenizer_amd.config import default_config
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _same(gpu, ref, what):
+    g = gpu.detach().cpu().numpy()
+    bad = (g.view(np.uint32) != ref.view(np.uint32)) & ~((g == 0) & (ref == 0))
+    assert int(bad.sum()) == 0, f"{what}: {int(bad.sum())} of {g.size} fp32 elements differ from the oracle"
+
+
+def _rand(seed, shape, scale=1.0):
+    return (synth.hash_normalish(seed, shape) * scale).float().contiguous()
+
+
+@pytest.mark.parametrize("valid,see_x", [(512, True), (301, True), (20, True), (256, True), (257, False), (0, True)])
+def test_joint_attention_with_prefix_mask(valid, see_x):
+    """context rows and image rows of the joint attention: K = 512 context slots of which `valid` are visible (held as `valid` rows), 256 image keys;
+    24 heads x 64 as in the MMDiT (2 heads here)"""
+    B, H, D, K, nx = 2, 2, 64, 512, 256
+    HD = H * D
+    cq = _rand(0x30 + valid, (B, max(valid, 1), 3 * HD), 1.3)[:, :valid].contiguous() if valid else None
+    xq = _rand(0x31, (B, nx, 3 * HD), 1.3)
+    xk, xv = xq[..., HD:2 * HD], xq[..., 2 * HD:]
+    xc = xq.cuda()
+    if valid:
+        cc = cq.cuda()
+        ref_x = EX.attention(xq[..., :HD].numpy(), cq[..., HD:2 * HD].numpy(), cq[..., 2 * HD:].numpy(), H, xk.numpy(), xv.numpy(), valid1=valid, slots1=K)
+        out_x = ops.ex_attention(xc[..., :HD], cc[..., HD:2 * HD], cc[..., 2 * HD:], H, xc[..., HD:2 * HD], xc[..., 2 * HD:], slots1=K)
+        _same(out_x, ref_x, f"image rows, {valid} of {K} context keys visible")
+        k2 = (xk.numpy(), xv.numpy()) if see_x else (None, None)
+        ref_c = EX.attention(cq[..., :HD].numpy(), cq[..., HD:2 * HD].numpy(), cq[..., 2 * HD:].numpy(), H, k2[0], k2[1], valid1=valid, slots1=K)
+        out_c = ops.ex_attention(cc[..., :HD], cc[..., HD:2 * HD], cc[..., 2 * HD:], H, xc[..., HD:2 * HD] if see_x else None, xc[..., 2 * HD:] if see_x else None, slots1=K)
+        _same(out_c, ref_c, f"context rows, {valid} of {K} visible, see_x={see_x}")
+    else:       # cfg_inference: no context key visible at all -- the first kv block is fully masked
+        dummy = np.zeros((B, 16, HD), np.float32)
+        ref_x = EX.attention(xq[..., :HD].numpy(), dummy, dummy, H, xk.numpy(), xv.numpy(), valid1=0, slots1=K)
+        out_x = ops.ex_attention(xc[..., :HD], None, None, H, xc[..., HD:2 * HD], xc[..., 2 * HD:], slots1=K)
+        _same(out_x, ref_x, "image rows, no context key visible")
+
+
+def test_per_sample_tables():
+    """the image stream's modulation ('t_emb': one [6H] row per sample): LayerNorm + modulate and the gated residual epilogue index their tables by sample"""
+    B, T, N = 3, 256, 1536
+    x = _rand(0x40, (B, T, N), 2.0)
+    tab = _rand(0x41, (B, 6 * N), 0.5)
+    ref = EX.layernorm(x.numpy()) * (np.float32(1) + tab[:, None, N:2 * N].numpy()) + tab[:, None, 0:N].numpy()
+    tc = tab.cuda()
+    out = ops.ex_layernorm_mod(x.cuda(), shift=tc[:, 0:N], scale=tc[:, N:2 * N], per_sample=True)
+    _same(out, ref, "LayerNorm + per-sample modulate")
+    w, b = _rand(0x42, (512, N), N ** -0.5), _rand(0x43, (512,), 0.1)
+    y = EX.linear(ref, w.numpy(), b.numpy())
+    res = _rand(0x44, (B, T, 512))
+    g = _rand(0x45, (B, 6 * 512), 0.7)
+    ref2 = res.numpy() + g[:, None, 2 * 512:3 * 512].numpy() * y
+    out2 = ops.ex_linear(out, w.cuda(), b.cuda(), res=res.cuda(), gate=g.cuda()[:, 2 * 512:3 * 512], gate_mod=-T)
+    _same(out2, ref2, "x + gate[sample] * Linear")
+
+
+@pytest.fixture(scope="module")
+def models():
+    from selftoktokenizer_amd.encoder import QformerEncoderGPU
+    from selftoktokenizer_amd.mmdit import MMDiTGPU
+    sd = W.synthetic_state_dict(W.expected_shapes(512), device="cuda")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    enc = QformerEncoderGPU(sd, dev, 512, mode="exact")
+    dit = MMDiTGPU(sd, dev, 512, gemm="exact")
+    return sd, enc, dit
+
+
+def test_forward_16_images_equals_the_reference_block_by_block(models):
+    """MMDiT.forward at B = 16, three scheduled timesteps (k = 511, 302 ..): the image stream after EVERY joint block and the velocity have the
+    reference's crc32 (tests/golden/dit_forward_b16.npz)"""
+    from selftoktokenizer_amd.pipeline import _Flow
+    sd, enc, dit = models
+    g = np.load(os.path.join(GOLD, "dit_forward_b16.npz"))
+    B = 16
+    ehs = enc.codes_ln(torch.from_numpy(synth.synthetic_token_ids(B)).cuda())
+    x = synth.synthetic_noise(B, device="cuda")
+    flow = _Flow(50, 1.0, dit.device)
+    ctx0 = dit.embed_context(ehs)
+    for j, i in enumerate(g["steps"]):
+        k = int(g[f"k_{j}"])
+        tf = flow.t_freq_exact[i:i + 1].expand(B, -1).contiguous()
+        trace = []
+        dit._trace = trace
+        try:
+            y = dit.velocity_tokens(x, tf, ctx0, k + 1, True)
+        finally:
+            dit._trace = None
+        _, v = ops.unpatchify_cfg_euler(y, None, 0.0, C=16, hp=16, wp=16)
+        crcs = np.array([zlib.crc32(t.contiguous().cpu().numpy().tobytes()) for t in trace], dtype=np.uint32)
+        first = np.nonzero(crcs != g[f"xcrc_{j}"])[0]
+        if first.size:
+            b = int(first[0])
+            print(f"step {i} (k = {k}): first differing block {b}; head ours {trace[b][0, 0, :8].cpu().numpy()} reference {g[f'xhead_{j}'][b]}")
+        sub = v[:, :, ::4, ::4].contiguous().cpu().numpy()
+        print(f"step {i} (k = {k}): velocity sub-sample max abs diff vs the reference {np.abs(sub - g[f'vsub_{j}']).max():.3e}")
+        assert first.size == 0, f"step {i}: the image stream differs from the reference's from block {int(first[0])} on"
+        assert zlib.crc32(v.contiguous().cpu().numpy().tobytes()) == int(g[f"vcrc_{j}"])
+
+
+def test_pipeline_16_images_pixels_equal_the_reference_bit_for_bit():
+    """the reference pipeline's own 16-image run (pipeline_b16.npz, decode_b16.npz): with gemm='exact' (+ the exact VAE and encoder) the final latents
+    of the 50-step loop, the decoded pixels and hence the PSNR of every image EQUAL the reference's"""
+    from mimogpt.infer.SelftokPipeline import SelftokPipeline
+    from selftoktokenizer_amd import evaluate as E
+    g, gd = np.load(os.path.join(GOLD, "pipeline_b16.npz")), np.load(os.path.join(GOLD, "decode_b16.npz"))
+    sd = W.synthetic_state_dict(W.expected_shapes(512), device="cuda")
+    pipe = SelftokPipeline(default_config(512), None, None, device="cuda", state_dict=sd, vae_state_dict=W.synthetic_vae_state_dict(device="cuda"), verbose=False, gemm="exact")
+    imgs = synth.synthetic_images(16, device="cuda")
+    ids = pipe.encoding(imgs)
+    assert np.array_equal(ids.cpu().numpy(), g["tokens"].astype(np.int64))
+    rec, lat = pipe.decoding(ids.cpu().numpy(), noise=synth.synthetic_noise(16), return_latent=True)
+    d = (lat.cpu() - torch.from_numpy(g["lat"])).abs().max()
+    print(f"\nfinal latents after 50 exact-order steps vs the reference: max abs diff {float(d):.3e}; differing elements {int((lat.cpu() != torch.from_numpy(g['lat'])).sum())}")
+    assert torch.equal(lat.cpu(), torch.from_numpy(g["lat"])), "final latents differ from the reference's"
+    bits = rec.cpu().view(torch.int16).numpy().view(np.uint16)
+    crc = np.array([zlib.crc32(np.ascontiguousarray(bits[i]).tobytes()) for i in range(16)], dtype=np.uint32)
+    assert np.array_equal(crc, gd["crc"]), "pixels differ from the reference's"
+    psnr = E.psnr_each(rec, imgs)
+    assert np.array_equal(psnr, g["psnr_ref"]), np.abs(psnr - g["psnr_ref"]).max()
+    print("pixels of all 16 images equal the reference's; PSNR identical:", psnr[:4])

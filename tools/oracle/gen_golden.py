@@ -521,6 +521,42 @@ def stage_config():
     report("config", absent=absent)
 
 
+def stage_dit4():
+    """the reference MMDiT.forward at B = 16 (>= 16 rows in the conditioning Linears and >= 1024 in the token Linears: the regime where MKL's K-blocking
+    is row-count independent -- below 16 rows sgemm takes another path, probed -- the one the B = 16 / 64 pipeline runs live in) at three scheduled
+    timesteps, for the exact-order MMDiT mode: crc32 + a sub-sampled copy of the velocity, and a crc32 / head of the image stream after every joint
+    block (forward hooks), so that a first differing bit can be located"""
+    import zlib
+    cfg, model, sd = tokenizer(CFG_256)
+    B = 16
+    ids = torch.from_numpy(synth.synthetic_token_ids(B))
+    with torch.no_grad():
+        codes = model.encoder.quantizer.get_output_from_indices(ids)
+        ehs = model.encoder.final_layer_norm3(codes.reshape(B, -1, 16))
+    x = synth.synthetic_noise(B)
+    from selftoktokenizer_amd.schedule import FlowSchedule, DiTiCont
+    p = cfg.tokenizer.params
+    fs = FlowSchedule(50, 1.0)
+    ktab = DiTiCont(1000, 512, p.stages, p.k_per_stage).to_indices(fs.t_long)
+    out = {"steps": np.array([0, 25, 49])}
+    for j, i in enumerate((0, 25, 49)):
+        t = torch.full((B,), float(fs.scheduled_t[i]))
+        k = int(ktab[i])
+        mask = (torch.arange(512)[None] <= k).expand(B, -1)
+        crcs, heads = [], []
+        def hook(m, a, o):                                  # (a hook that returns a value replaces the output: return None)
+            crcs.append(zlib.crc32(o[1].contiguous().numpy().tobytes()))
+            heads.append(o[1][0, 0, :8].numpy().copy())
+        hooks = [blk.register_forward_hook(hook) for blk in model.model.joint_blocks]
+        with torch.no_grad():
+            v, _ = model.model(x, t, encoder_hidden_states=ehs, mask=mask, context_see_xt=True)
+        for h in hooks:
+            h.remove()
+        out[f"vcrc_{j}"] = np.uint32(zlib.crc32(v.contiguous().numpy().tobytes())); out[f"vsub_{j}"] = v[:, :, ::4, ::4].contiguous().numpy(); out[f"k_{j}"] = np.int64(k); out[f"xcrc_{j}"] = np.array(crcs, dtype=np.uint32); out[f"xhead_{j}"] = np.stack(heads)
+        report(f"dit4_{j}", step=i, k=k, v_absmax=float(v.abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "dit_forward_b16.npz"), **out)
+
+
 def stage_renderer():
     cfg, model, sd = tokenizer(CFG_RND)
     ids = torch.from_numpy(synth.synthetic_token_ids(1, first_index=7))
@@ -800,7 +836,7 @@ def stage_rmsnorm_rotary():
     report("rmsnorm_rotary", arrays=sorted(out), rms_absmax=float(np.abs(out["rms_affine"]).max()), rot_absmax=float(np.abs(out["rot_full"]).max()))
 
 
-STAGES = dict(config=stage_config, decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
+STAGES = dict(dit4=stage_dit4, config=stage_config, decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
               vae=stage_vae, pipeline=stage_pipeline, pipeline16=stage_pipeline16, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024, vqtrain=stage_vqtrain)
 
 if __name__ == "__main__":

@@ -30,3 +30,16 @@ assert np.array_equal(table.view(np.uint32), own.view(np.uint32)), "the referenc
 out = os.path.join(ROOT, "selftoktokenizer_amd", "data", "encoder_pos_sincos.npy")
 np.save(out, table)
 print("wrote", out, table.shape, "cpu capability", torch.backends.cpu.get_cpu_capability())
+
+
+# ---- the MMDiT's timestep embeddings of the DEFAULT sampler schedule (50 steps, start = 1.0): `t_embedder.timestep_embedding(t * 1000)` (sd3/mmdit.py:156-175,
+# 999, 1022) and cfg_inference's `floor(t * 1000).int().clamp(0, 999)` (:1126) -- the same MKL-VML arithmetic, [2, 50, 256]: used by the exact-order MMDiT mode
+from mimogpt.models.selftok.sd3.mmdit import TimestepEmbedder as DitTE  # noqa: E402
+from selftoktokenizer_amd.schedule import FlowSchedule  # noqa: E402
+fs = FlowSchedule(50, 1.0)
+t = torch.from_numpy(fs.scheduled_t)
+cond = DitTE.timestep_embedding(t * 1000.0, 256).float().numpy()
+unc = DitTE.timestep_embedding(torch.floor(t * 1000).int().clamp(0, 999), 256).float().numpy()
+out2 = os.path.join(ROOT, "selftoktokenizer_amd", "data", "flow50_t_sincos.npy")
+np.save(out2, np.stack([cond, unc]))
+print("wrote", out2, np.stack([cond, unc]).shape)
