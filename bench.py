@@ -58,7 +58,9 @@ def parse(argv=None):
     ap.add_argument("--tokens", type=int, default=512, choices=[512, 1024])
     ap.add_argument("--decoder", default="diffusion", choices=["diffusion", "renderer"])
     ap.add_argument("--decode-steps", type=int, default=None, help="debug only: truncate the 50-step loop (marks the line invalid)")
-    ap.add_argument("--gemm", default=None, choices=["fp32", "f16x2"], help="arithmetic of the MMDiT block Linears of the headline number")
+    ap.add_argument("--gemm", default=None, choices=["fp32", "f16x2", "exact"], help="arithmetic of the MMDiT of the headline number (exact: every operation in the "
+                    "reference's torch-CPU order -- pixels bit-equal to the reference's, the parity mode)")
+    ap.add_argument("--no-exact", action="store_true", help="skip the timed step and the 16-image pixel-equality check in the exact-order MMDiT mode")
     ap.add_argument("--vae", default=None, choices=["exact", "parity", "miopen", "fast"], help="VAE arithmetic (vae.AutoencoderKLGPU); default: the pipeline's (exact-order encoder at 256 x 256)")
     ap.add_argument("--tune-gemm", type=int, default=1, choices=[0, 1], help="fp32 Linears: hipBLASLt kernel chosen per shape family by measurement (gemm_tune.py, opt-in in the "
                     "pipeline; the bench asks for it explicitly, before the warm-up, and reports the kernels in config.fp32_linear_kernels); 0: hipBLASLt's own choice")
@@ -299,7 +301,7 @@ def vq_roofline(n_vq, C, Dm, main_ms, fin_ms, launches, traffic, traffic_note, f
 GOLD16 = os.path.join(ROOT, "tests", "golden", "pipeline_b16.npz")
 
 
-def parity_16(pipe):
+def parity_16(pipe, exact_leg=True):
     """16 images against the REFERENCE's own SelftokPipeline run on the same synthetic weights (tests/golden/pipeline_b16.npz, made by
     tools/oracle/gen_golden.py pipeline16): token ids from pixels (through the bf16 VAE), the reference's top-1/top-2 gap of every
     flipped token, and reconstruction PSNR -- end to end, and with the reference's final latents and ours through the SAME decoder
@@ -311,6 +313,7 @@ def parity_16(pipe):
     ref = g["tokens"].astype(np.int64)
     B = ref.shape[0]
     dev = pipe.device
+    dit_mode = pipe.model.model.gemm
     imgs = synth.synthetic_images(B, device=dev)
     x0 = pipe.encode_latents(imgs)
     z = pipe.model.encoder.features(x0)
@@ -356,6 +359,21 @@ def parity_16(pipe):
                                "final latents and ours through ONE call of our decoder (north star: 1e-3 dB); second cpu implementation = the CPU bf16 VAE with "
                                "diffusers' Linear attention projections on the reference's latents vs the reference's pixels: the spread between two CPU "
                                "implementations of the same bf16 network"}
+        if exact_leg and dit_mode != "exact":
+            import zlib
+            gd = os.path.join(os.path.dirname(GOLD16), "decode_b16.npz")
+            pipe.set_gemm("exact")
+            try:
+                rec_x, lat_x = pipe.decoding(ref, noise=synth.synthetic_noise(B), return_latent=True)
+            finally:
+                pipe.set_gemm(dit_mode)
+            bits = rec_x.cpu().view(torch.int16).numpy().view(np.uint16)
+            crc = np.array([zlib.crc32(np.ascontiguousarray(bits[i]).tobytes()) for i in range(B)], dtype=np.uint32)
+            out["exact_mode"] = {"gemm": "exact", "final_latent_elements_differing_from_the_reference": int((lat_x != lat_ref).sum()),
+                                 "images_with_pixels_bit_equal_to_the_reference": (int((crc == np.load(gd)["crc"]).sum()) if os.path.exists(gd) else None), "images": B,
+                                 "psnr_delta_max_dB": float(np.abs(psnr_each(rec_x) - g["psnr_ref"]).max()),
+                                 "note": "the same 16 ids and noise through the exact-order MMDiT + exact VAE decoder: crc32 of every image's bf16 pixels against the reference "
+                                         "pipeline run's (tests/golden/decode_b16.npz)"}
     return out
 
 
@@ -656,6 +674,12 @@ def main(argv=None):
             other = {"gemm": alt, "value": round(world * B * n_alt / el_alt, 4), "unit": "images/s", "steps": n_alt, "warmup": 1,
                      "ms_per_step": round(1000.0 * el_alt / n_alt, 2)}
         pipe.set_gemm(gemm_main)
+    exact = None
+    if not args.no_exact and not renderer and gemm_main != "exact" and not (world > 1 and not args.all_legs):
+        if pipe.set_gemm("exact") == "exact":
+            el_ex, _ = timed(1, 0)
+            exact = {"gemm": "exact", "value": round(world * B / el_ex, 4), "unit": "images/s", "steps": 1, "warmup": 0, "ms_per_step": round(1000.0 * el_ex, 2)}
+        pipe.set_gemm(gemm_main)
 
     if rank != 0:
         D.shutdown()
@@ -703,6 +727,11 @@ def main(argv=None):
     if other is not None:
         line["gemm_modes"] = {gemm_main: {"value": line["value"], "ms_per_step": line["ms_per_step"]}, other["gemm"]: other,
                               "note": "same step, MMDiT block Linears on the other arithmetic; 'value' of this line is the '%s' run" % gemm_main}
+    if exact is not None:
+        line.setdefault("gemm_modes", {gemm_main: {"value": line["value"], "ms_per_step": line["ms_per_step"]}})["exact"] = dict(
+            exact, note="the parity mode: every Linear / LayerNorm / GELU / SiLU / attention of the MMDiT in the summation order torch-CPU executes for the reference "
+                        "(csrc/encoder_exact.hip; MKL's K-blocking on chained fp32 MFMAs, the joint attention on the full masked key sequence) -- final latents and pixels "
+                        "bit-equal to the reference pipeline's (parity_16.exact_mode)")
     if args.decode_steps is not None and not renderer:
         line["config"]["INVALID"] = "decode loop truncated with --decode-steps (debug run)"
     if not args.no_kernel_roofs and not renderer:
@@ -710,7 +739,7 @@ def main(argv=None):
     if not args.no_token_check:
         line["token_match"] = token_match(pipe, images, last["tokens"], sd, vsd, K, first_index=rank * B)
         if K == 512 and os.path.exists(GOLD16) and not args.no_parity16:
-            line["parity_16"] = parity_16(pipe)
+            line["parity_16"] = parity_16(pipe, exact_leg=not args.no_exact)
     if not args.no_latency and not renderer:
         line["latency_b1"] = latency_b1(pipe)
     if world == 1 and not args.no_cpu_baseline:

@@ -992,8 +992,8 @@ int selftok_ex_linear_f32(const float* x, long ldx, const float* w, const float*
             float v = yc[(size_t)m * N + n];
             if ((gelu & 2) && bias) v = v + bias[n];
             if (gelu & 1) v = xe_gelu_tanh1(v);
-            if (gate) v = gate[(size_t)(gate_mod ? m % gate_mod : m) * ldg + n] * v;
-            if (res) v = res[(size_t)(res_mod ? m % res_mod : m) * ldr + n] + v;
+            if (gate) v = gate[(size_t)(gate_mod > 0 ? m % gate_mod : (gate_mod < 0 ? m / -gate_mod : m)) * ldg + n] * v;
+            if (res) v = res[(size_t)(res_mod > 0 ? m % res_mod : (res_mod < 0 ? m / -res_mod : m)) * ldr + n] + v;
             out[(size_t)m * ldo + n] = v;
         }
     free(xc); free(yc);
@@ -1005,12 +1005,13 @@ int selftok_ex_layernorm_mod_f32(const float* x, long ldx, float* out, long ldo,
 {
     (void)s;
     if (rows == 0) return SELFTOK_OK;
-    if (!x || !out || rows < 0 || N <= 0 || N % 8 || N > 4096 || ldx % 4 || ldo % 4 || ((shift == NULL) != (scale == NULL)) || (scale && T <= 0))
+    if (!x || !out || rows < 0 || N <= 0 || N % 8 || N > 4096 || ldx % 4 || ldo % 4 || ((shift == NULL) != (scale == NULL)) || (scale && T == 0))
         return fail("ex_layernorm: bad argument");
     for (long r = 0; r < rows; ++r) {
         xe_layernorm(x + (size_t)r * ldx, out + (size_t)r * ldo, gamma, beta, 1, N, eps, stats ? stats + 2 * r : NULL);
         if (scale) {
-            const float *sc = scale + (size_t)(r % T) * ldt, *sh = shift + (size_t)(r % T) * ldt;
+            const long tok = T > 0 ? r % T : r / -T;                  /* T < 0: per-sample tables, -T rows per sample */
+            const float *sc = scale + (size_t)tok * ldt, *sh = shift + (size_t)tok * ldt;
             float* o = out + (size_t)r * ldo;
             for (int j = 0; j < N; ++j) o[j] = o[j] * (1.0f + sc[j]) + sh[j];
         }

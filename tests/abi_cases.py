@@ -585,6 +585,27 @@ def _(alloc):
     return "selftok_ex_linear_f32", [alloc(x).ptr, K, alloc(w).ptr, alloc(b).ptr, None, 0, 0, None, 0, 0, out.ptr, N, M, N, K, 0, None], dict(out=out)
 
 
+@case("ex_linear_bias_last_per_sample_gate")
+def _(alloc):
+    """the MMDiT's attention projection: bias added after the K-blocks (at::linear on a non-contiguous input), gate table indexed by sample"""
+    r = rng(76)
+    B, T, K, N = 3, 64, 1536, 64
+    x = f32(r.standard_normal((B * T, K))); w = f32(r.standard_normal((N, K)) / np.sqrt(K)); b = f32(r.standard_normal(N))
+    res = f32(r.standard_normal((B * T, N))); gate = f32(r.standard_normal((B, 6 * N)))
+    out = alloc(np.zeros((B * T, N), np.float32))
+    return "selftok_ex_linear_f32", [alloc(x).ptr, K, alloc(w).ptr, alloc(b).ptr, alloc(res).ptr, N, 0, alloc(gate).ptr + 4 * 2 * N, 6 * N, -T, out.ptr, N,
+                                     B * T, N, K, 2, None], dict(out=out)
+
+
+@case("ex_layernorm_mod_per_sample")
+def _(alloc):
+    r = rng(77)
+    B, T, N = 3, 32, 1536
+    x = f32(r.standard_normal((B * T, N)) * 2 + 0.3); table = f32(r.standard_normal((B, 6 * N)) * 0.5)
+    out = alloc(np.zeros((B * T, N), np.float32)); td = alloc(table)
+    return "selftok_ex_layernorm_mod_f32", [alloc(x).ptr, N, out.ptr, N, td.ptr, td.ptr + 4 * N, 6 * N, -T, None, None, None, B * T, N, 1e-6, None], dict(out=out)
+
+
 @case("ex_layernorm_mod")
 def _(alloc):
     r = rng(73)
