@@ -694,6 +694,8 @@ def main(argv=None):
     traffic, traffic_note = measured_vq_traffic(n_vq, ops.VQ_DEFAULT_COARSE)
     roof = vq_roofline(n_vq, 32768, 16, vq_main, vq_fin, len(vq_events), traffic, traffic_note, fp32_main, fp32_fin, mfmas=ops.VQ_COARSE_MFMAS)
     arith = {"fp32": "fp32 Q-Former/VQ/MMDiT (hipBLASLt fp32 GEMMs), bf16 SD3-VAE (reference dtypes)",
+             "exact": "every operation of Q-Former, VQ, MMDiT and VAE as the sequence of fp32 / bf16 operations the reference's torch-CPU run executes (MKL / oneDNN / ATen / Sleef orders "
+                      "on chained fp32 MFMAs): ids, latents and pixels bit-equal to the reference's",
              "f16x2": "fp32 Q-Former/VQ/MMDiT with the MMDiT block Linears and joint attention as f16x2-split products on the f16 matrix cores "
                       "(fp32-equivalent: error vs fp64 below the fp32 kernels', tests/test_gemm_gpu.py, test_kernels_gpu.py), bf16 SD3-VAE"}
     line = {

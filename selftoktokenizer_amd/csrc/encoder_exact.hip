@@ -200,6 +200,8 @@ struct XeGemmArgs {
     int M, N, K, H;
     int mode, gelu;                             // gelu: bit 0 GELU(tanh) epilogue, bit 1 bias added after the K-blocks instead of before
     int nblk;
+    int mt, nt;                                 // xe_gemm128_kernel: row / column tile counts (1-D XCD-aware grid)
+    int blk_chunks;                             // xe_gemm128_kernel: uniform K-block length in 32-k chunks (the launcher checks that blk_end is uniform)
     int blk_end[XE_MAXBLK];                     // K-block ends (multiples of 4; K itself a multiple of 16)
     unsigned rescale_mask;
 };
@@ -340,9 +342,155 @@ __global__ __launch_bounds__(256) void xe_gemm_kernel(XeGemmArgs g)
     }
 }
 
+// The same GEMM for the big Linears (N >= 128, K a multiple of 32, K-block ends multiples of 32: every block Linear of the MMDiT, the wide ones of the Q-Former).
+// Workgroup = 8 waves = 128 x 128 outputs, wave = 64 x 32 = two MFMA tiles (two independent chains); one staged chunk = 32 k.  The even / odd k of a row are
+// de-interleaved while staging ([16 even | 16 odd] fp32 per row and chunk, as xconv_kernel's rows): a lane reads the operands of ITS half of every k pair (lanes 0..31
+// the even k, 32..63 the odd k) as four ds_read_b128 per row tile -- no per-MFMA select, 32 MFMAs (2048 matrix cycles) per wave and barrier instead of 16, and
+// ~110 VGPRs: two workgroups (16 waves) per CU.
+__global__ __launch_bounds__(512) void xe_gemm128_kernel(XeGemmArgs g)
+{
+    constexpr int RA = 128, RB = 128;
+    __shared__ xu32x4 lds[2][(RA + RB) * 8];                      // 128 bytes per row and chunk: 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int i = lane & 31, h = lane >> 5;
+    const int z = blockIdx.z, zb = z / g.H, zh = z - zb * g.H;
+    // XCD-aware tile order (1-D grid of 8 * ceil(tiles / 8) workgroups): workgroups go round-robin to the 8 XCDs, each with its own L2.  All tiles are listed band by band
+    // (a band = 8 row tiles; inside a band column tile by column tile) and XCD x takes the x-th eighth of that list, in order: the ~64 workgroups resident on an XCD then
+    // cover 8 row tiles x 8 column tiles = 16 operand tiles (the plain row-fastest order: 64 row tiles x 1 column tile = 65 operand tiles, every A tile used once per L2)
+    int tm_, tn_;
+    {
+        const int MT = g.mt, NT = g.nt, T = MT * NT, per = (T + 7) >> 3;
+        const int L = blockIdx.x, sidx = (L & 7) * per + (L >> 3);
+        if ((L >> 3) >= per || sidx >= T) return;
+        const int full = MT >> 3, rem = MT & 7, cut = full * 8 * NT;
+        if (sidx < cut) { const int band = sidx / (8 * NT), r = sidx - band * 8 * NT; tn_ = r >> 3; tm_ = band * 8 + (r & 7); }
+        else { const int r = sidx - cut; tn_ = r / rem; tm_ = full * 8 + (r - tn_ * rem); }
+    }
+    const int pwg = tm_ * RA, nwg = tn_ * RB;
+    const int p0 = pwg + wm * 64, n0 = nwg + wn * 32;
+    const float* A = g.a + (size_t)zb * g.a_bs + (size_t)zh * g.a_hs;
+    const float* Bm = g.b + (size_t)zb * g.b_bs + (size_t)zh * g.b_hs;
+
+    // staging: piece (row, q) = k 8 q .. 8 q + 7 of the row's chunk (two 16-byte loads) -> even k (4 floats) to LDS piece q, odd k to piece 4 + q; 2 pieces per thread
+    const float* src[2]; int slot[2], sw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = tid + 512 * j, row = idx >> 2, q = idx & 3;            // rows 0..127 = A, 128..255 = B
+        const bool isb = row >= RA;
+        const int r = isb ? row - RA : row;
+        const float* base = isb ? Bm + (size_t)min(nwg + r, g.N - 1) * g.ldb : A + (size_t)min(pwg + r, g.M - 1) * g.lda;
+        src[j] = base + q * 8;
+        sw[j] = (row >> 1) & 7;
+        slot[j] = row * 8 + q;
+    }
+    float C[2][16];
+    f32x16 acc[2];
+    {
+        const int n = n0 + i;
+        const float b0 = (g.mode == 0 && g.bias != nullptr && n < g.N && !(g.gelu & 2)) ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { C[tm][r] = b0; acc[tm][r] = 0.f; }
+    }
+    xu32x4 s0[2], s1[2];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            s0[j] = *reinterpret_cast<const xu32x4*>(src[j] + c * 32);
+            s1[j] = *reinterpret_cast<const xu32x4*>(src[j] + c * 32 + 4);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const xu32x4 ev = {s0[j][0], s0[j][2], s1[j][0], s1[j][2]}, od = {s0[j][1], s0[j][3], s1[j][1], s1[j][3]};
+            const int base = slot[j] & ~7, q = slot[j] & 7;
+            lds[buf][base + (q ^ sw[j])] = ev;
+            lds[buf][base + ((4 + q) ^ sw[j])] = od;
+        }
+    };
+    int ra[2], swa[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { ra[t] = wm * 64 + t * 32 + i; swa[t] = (ra[t] >> 1) & 7; }
+    const int rb = RA + wn * 32 + i, swb = (rb >> 1) & 7;
+    auto fold = [&]() {                            // (no rescale here: the P V product of the attention has N = head_dim < 128 and takes xe_gemm_kernel)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { C[tm][r] = C[tm][r] + acc[tm][r]; acc[tm][r] = 0.f; }
+    };
+    auto compute = [&](int buf) {
+        // register double buffer over the four 8-k pieces of the chunk: piece q + 1 is read while piece q's 8 MFMAs issue; the scheduling barriers keep
+        // the compiler from hoisting all twelve ds_read_b128 to the top (48 live registers: 177 VGPRs, one workgroup per CU instead of two)
+        xu32x4 va0 = lds[buf][ra[0] * 8 + ((4 * h) ^ swa[0])], va1 = lds[buf][ra[1] * 8 + ((4 * h) ^ swa[1])], vb = lds[buf][rb * 8 + ((4 * h) ^ swb)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xu32x4 na0 = va0, na1 = va1, nb = vb;
+            if (q < 3) {
+                na0 = lds[buf][ra[0] * 8 + ((4 * h + q + 1) ^ swa[0])]; na1 = lds[buf][ra[1] * 8 + ((4 * h + q + 1) ^ swa[1])]; nb = lds[buf][rb * 8 + ((4 * h + q + 1) ^ swb)];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {          // k pair 8 q + 2 e (+1): this lane's element is its half's e-th of the piece
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(va0[e]), __uint_as_float(vb[e]), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(va1[e]), __uint_as_float(vb[e]), acc[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            va0 = na0; va1 = na1; vb = nb;
+        }
+    };
+    const int nchunks = g.K >> 5;
+    int cb = 0;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        if (more) fetch(c + 1);
+        compute(c & 1);
+        if (++cb == g.blk_chunks || !more) { cb = 0; fold(); }      // uniform K-blocks of g.blk_chunks chunks (the last may be shorter): no table lookup in the loop
+        if (more) stage((c + 1) & 1);
+        __syncthreads();
+    }
+    float* Cout = g.c + (size_t)zb * g.c_bs + (size_t)zh * g.c_hs;
+    const int n = n0 + i;
+    if (n < g.N) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = p0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= g.M) continue;
+                float v = C[tm][r];
+                if (g.mode == 1) v = v * g.out_scale;
+                else if (g.mode == 2) v = v * g.rowscale[(size_t)z * g.M + m];
+                else {
+                    if ((g.gelu & 2) && g.bias != nullptr) v = v + g.bias[n];
+                    if (g.gelu & 1) v = xe_gelu_tanh1(v);
+                    if (g.gate != nullptr) v = g.gate[(size_t)(g.gate_mod > 0 ? m % g.gate_mod : (g.gate_mod < 0 ? m / -g.gate_mod : m)) * g.ldg + n] * v;
+                    if (g.res != nullptr) v = g.res[(size_t)(g.res_mod > 0 ? m % g.res_mod : (g.res_mod < 0 ? m / -g.res_mod : m)) * g.ldr + n] + v;
+                }
+                Cout[(size_t)m * g.ldc + n] = v;
+                __builtin_amdgcn_sched_barrier(0);          // one output at a time: the unrolled epilogue must not set the kernel's register count
+            }
+    }
+}
+
 static int launch_xe_gemm(const XeGemmArgs& g, int Z, hipStream_t stream)
 {
-    if (g.N > 64) {
+    bool wide = g.rescale_mask == 0 && g.N >= 128 && g.M >= 128 && (g.K & 31) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 && g.nblk > 0 && (g.blk_end[0] & 31) == 0;
+    for (int j = 0; j < g.nblk && wide; ++j) wide = g.blk_end[j] == ((j + 1) * g.blk_end[0] < g.K ? (j + 1) * g.blk_end[0] : g.K);      // uniform blocks, last one shorter
+    if (wide) {
+        XeGemmArgs w = g;
+        w.blk_chunks = g.blk_end[0] >> 5;
+        w.mt = (g.M + 127) / 128; w.nt = (g.N + 127) / 128;
+        dim3 grid((unsigned)(8 * ((w.mt * w.nt + 7) / 8)), 1, Z);
+        hipLaunchKernelGGL(xe_gemm128_kernel, grid, dim3(512), 0, stream, w);
+    } else if (false) {
+        dim3 grid((unsigned)((g.M + 127) / 128), (unsigned)((g.N + 127) / 128), Z);
+        hipLaunchKernelGGL(xe_gemm128_kernel, grid, dim3(512), 0, stream, g);
+    } else if (g.N > 64) {
         dim3 grid((unsigned)((g.M + 63) / 64), (unsigned)((g.N + 127) / 128), Z);
         hipLaunchKernelGGL((xe_gemm_kernel<2, 2, 2>), grid, dim3(256), 0, stream, g);
     } else if (g.N > 32) {
