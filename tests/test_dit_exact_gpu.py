@@ -136,3 +136,23 @@ def test_pipeline_16_images_pixels_equal_the_reference_bit_for_bit():
     psnr = E.psnr_each(rec, imgs)
     assert np.array_equal(psnr, g["psnr_ref"]), np.abs(psnr - g["psnr_ref"]).max()
     print("pixels of all 16 images equal the reference's; PSNR identical:", psnr[:4])
+
+
+def test_guided_steps_16_images_equal_the_reference(models):
+    """classifier-free guidance (sd3/rectified_flow.py:280-289: MMDiT.cfg_inference -- integer-floored timestep, no context key visible -- and the conditional
+    call without context_see_xt, mixed as u + s (c - u)): the latents after one and two guided steps at B = 16 have the reference's crc32 (tests/golden/cfg_b16.npz)"""
+    from selftoktokenizer_amd.pipeline import _Flow
+    from selftoktokenizer_amd.schedule import DiTiCont
+    sd, enc, dit = models
+    g = np.load(os.path.join(GOLD, "cfg_b16.npz"))
+    B = 16
+    cfgp = default_config(512).tokenizer.params
+    flow = _Flow(50, 1.0, dit.device)
+    ktab = DiTiCont(1000, 512, cfgp.stages, cfgp.k_per_stage).to_indices(flow.t_long)
+    ehs = enc.codes_ln(torch.from_numpy(synth.synthetic_token_ids(B, first_index=11)).cuda())
+    noise = synth.synthetic_noise(B, first_index=11)
+    for steps in (1, 2):
+        lat = flow.p_sample_loop(dit, noise, ehs, ktab, context_see_xt=True, uncond_scale=float(g["scale"]), max_steps=steps)
+        sub = lat[:, :, ::4, ::4].contiguous().cpu().numpy()
+        print(f"\nafter {steps} guided step(s): sub-sample max abs diff vs the reference {np.abs(sub - g[f'sub_{steps}']).max():.3e}")
+        assert zlib.crc32(lat.contiguous().cpu().numpy().tobytes()) == int(g[f"crc_{steps}"]), f"latents after {steps} guided step(s) differ from the reference's"

@@ -619,6 +619,35 @@ def stage_cfg():
     np.savez_compressed(os.path.join(GOLD, "cfg_b1.npz"), **out)
 
 
+def stage_cfg16():
+    """classifier-free guidance at B = 16 (the row regime of MKL's K-blocking the exact-order MMDiT mode reproduces): two guided sampler steps of the
+    reference (sd3/rectified_flow.py:258-294 -> MMDiT.cfg_inference + MMDiT.forward without context_see_xt) from the first schedule entries; crc32 + a
+    sub-sampled copy of the latents after each step"""
+    import zlib
+    cfg, model, sd = tokenizer(CFG_256)
+    flow = _ref_flow()
+    from mimogpt.models.selftok.diti_utils import DiTi_cont
+    diti = DiTi_cont(1000, 512, cfg.tokenizer.params.stages, cfg.tokenizer.params.k_per_stage)
+    B = 16
+    ids = torch.from_numpy(synth.synthetic_token_ids(B, first_index=11))
+    with torch.no_grad():
+        codes = model.encoder.quantizer.get_output_from_indices(ids)
+        ehs = model.encoder.final_layer_norm3(codes.reshape(B, -1, 16))
+    x = synth.synthetic_noise(B, first_index=11)
+    out = {"scale": np.float32(2.0)}
+    xr = x.clone()
+    for i in (0, 1):
+        t = torch.tensor([flow.scheduled_t[i]] * B)
+        k = diti.to_indices(torch.tensor([flow.timestep_map[i]] * B).long())
+        mask = model.encoder.get_encoder_mask(x, k)
+        kw = dict(encoder_hidden_states=ehs, mask=mask, context_see_xt=True)
+        with torch.no_grad():
+            xr, _ = flow.sample_one_step(model.model, xr, t, index=i, model_kwargs=kw, cfg_scale=2.0)
+        out[f"crc_{i + 1}"] = np.uint32(zlib.crc32(xr.contiguous().numpy().tobytes())); out[f"sub_{i + 1}"] = xr[:, :, ::4, ::4].contiguous().numpy()
+        report(f"cfg16_step{i}", k=int(k[0]), absmax=float(xr.abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "cfg_b16.npz"), **out)
+
+
 def stage_sampler_options():
     """two dormant branches of the reference's sampler, from the reference's own RectifiedFlow.sample_one_step on the real MMDiT:
     (a) `parameterization: x0` (euler_step, sd3/rectified_flow.py:305-307): two steps from the first schedule entries;
@@ -693,6 +722,37 @@ def stage_k1024():
     report("k1024_dit", v_maxdiff=maxdiff(v, v_o), v_absmax=float(v.abs().max()))
     np.savez_compressed(os.path.join(GOLD, "k1024_b1.npz"), z=cap["z"].numpy(), ids=ids.numpy(), gap=gap.numpy(), outs_q=outs_q.numpy(),
                         v=v.numpy(), t=np.float32(tval), k=np.int64(k))
+
+
+def stage_k1024_16():
+    """BASELINE configs[2] in the exact-order regime: the reference's ImageTokenizer(k = 1024) at B = 16 -- encoder features + ids from 16 latents (crc32, and the
+    features of two images in full) and one MMDiT.forward at a scheduled timestep (crc32 + sub-sample): for the exact-order encoder / MMDiT at K = 1024"""
+    import zlib
+    cfg = H.load_cfg(CFG_256)
+    cfg.tokenizer.params.k = 1024
+    cfg.tokenizer.params.k_per_stage = "384,368,144,96,32"
+    model, ref_sd = H.build_tokenizer(cfg)
+    B = 16
+    x0 = synth.synthetic_latents(B, first_index=5).to(torch.bfloat16).float()
+    cap = {}
+    hk = model.encoder.quantizer.project_in.register_forward_hook(lambda m, i, o: cap.__setitem__("z", o.detach().clone()))
+    with torch.no_grad():
+        outs_q, ids = model.encoder(x0, d=None)
+    hk.remove()
+    from selftoktokenizer_amd.schedule import FlowSchedule, DiTiCont
+    fs = FlowSchedule(50, 1.0)
+    ktab = DiTiCont(1000, 1024, cfg.tokenizer.params.stages, cfg.tokenizer.params.k_per_stage).to_indices(fs.t_long)
+    i = 25
+    x = synth.synthetic_noise(B, first_index=5)
+    t = torch.full((B,), float(fs.scheduled_t[i]))
+    k = int(ktab[i])
+    mask = (torch.arange(1024)[None] <= k).expand(B, -1)
+    with torch.no_grad():
+        v, _ = model.model(x, t, encoder_hidden_states=outs_q, mask=mask, context_see_xt=True)
+    report("k1024_16", k=k, step=i, v_absmax=float(v.abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "k1024_b16.npz"), zcrc=np.uint32(zlib.crc32(cap["z"].contiguous().numpy().tobytes())), z2=cap["z"][:2].numpy(),
+                        ids=ids.numpy().astype(np.int16), vcrc=np.uint32(zlib.crc32(v.contiguous().numpy().tobytes())), vsub=v[:, :, ::4, ::4].contiguous().numpy(),
+                        step=np.int64(i), k=np.int64(k))
 
 
 def stage_vqtrain():
@@ -836,7 +896,7 @@ def stage_rmsnorm_rotary():
     report("rmsnorm_rotary", arrays=sorted(out), rms_absmax=float(np.abs(out["rms_affine"]).max()), rot_absmax=float(np.abs(out["rot_full"]).max()))
 
 
-STAGES = dict(dit4=stage_dit4, config=stage_config, decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
+STAGES = dict(k1024_16=stage_k1024_16, cfg16=stage_cfg16, dit4=stage_dit4, config=stage_config, decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
               vae=stage_vae, pipeline=stage_pipeline, pipeline16=stage_pipeline16, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024, vqtrain=stage_vqtrain)
 
 if __name__ == "__main__":
