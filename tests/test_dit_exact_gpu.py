@@ -156,3 +156,30 @@ def test_guided_steps_16_images_equal_the_reference(models):
         sub = lat[:, :, ::4, ::4].contiguous().cpu().numpy()
         print(f"\nafter {steps} guided step(s): sub-sample max abs diff vs the reference {np.abs(sub - g[f'sub_{steps}']).max():.3e}")
         assert zlib.crc32(lat.contiguous().cpu().numpy().tobytes()) == int(g[f"crc_{steps}"]), f"latents after {steps} guided step(s) differ from the reference's"
+
+
+def test_k1024_tokenizer_equals_the_reference_at_16_images():
+    """BASELINE configs[2] (K = 1024: 1280 keys in the Q-Former's query attention, 1024 context slots in the joint attention): the reference's own
+    ImageTokenizer(k = 1024) at B = 16 (tests/golden/k1024_b16.npz) -- encoder features and ids from 16 latents and one MMDiT.forward, bit for bit"""
+    from selftoktokenizer_amd.encoder import QformerEncoderGPU
+    from selftoktokenizer_amd.mmdit import MMDiTGPU
+    from selftoktokenizer_amd.pipeline import _Flow
+    g = np.load(os.path.join(GOLD, "k1024_b16.npz"))
+    sd = W.synthetic_state_dict(W.expected_shapes(1024), device="cuda")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    enc = QformerEncoderGPU(sd, dev, 1024, mode="exact")
+    B = 16
+    x0 = synth.synthetic_latents(B, first_index=5).to(torch.bfloat16).float().cuda()
+    z = enc.features(x0)
+    _same(z[:2], g["z2"], "K = 1024 encoder features (first two images)")
+    assert zlib.crc32(z.contiguous().cpu().numpy().tobytes()) == int(g["zcrc"])
+    outs_q, ids = enc(x0)
+    assert np.array_equal(ids.cpu().numpy(), g["ids"].astype(np.int64))
+    dit = MMDiTGPU(sd, dev, 1024, gemm="exact")
+    flow = _Flow(50, 1.0, dev)
+    i, k = int(g["step"]), int(g["k"])
+    x = synth.synthetic_noise(B, first_index=5, device="cuda")
+    y = dit.velocity_tokens(x, flow.t_freq_exact[i:i + 1].expand(B, -1).contiguous(), dit.embed_context(outs_q), k + 1, True)
+    _, v = ops.unpatchify_cfg_euler(y, None, 0.0, C=16, hp=16, wp=16)
+    print(f"\nK = 1024, step {i} (k = {k}): velocity sub-sample max abs diff vs the reference {np.abs(v[:, :, ::4, ::4].cpu().numpy() - g['vsub']).max():.3e}")
+    assert zlib.crc32(v.contiguous().cpu().numpy().tobytes()) == int(g["vcrc"])
