@@ -115,6 +115,10 @@ class _Flow(FlowSchedule):
         if visible is None and super_mask is not None:
             visible = self.resolve_super_mask(super_mask, ctx0.shape[1])
         if visible is not None:
+            if dit.gemm == "exact" and not np.array_equal(visible[1], np.arange(len(visible[1]))):
+                # the exact mode keeps every context key at its POSITION in the reference's key sequence (kv blocks of 512, MKL's K-blocks); gathering the
+                # visible tokens of a non-prefix pattern moves them.  Prefix patterns (the sampler's own masks, prefix_k) are exact.
+                raise NotImplementedError("gemm='exact' reproduces the reference's bits for prefix visibility patterns; decode a non-prefix super_mask with gemm='fp32' / 'f16x2'")
             idx_dev, vis_pos = visible                                        # device index tensor (made outside any capture), host positions
             ctx0, tables, _ = dit.gather_context(ctx0, index=idx_dev)
         cqkv0 = dit.block0_context_qkv(ctx0, tables) if ctx0.shape[1] > 0 else None   # block 0's context QKV is step independent too
