@@ -26,7 +26,7 @@ ap.add_argument("--renderer-pretrained", default=None)
 ap.add_argument("--data_size", type=int, default=256)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--seed", type=int, default=1234)
-ap.add_argument("--gemm", default=None, choices=["fp32", "f16x2"])
+ap.add_argument("--gemm", default=None, choices=["fp32", "f16x2", "exact"], help="exact: every operation in the reference's torch-CPU order (bit-equal pixels, the parity mode)")
 ap.add_argument("--out", default=None, help="also write the JSON line to this file (rank 0)")
 a = ap.parse_args()
 
