@@ -919,16 +919,16 @@ int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const
 }
 size_t selftok_vx_groupnorm_workspace_bytes(int B, int HW, int C)
 {
-    const int RP = HW >= 4096 ? 4096 : 1024;
-    if (B <= 0 || HW % RP || C % 128) return 0;
-    return (size_t)B * C * (HW / RP) * 8 * 8 + (size_t)2 * B * C * sizeof(float);
+    if (B <= 0 || HW <= 0 || HW % 16 || C % 128) return 0;
+    return ((size_t)B * C * HW / 256 + (size_t)B * C) * 16 * 8 + (size_t)2 * B * C * sizeof(float);          /* unused here: an upper bound of the HIP build's */
 }
 int selftok_vx_groupnorm_bf16(const void* x, const void* gamma, const void* beta, void* out, void* workspace, const void* silu_table, float* stats, int B, int HW,
                               int C, int groups, double eps, hipStream_t s)
 {
     (void)s; (void)workspace;
     if (B == 0) return SELFTOK_OK;
-    if (!x || !gamma || !beta || !out || B < 0 || groups <= 0 || C % groups) return fail("vx_groupnorm: bad argument");
+    if (!x || !gamma || !beta || !out || B < 0 || groups <= 0 || C % groups || C % 128 || HW <= 0 || HW % 16 || ((C / groups) & (C / groups - 1)))
+        return fail("vx_groupnorm: need C % 128 == 0, H*W % 16 == 0, power-of-two channels per group");
     vx_group_norm_nhwc((const uint16_t*)x, (const uint16_t*)gamma, (const uint16_t*)beta, (uint16_t*)out, B, HW, C, groups, eps, (const uint16_t*)silu_table, stats);
     return SELFTOK_OK;
 }
@@ -947,14 +947,14 @@ int selftok_vx_silu_table_bf16(void* table, hipStream_t s)
 }
 size_t selftok_vx_attention_workspace_bytes(int B, int T, int C)
 {
-    if (B <= 0) return 0;
-    return (size_t)B * T * T * 4 + (size_t)B * T * T * 2 + (size_t)B * T * C * 2 + (size_t)2 * B * T * 4;
+    if (B <= 0 || T <= 0) return 0;
+    return (size_t)B * T * T * 4 + (size_t)B * T * T * 2 + (size_t)B * T * C * 2 + ((size_t)(T + 511) / 512 + 1) * B * T * 4;
 }
 int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void* out, void* workspace, int B, int T, int C, hipStream_t s)
 {
     (void)s; (void)workspace;
     if (B == 0) return SELFTOK_OK;
-    if (!q || !k || !v || !out || B < 0 || T != 1024 || C % 128) return fail("vx_attention: one head, T == 1024, C % 128 == 0");
+    if (!q || !k || !v || !out || B < 0 || T <= 0 || T % 32 || C % 128 || C > 4096) return fail("vx_attention: one head, T % 32 == 0, C % 128 == 0");
     return vx_attention((const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (uint16_t*)out, B, T, C) ? fail("vx_attention") : SELFTOK_OK;
 }
 int selftok_vx_expf_f32(const float* x, float* y, long n, hipStream_t s)

@@ -50,11 +50,13 @@ def silu_table() -> np.ndarray:
     return np.load(SILU_TABLE)
 
 
-def conv_order(ic: int, kh: int, stride: int) -> int:
-    """the chunk order oneDNN's AMX kernel uses for the layers of the SD3-VAE encoder at 256 x 256 (probed per layer shape)"""
+def conv_order(ic: int, kh: int, stride: int, width: int = 256) -> int:
+    """the chunk order oneDNN's AMX kernel uses for a layer of the SD3-VAE encoder (probed per layer shape at 128 / 256 / 320 px,
+    tools/probe_cpu_bf16/): a stride-2 layer runs channel-block major (order 3) iff its input is at least 102 pixels wide -- at 256 px the
+    128- and 256-channel Downsample layers (256 and 128 wide; the 512-channel one is 64 wide)"""
     if ic < 32:
         return 2
-    if stride == 2 and ic in (128, 256):
+    if stride == 2 and width >= 102:
         return 3
     return 0
 
@@ -72,7 +74,7 @@ def conv2d(x, w, b, stride=1, pad=1, residual=None, order=None, out_hw=None):
     y = np.empty((B, OH, OW, OC), dtype=np.uint16)
     r = None if residual is None else _u16(residual)
     rc = lib().vx_conv2d_nhwc(_p(x), _p(w), _p(b), _p(r), _p(y), B, H, W, IC, OC, KH, KW, stride, pad, OH, OW,
-                              conv_order(IC, KH, stride) if order is None else order)
+                              conv_order(IC, KH, stride, W) if order is None else order)
     assert rc == 0
     return y
 

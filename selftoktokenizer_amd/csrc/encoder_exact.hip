@@ -347,11 +347,13 @@ __global__ __launch_bounds__(256) void xe_gemm_kernel(XeGemmArgs g)
 // de-interleaved while staging ([16 even | 16 odd] fp32 per row and chunk, as xconv_kernel's rows): a lane reads the operands of ITS half of every k pair (lanes 0..31
 // the even k, 32..63 the odd k) as four ds_read_b128 per row tile -- no per-MFMA select, 32 MFMAs (2048 matrix cycles) per wave and barrier instead of 16, and
 // ~110 VGPRs: two workgroups (16 waves) per CU.
-__global__ __launch_bounds__(512) void xe_gemm128_kernel(XeGemmArgs g)
+template <int TN>      // column tiles per wave: 1 = 8 waves of 64 x 32 (the built default), 2 = 4 waves of 64 x 64
+__global__ __launch_bounds__(512 / TN) void xe_gemm128_kernel(XeGemmArgs g)
 {
     constexpr int RA = 128, RB = 128;
     __shared__ xu32x4 lds[2][(RA + RB) * 8];                      // 128 bytes per row and chunk: 64 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NTHR = 512 / TN, NPC = 1024 / NTHR;
     const int wm = wave & 1, wn = wave >> 1;
     const int i = lane & 31, h = lane >> 5;
     const int z = blockIdx.z, zb = z / g.H, zh = z - zb * g.H;
@@ -368,15 +370,15 @@ __global__ __launch_bounds__(512) void xe_gemm128_kernel(XeGemmArgs g)
         else { const int r = sidx - cut; tn_ = r / rem; tm_ = full * 8 + (r - tn_ * rem); }
     }
     const int pwg = tm_ * RA, nwg = tn_ * RB;
-    const int p0 = pwg + wm * 64, n0 = nwg + wn * 32;
+    const int p0 = pwg + wm * 64, n0 = nwg + wn * (32 * TN);
     const float* A = g.a + (size_t)zb * g.a_bs + (size_t)zh * g.a_hs;
     const float* Bm = g.b + (size_t)zb * g.b_bs + (size_t)zh * g.b_hs;
 
     // staging: piece (row, q) = k 8 q .. 8 q + 7 of the row's chunk (two 16-byte loads) -> even k (4 floats) to LDS piece q, odd k to piece 4 + q; 2 pieces per thread
-    const float* src[2]; int slot[2], sw[2];
+    const float* src[NPC]; int slot[NPC], sw[NPC];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int idx = tid + 512 * j, row = idx >> 2, q = idx & 3;            // rows 0..127 = A, 128..255 = B
+    for (int j = 0; j < NPC; ++j) {
+        const int idx = tid + NTHR * j, row = idx >> 2, q = idx & 3;            // rows 0..127 = A, 128..255 = B
         const bool isb = row >= RA;
         const int r = isb ? row - RA : row;
         const float* base = isb ? Bm + (size_t)min(nwg + r, g.N - 1) * g.ldb : A + (size_t)min(pwg + r, g.M - 1) * g.lda;
@@ -384,27 +386,28 @@ __global__ __launch_bounds__(512) void xe_gemm128_kernel(XeGemmArgs g)
         sw[j] = (row >> 1) & 7;
         slot[j] = row * 8 + q;
     }
-    float C[2][16];
-    f32x16 acc[2];
-    {
-        const int n = n0 + i;
+    float C[2][TN][16];
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + tn * 32 + i;
         const float b0 = (g.mode == 0 && g.bias != nullptr && n < g.N && !(g.gelu & 2)) ? g.bias[n] : 0.f;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { C[tm][r] = b0; acc[tm][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { C[tm][tn][r] = b0; acc[tm][tn][r] = 0.f; }
     }
-    xu32x4 s0[2], s1[2];
+    xu32x4 s0[NPC], s1[NPC];
     auto fetch = [&](int c) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NPC; ++j) {
             s0[j] = *reinterpret_cast<const xu32x4*>(src[j] + c * 32);
             s1[j] = *reinterpret_cast<const xu32x4*>(src[j] + c * 32 + 4);
         }
     };
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NPC; ++j) {
             const xu32x4 ev = {s0[j][0], s0[j][2], s1[j][0], s1[j][2]}, od = {s0[j][1], s0[j][3], s1[j][1], s1[j][3]};
             const int base = slot[j] & ~7, q = slot[j] & 7;
             lds[buf][base + (q ^ sw[j])] = ev;
@@ -414,30 +417,44 @@ __global__ __launch_bounds__(512) void xe_gemm128_kernel(XeGemmArgs g)
     int ra[2], swa[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) { ra[t] = wm * 64 + t * 32 + i; swa[t] = (ra[t] >> 1) & 7; }
-    const int rb = RA + wn * 32 + i, swb = (rb >> 1) & 7;
+    int rb[TN], swb[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) { rb[t] = RA + wn * (32 * TN) + t * 32 + i; swb[t] = (rb[t] >> 1) & 7; }
     auto fold = [&]() {                            // (no rescale here: the P V product of the attention has N = head_dim < 128 and takes xe_gemm_kernel)
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { C[tm][r] = C[tm][r] + acc[tm][r]; acc[tm][r] = 0.f; }
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { C[tm][tn][r] = C[tm][tn][r] + acc[tm][tn][r]; acc[tm][tn][r] = 0.f; }
     };
     auto compute = [&](int buf) {
         // register double buffer over the four 8-k pieces of the chunk: piece q + 1 is read while piece q's 8 MFMAs issue; the scheduling barriers keep
         // the compiler from hoisting all twelve ds_read_b128 to the top (48 live registers: 177 VGPRs, one workgroup per CU instead of two)
-        xu32x4 va0 = lds[buf][ra[0] * 8 + ((4 * h) ^ swa[0])], va1 = lds[buf][ra[1] * 8 + ((4 * h) ^ swa[1])], vb = lds[buf][rb * 8 + ((4 * h) ^ swb)];
+        xu32x4 va[2], vb[TN];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) va[t] = lds[buf][ra[t] * 8 + ((4 * h) ^ swa[t])];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) vb[t] = lds[buf][rb[t] * 8 + ((4 * h) ^ swb[t])];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            xu32x4 na0 = va0, na1 = va1, nb = vb;
-            if (q < 3) {
-                na0 = lds[buf][ra[0] * 8 + ((4 * h + q + 1) ^ swa[0])]; na1 = lds[buf][ra[1] * 8 + ((4 * h + q + 1) ^ swa[1])]; nb = lds[buf][rb * 8 + ((4 * h + q + 1) ^ swb)];
-            }
+            xu32x4 na[2], nb[TN];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {          // k pair 8 q + 2 e (+1): this lane's element is its half's e-th of the piece
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(va0[e]), __uint_as_float(vb[e]), acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(va1[e]), __uint_as_float(vb[e]), acc[1], 0, 0, 0);
-            }
+            for (int t = 0; t < 2; ++t) na[t] = q < 3 ? lds[buf][ra[t] * 8 + ((4 * h + q + 1) ^ swa[t])] : va[t];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) nb[t] = q < 3 ? lds[buf][rb[t] * 8 + ((4 * h + q + 1) ^ swb[t])] : vb[t];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)            // k pair 8 q + 2 e (+1): this lane's element is its half's e-th of the piece
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(va[tm][e]), __uint_as_float(vb[tn][e]), acc[tm][tn], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            va0 = na0; va1 = na1; vb = nb;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) va[t] = na[t];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) vb[t] = nb[t];
         }
     };
     const int nchunks = g.K >> 5;
@@ -454,15 +471,17 @@ __global__ __launch_bounds__(512) void xe_gemm128_kernel(XeGemmArgs g)
         __syncthreads();
     }
     float* Cout = g.c + (size_t)zb * g.c_bs + (size_t)zh * g.c_hs;
-    const int n = n0 + i;
-    if (n < g.N) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + tn * 32 + i;
+        if (n >= g.N) continue;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = p0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m >= g.M) continue;
-                float v = C[tm][r];
+                float v = C[tm][tn][r];
                 if (g.mode == 1) v = v * g.out_scale;
                 else if (g.mode == 2) v = v * g.rowscale[(size_t)z * g.M + m];
                 else {
@@ -477,6 +496,9 @@ __global__ __launch_bounds__(512) void xe_gemm128_kernel(XeGemmArgs g)
     }
 }
 
+#ifndef XE_GEMM128_TN
+#define XE_GEMM128_TN 1          // measured (profiles/r5_ex_gemm_wave_tile.txt): 64 x 32 wave tiles at 122 VGPRs / 4 waves per SIMD beat 64 x 64 at 211 / 2
+#endif
 static int launch_xe_gemm(const XeGemmArgs& g, int Z, hipStream_t stream)
 {
     bool wide = g.rescale_mask == 0 && g.N >= 128 && g.M >= 128 && (g.K & 31) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 && g.nblk > 0 && (g.blk_end[0] & 31) == 0;
@@ -486,10 +508,7 @@ static int launch_xe_gemm(const XeGemmArgs& g, int Z, hipStream_t stream)
         w.blk_chunks = g.blk_end[0] >> 5;
         w.mt = (g.M + 127) / 128; w.nt = (g.N + 127) / 128;
         dim3 grid((unsigned)(8 * ((w.mt * w.nt + 7) / 8)), 1, Z);
-        hipLaunchKernelGGL(xe_gemm128_kernel, grid, dim3(512), 0, stream, w);
-    } else if (false) {
-        dim3 grid((unsigned)((g.M + 127) / 128), (unsigned)((g.N + 127) / 128), Z);
-        hipLaunchKernelGGL(xe_gemm128_kernel, grid, dim3(512), 0, stream, g);
+        hipLaunchKernelGGL((xe_gemm128_kernel<XE_GEMM128_TN>), grid, dim3(512 / XE_GEMM128_TN), 0, stream, w);
     } else if (g.N > 64) {
         dim3 grid((unsigned)((g.M + 63) / 64), (unsigned)((g.N + 127) / 128), Z);
         hipLaunchKernelGGL((xe_gemm_kernel<2, 2, 2>), grid, dim3(256), 0, stream, g);

@@ -57,13 +57,15 @@ struct XConvArgs {
     const unsigned short* bias;   // [OC] bf16 or null
     const unsigned short* res;    // [P][OC] bf16 or null                    (+ z * y_bs)
     void* y;                      // [P][OC] bf16 (mode 0, 2) / fp32 (mode 1) (+ z * y_bs)
-    const float* rescale;         // [P] or null: C *= rescale[p] before chunk `split`   (+ z * v_bs)
+    const float* rescale;         // [nblk][rs_stride] or null: C *= rescale[j][p] before chunk j * split, j >= 1   (+ z * v_bs)
     const float* rowscale;        // [P]: mode 2, y = bf16(C * rowscale[p])              (+ z * v_bs)
     float out_scale;              // mode 1: y = C * out_scale
     int H, W, IC, OC, KH, KW, stride, pad, OH, OW;
     int split, mode;
     int up;                       // 1: the convolution reads a nearest-2x upsampled view of x ([B][H/2][W/2][IC] in memory; H, W = the upsampled size)
     long x_bs, w_bs, y_bs, v_bs;
+    long P;                       // rows (output pixels) per z: the last workgroup's rows beyond P are neither read nor written
+    long rs_stride;
 };
 
 typedef float xf32x2 __attribute__((ext_vector_type(2)));
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
         const int idx = tid + 256 * j, row = idx >> 2, q = idx & 3;
-        aon[j] = idx < RA * 4;
+        aon[j] = idx < RA * 4 && pwg + row < a.P;
         const long pa = pwg + (aon[j] ? row : 0);
         const int ohw = a.OH * a.OW;
         const int b = (int)(pa / ohw);
@@ -210,11 +212,12 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
     for (int c = 0; c < nchunks; ++c) {
         const bool more = c + 1 < nchunks;
         if (more) fetch();                                       // the next chunk's 12 KB are in flight during this chunk's MFMAs
-        if (a.rescale != nullptr && c == a.split) {              // the flash kernel's `dst *= exp(old max - new max)` between its two kv blocks
-            const float* rs = a.rescale + (size_t)z * a.v_bs + p0;
+        if (a.rescale != nullptr && c > 0 && c % a.split == 0) {  // the flash kernel's `dst *= exp(old max - new max)` when a new kv block starts
+            const float* rs = a.rescale + (size_t)(c / a.split) * a.rs_stride + (size_t)z * a.v_bs;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float f = rs[(r & 3) + 8 * (r >> 2) + 4 * h];
+                const long pr = p0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float f = rs[pr < a.P ? pr : a.P - 1];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) C[t][r] = C[t][r] * f;
             }
@@ -238,6 +241,7 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long p = p0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (p >= a.P) continue;
             const size_t off = (size_t)z * a.y_bs + (size_t)p * OC + oc;
             if (a.mode == 1) {
                 reinterpret_cast<float*>(a.y)[off] = C[t][r] * a.out_scale;
@@ -321,10 +325,10 @@ __device__ __forceinline__ void add_moments_vec(int m0_add, Mom add, int& m0, Mo
 // a vector's first half is pixel 16 j + l, of its second half pixel 16 j + 8 + l.  Every thread runs ATen's chunk loop + binary cascade
 // over the RP / 256 chunks of its range for its 8 channels; the range's node (level log2(RP / 256)) goes to the workspace.
 // node layout: [B][C][R][8 lanes] of Mom.
-template <int NCH>       // chunks per range: 16 (RP = 4096) or 4 (RP = 1024)
+template <int NCH>       // chunks per range: 16 (RP = 4096), 4 (RP = 1024) or 2 (RP = 512)
 __global__ __launch_bounds__(128) void xgn_partial_kernel(const unsigned short* __restrict__ x, Mom* __restrict__ nodes, int HW, int C, int R)
 {
-    constexpr int LV = NCH == 16 ? 5 : 3;          // levels 0 .. log2(NCH)
+    constexpr int LV = NCH == 16 ? 5 : (NCH == 4 ? 3 : 2);          // levels 0 .. log2(NCH)
     const int l = threadIdx.x >> 4, cq = threadIdx.x & 15;
     const int r = blockIdx.x, cblk = blockIdx.y, b = blockIdx.z;
     const int c0 = cblk * 128 + cq * 8;
@@ -389,7 +393,7 @@ __global__ void xgn_finish_kernel(const Mom* __restrict__ nodes, const unsigned 
     const int Q = D * R;
     int depth = 0;
     while ((1 << depth) < Q) ++depth;
-    constexpr int MAXD = 9;                     // Q <= 256 nodes; every stack index below is a compile-time constant (registers, no scratch)
+    constexpr int MAXD = 10;                    // Q <= 512 nodes; every stack index below is a compile-time constant (registers, no scratch)
     Mom stk[MAXD];
     int m0s[MAXD];
 #pragma unroll
@@ -414,6 +418,129 @@ __global__ void xgn_finish_kernel(const Mom* __restrict__ nodes, const unsigned 
     for (int j = 1; j < MAXD; ++j)
         if (j < depth) add_moments_vec(m0s[j], stk[j], m0s[0], stk[0]);
     // lane combination on lane 0 of the 8 (the values of lanes 1..7 through shuffles)
+    float m1 = 0.f, m2 = 0.f;
+    int m0 = 0;
+    const int m0_add = m0s[0];
+    for (int k = 0; k < 8; ++k) {
+        const float a1 = __shfl(stk[0].m1, (threadIdx.x & ~7) + k, WAVE), a2 = __shfl(stk[0].m2, (threadIdx.x & ~7) + k, WAVE);
+        const int n = m0 + m0_add;
+        const float c = n == 0 ? 0.f : (float)m0_add / (float)n;
+        const float delta = a1 - m1;
+        m1 = fmaf(c, delta, m1);
+        m2 = m2 + fmaf(delta * delta * c, (float)m0, a2);
+        m0 = n;
+    }
+    if (l != 0) return;
+    const float N = (float)((long)D * HW);
+    const float var = m2 / N;
+    const float rstd = (float)(1.0 / sqrt((double)fmaxf(var, 0.f) + eps));
+    if (stats != nullptr) { stats[2 * grp] = m1; stats[2 * grp + 1] = rstd; }
+    for (int d = 0; d < D; ++d) {
+        const int c = g * D + d;
+        const float sc = rstd * xbf2f(gamma[c]);
+        scale[(size_t)b * C + c] = sc;
+        bias[(size_t)b * C + c] = fmaf(-sc, m1, xbf2f(beta[c]));
+    }
+}
+
+// Shapes whose channels hold an ODD number of chunks (H*W = 6400, 256: the 80 x 80 and 16 x 16 maps of a 320 / 128 px image) or whose chunks
+// straddle channel boundaries (H*W % 256 != 0: 40 x 40) have no aligned pair of chunks to pre-combine: level 0 of ATen's cascade takes the two
+// halves (a, b) of chunk i and then of chunk i + 1 one after the other, so pass 1 stores every chunk's two half-moments RAW and pass 2 replays
+// the whole loop.  raw layout: [B][G][m chunks of the group][2 halves][8 lanes] of Mom, m = ceil(D * HW / 256).
+// Pass 1r, H*W % 256 == 0: the chunk grid is the same for every channel -> the vectorised body of xgn_partial_kernel, one chunk per thread.
+__global__ __launch_bounds__(128) void xgn_chunk_kernel(const unsigned short* __restrict__ x, Mom* __restrict__ raw, int HW, int C, int NC)
+{
+    const int l = threadIdx.x >> 4, cq = threadIdx.x & 15;
+    const int ic = blockIdx.x, cblk = blockIdx.y, b = blockIdx.z;
+    const int c0 = cblk * 128 + cq * 8;
+    const unsigned short* xp = x + ((size_t)b * HW + (size_t)ic * 256) * C + c0;
+    Mom a[8], bb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = Mom{0.f, 0.f}; bb[e] = Mom{0.f, 0.f}; }
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+        const float cj = 1.0f / (float)(j + 1);
+        const us8v va = *reinterpret_cast<const us8v*>(xp + (size_t)(j * 16 + l) * C);
+        const us8v vb = *reinterpret_cast<const us8v*>(xp + (size_t)(j * 16 + 8 + l) * C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x0 = xbf2f(va[e]), x1 = xbf2f(vb[e]);
+            const float d0 = x0 - a[e].m1, d1 = x1 - bb[e].m1;
+            a[e].m1 = fmaf(d0, cj, a[e].m1); bb[e].m1 = fmaf(d1, cj, bb[e].m1);
+            const float e0 = x0 - a[e].m1, e1 = x1 - bb[e].m1;
+            a[e].m2 = fmaf(d0, e0, a[e].m2); bb[e].m2 = fmaf(d1, e1, bb[e].m2);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        Mom* o = raw + (((size_t)b * C + c0 + e) * NC + ic) * 16;          // (b C + g D + d) NC + ic = (b G + g) m + (d NC + ic)
+        o[l] = a[e]; o[8 + l] = bb[e];
+    }
+}
+
+// Pass 1r, any H*W % 16 == 0: element e of the group's NCHW sequence is channel e / HW, pixel e % HW.  One thread = (chunk, half, lane).
+__global__ __launch_bounds__(256) void xgn_gather_kernel(const unsigned short* __restrict__ x, Mom* __restrict__ raw, int HW, int C, int G, int m, long nvec, long total)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int l = (int)(t & 7), half = (int)((t >> 3) & 1);
+    const long ch = t >> 4;                                   // (b G + g) m + chunk
+    const int gi = (int)(ch % m);
+    const long bg = ch / m;
+    const int g = (int)(bg % G), D = C / G;
+    const long b = bg / G;
+    const long left = nvec - 16L * gi;
+    const int m0 = left < 16 ? (int)left : 16;
+    const unsigned short* xp = x + (size_t)b * HW * C + g * D;
+    Mom a = Mom{0.f, 0.f};
+    for (int j = 0; j < m0; ++j) {
+        const long e = 256L * gi + 16 * j + 8 * half + l;
+        const int d = (int)(e / HW), px = (int)(e - (long)d * HW);
+        const float cj = 1.0f / (float)(j + 1);
+        const float x0 = xbf2f(xp[(size_t)px * C + d]);
+        const float d0 = x0 - a.m1;
+        a.m1 = fmaf(d0, cj, a.m1);
+        a.m2 = fmaf(d0, x0 - a.m1, a.m2);
+    }
+    raw[t] = a;
+}
+
+// Pass 2r.  One thread = one fp32 lane of one (image, group): ATen's chunk loop on the stored half-moments, then as xgn_finish_kernel.
+__global__ void xgn_finish_raw_kernel(const Mom* __restrict__ raw, const unsigned short* __restrict__ gamma, const unsigned short* __restrict__ beta,
+                                      float* __restrict__ scale, float* __restrict__ bias, float* __restrict__ stats, int BG, int C, int G, int m, long nvec, int HW, double eps)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int grp = t >> 3, l = t & 7;
+    if (grp >= BG) return;
+    const int b = grp / G, g = grp % G, D = C / G;
+    int depth = 0;
+    while ((1 << depth) < m) ++depth;
+    constexpr int MAXD = 10;                    // m <= 512 chunks
+    Mom stk[MAXD];
+    int m0s[MAXD];
+#pragma unroll
+    for (int v = 0; v < MAXD; ++v) { stk[v] = Mom{0.f, 0.f}; m0s[v] = 0; }
+    const Mom* rp = raw + (size_t)grp * m * 16 + l;
+    for (int q = 0; q < m; ++q) {
+        const long left = nvec - 16L * q;
+        const int m0 = left < 16 ? (int)left : 16;
+        add_moments_vec(m0, rp[(size_t)q * 16], m0s[0], stk[0]);
+        add_moments_vec(m0, rp[(size_t)q * 16 + 8], m0s[0], stk[0]);
+        int mask = q + 1;
+        bool go = true;
+#pragma unroll
+        for (int j = 1; j < MAXD; ++j) {
+            go = go && j < depth && (mask & 1) == 0;
+            if (go) {
+                add_moments_vec(m0s[j - 1], stk[j - 1], m0s[j], stk[j]);
+                m0s[j - 1] = 0; stk[j - 1] = Mom{0.f, 0.f};
+                mask >>= 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 1; j < MAXD; ++j)
+        if (j < depth) add_moments_vec(m0s[j], stk[j], m0s[0], stk[0]);
     float m1 = 0.f, m2 = 0.f;
     int m0 = 0;
     const int m0_add = m0s[0];
@@ -534,39 +661,39 @@ __global__ void xexpf_kernel(const float* __restrict__ x, float* __restrict__ y,
     if (i < n) y[i] = xexpf_glibc(x[i]);
 }
 
-// s [B*T][T] fp32 scaled scores -> p [B*T][T] bf16 un-normalised probabilities (block 0 relative to its own maximum, block 1 relative
-// to the running maximum), rescale [B*T] = expf(max0 - max1), rowscale [B*T] = 1 / sum.  T = 1024: two kv blocks of 512.
-// 16 lanes per (row, block): lane = key mod 16 sums its 32 probabilities sequentially, then the 8 / 4 / 2 / 1 fold of vec_reduce_all.
+// s [B*T][T] fp32 scaled scores -> p [B*T][T] bf16 un-normalised probabilities (every kv block of 512 keys relative to the running maximum
+// after that block), rescale [nblk][B*T] = expf(old max - new max) at each block (block 0: 0), rowscale [B*T] = 1 / sum.  T % 16 == 0, T <= 512 nblk.
+// 16 lanes per row: lane = key mod 16 sums its <= 32 probabilities of a block sequentially, then the 8 / 4 / 2 / 1 fold of vec_reduce_all;
+// sum = fma(exp_tmp, old sum, block sum) (ATen cpu_flash_attention, kvSplitSize 512; oracle/vae_exact.c vx_attention).
 __global__ __launch_bounds__(256) void xattn_softmax_kernel(const float* __restrict__ s, unsigned short* __restrict__ p, float* __restrict__ rescale,
                                                             float* __restrict__ rowscale, long rows, int T)
 {
-    const int sub = threadIdx.x >> 4, l = threadIdx.x & 15;          // 16 (row, block) pairs per workgroup
-    const long row = (long)blockIdx.x * 8 + (sub >> 1);
-    const int blk = sub & 1;
+    const int l = threadIdx.x & 15;
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (row >= rows) return;
-    const float* sr = s + (size_t)row * T + blk * 512;
-    float v[32];
-    float bm = -__builtin_inff();
+    float m_old = -__builtin_inff(), sum_old = 0.f;
+    for (int n0 = 0, blk = 0; n0 < T; n0 += 512, ++blk) {
+        const int cnt = (T - n0 < 512 ? T - n0 : 512) >> 4;
+        const float* sr = s + (size_t)row * T + n0;
+        unsigned short* pr = p + (size_t)row * T + n0;
+        float v[32];
+        float bm = -__builtin_inff();
 #pragma unroll
-    for (int k = 0; k < 32; ++k) { v[k] = sr[16 * k + l]; bm = fmaxf(bm, v[k]); }
+        for (int k = 0; k < 32; ++k) { v[k] = k < cnt ? sr[16 * k + l] : -__builtin_inff(); bm = fmaxf(bm, v[k]); }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o, WAVE));
-    const float m0 = __shfl(bm, (threadIdx.x & 63 & ~31), WAVE);           // block 0's maximum of this row (lanes 0..15 of the 32)
-    const float m_new = blk ? fmaxf(m0, bm) : bm;
-    float acc = 0.f;
-    unsigned short* pr = p + (size_t)row * T + blk * 512;
+        for (int o = 8; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o, WAVE));
+        const float m_new = fmaxf(m_old, bm);
+        float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) { const float e = xfexp_u20(v[k] - m_new); acc += e; pr[16 * k + l] = xf2bf(e); }
+        for (int k = 0; k < 32; ++k) if (k < cnt) { const float e = xfexp_u20(v[k] - m_new); acc += e; pr[16 * k + l] = xf2bf(e); }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) acc = acc + __shfl_xor(acc, o, WAVE);
-    const float sum0 = __shfl(acc, (threadIdx.x & 63 & ~31), WAVE);
-    if (blk == 1 && l == 0) {
-        // block 0: exp_tmp = expf(-inf - m0) = 0, sum = fma(0, 0, sum0) = sum0; block 1:
-        const float exp_tmp = xexpf_glibc(m0 - m_new);
-        const float sum = fmaf(exp_tmp, sum0, acc);
-        rescale[row] = exp_tmp;
-        rowscale[row] = 1.0f / sum;
+        for (int o = 8; o > 0; o >>= 1) acc = acc + __shfl_xor(acc, o, WAVE);
+        const float exp_tmp = xexpf_glibc(m_old - m_new);          // block 0: expf(-inf) = 0
+        sum_old = fmaf(exp_tmp, sum_old, acc);
+        m_old = m_new;
+        if (l == 0) rescale[(size_t)blk * rows + row] = exp_tmp;
     }
+    if (l == 0) rowscale[row] = 1.0f / sum_old;
 }
 
 // v [B][T][C] -> vt [B][C][T] (bf16): the P V product reads V as [output channel][key]
@@ -580,14 +707,18 @@ __global__ void xtranspose_kernel(const unsigned short* __restrict__ v, unsigned
     for (int r = ty; r < 32; r += 8) vt[((size_t)b * C + c0 + r) * T + t0 + tx] = tile[tx][r];
 }
 
-static int launch_xconv(const XConvArgs& a, long P, int nz, bool partial, hipStream_t stream)
+static int launch_xconv(XConvArgs a, long P, int nz, bool partial, hipStream_t stream)
 {
+    a.P = P;
     if (a.OC % 128 == 0) {
-        dim3 grid((unsigned)(P / 64), a.OC / 128, nz);
+        dim3 grid((unsigned)((P + 63) / 64), a.OC / 128, nz);
         if (partial) hipLaunchKernelGGL((xconv_kernel<2, 2, 2, true>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((xconv_kernel<2, 2, 2, false>), grid, dim3(256), 0, stream, a);
+    } else if (a.OC % 64 == 0 && !partial) {                 // the scores of a 1600-token attention: 1600 keys = 25 x 64
+        dim3 grid((unsigned)((P + 63) / 64), a.OC / 64, nz);
+        hipLaunchKernelGGL((xconv_kernel<1, 2, 2, false>), grid, dim3(256), 0, stream, a);
     } else {
-        dim3 grid((unsigned)(P / 128), a.OC / 32, nz);
+        dim3 grid((unsigned)((P + 127) / 128), a.OC / 32, nz);
         if (partial) hipLaunchKernelGGL((xconv_kernel<1, 4, 1, true>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((xconv_kernel<1, 4, 1, false>), grid, dim3(256), 0, stream, a);
     }
@@ -618,8 +749,8 @@ int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const
     const int up = (order & SELFTOK_VX_UPSAMPLE2X) ? 1 : 0;
     order &= ~SELFTOK_VX_UPSAMPLE2X;
     if (up && (stride != 1 || ((H | W) & 1))) { set_last_error("vx_conv2d: SELFTOK_VX_UPSAMPLE2X needs stride 1 and even H, W (the upsampled size)"); return SELFTOK_EINVAL; }
-    if ((order != 0 && order != 3) || Cin % 32 || ldx != Cin || Cout % 32 || P % 128 || (stride == 2 && ((H | W) & 1))) {
-        set_last_error("vx_conv2d: need Cin % 32 == 0, Cout % 32 == 0, B*Ho*Wo % 128 == 0, order 0 / 2 / 3"); return SELFTOK_EINVAL;
+    if ((order != 0 && order != 3) || Cin % 32 || ldx != Cin || Cout % 32 || (stride == 2 && ((H | W) & 1))) {
+        set_last_error("vx_conv2d: need Cin % 32 == 0, Cout % 32 == 0, order 0 / 2 / 3"); return SELFTOK_EINVAL;
     }
     XConvArgs a{};
     a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.bias = (const unsigned short*)bias; a.res = (const unsigned short*)residual; a.y = out;
@@ -628,34 +759,60 @@ int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const
     return launch_xconv(a, P, 1, order == 3, stream);
 }
 
+// pass-1 plan of the exact GroupNorm: chunks of 256 elements per channel (nc); NCH = 16 / 4 / 2 aligned chunks pre-combined per thread when nc is
+// a multiple (H*W % 512 == 0), else 0 = the raw route
+static int xgn_plan(int HW) { if (HW % 256) return 0; const int nc = HW / 256; return nc % 16 == 0 ? 16 : (nc % 4 == 0 ? 4 : (nc % 2 == 0 ? 2 : 0)); }
+
 size_t selftok_vx_groupnorm_workspace_bytes(int B, int HW, int C)
 {
-    const int RP = HW >= 4096 ? 4096 : 1024;
-    if (B <= 0 || HW % RP || C % 128) return 0;
-    return (size_t)B * C * (HW / RP) * 8 * sizeof(Mom) + (size_t)2 * B * C * sizeof(float);
+    if (B <= 0 || HW <= 0 || HW % 16 || C % 128) return 0;
+    const int nch = xgn_plan(HW);
+    const size_t moms = nch ? (size_t)B * C * (HW / (256 * nch)) * 8 : ((size_t)B * C * HW / 256 + (size_t)B * C) * 16;        // raw: m <= D HW / 256 + 1 chunks per group
+    return moms * sizeof(Mom) + (size_t)2 * B * C * sizeof(float);
 }
 
 int selftok_vx_groupnorm_bf16(const void* x, const void* gamma, const void* beta, void* out, void* workspace, const void* silu_table, float* stats, int B, int HW,
                               int C, int groups, double eps, hipStream_t stream)
 {
     if (B == 0) return SELFTOK_OK;
-    const int RP = HW >= 4096 ? 4096 : 1024;
-    if (!x || !gamma || !beta || !out || !workspace || B < 0 || groups <= 0 || C % groups || C % 128 || HW % RP || (C / groups) & ((C / groups) - 1) || ((HW / RP) & (HW / RP - 1))) {
-        set_last_error("vx_groupnorm: need C % 128 == 0, H*W a multiple of 1024 (of 4096 above 4096), power-of-two channels per group and ranges"); return SELFTOK_EINVAL;
+    if (!x || !gamma || !beta || !out || !workspace || B < 0 || groups <= 0 || C % groups || C % 128 || HW <= 0 || HW % 16 || (C / groups) & ((C / groups) - 1)) {
+        set_last_error("vx_groupnorm: need C % 128 == 0, H*W % 16 == 0, power-of-two channels per group"); return SELFTOK_EINVAL;
     }
-    const int R = HW / RP;
+    const int nch = xgn_plan(HW), D = C / groups, BG = B * groups;
+    const size_t moms = nch ? (size_t)B * C * (HW / (256 * nch)) * 8 : ((size_t)B * C * HW / 256 + (size_t)B * C) * 16;
     Mom* nodes = (Mom*)workspace;
-    float* scale = (float*)((char*)workspace + (size_t)B * C * R * 8 * sizeof(Mom));
+    float* scale = (float*)((char*)workspace + moms * sizeof(Mom));
     float* bias = scale + (size_t)B * C;
-    dim3 grid(R, C / 128, B);
-    if (RP == 4096) hipLaunchKernelGGL((xgn_partial_kernel<16>), grid, dim3(128), 0, stream, (const unsigned short*)x, nodes, HW, C, R);
-    else hipLaunchKernelGGL((xgn_partial_kernel<4>), grid, dim3(128), 0, stream, (const unsigned short*)x, nodes, HW, C, R);
-    int rc = check_launch("xgn_partial_kernel");
-    if (rc) return rc;
-    const int BG = B * groups;
-    hipLaunchKernelGGL(xgn_finish_kernel, dim3((BG * 8 + 63) / 64), dim3(64), 0, stream, nodes, (const unsigned short*)gamma, (const unsigned short*)beta, scale, bias, stats,
-                       BG, C, groups, R, HW, RP / 8, eps);
-    rc = check_launch("xgn_finish_kernel");
+    int rc;
+    if (nch) {
+        const int R = HW / (256 * nch);
+        if ((long)D * R > 512) { set_last_error("vx_groupnorm: more than 512 nodes per group"); return SELFTOK_EINVAL; }
+        dim3 grid(R, C / 128, B);
+        if (nch == 16) hipLaunchKernelGGL((xgn_partial_kernel<16>), grid, dim3(128), 0, stream, (const unsigned short*)x, nodes, HW, C, R);
+        else if (nch == 4) hipLaunchKernelGGL((xgn_partial_kernel<4>), grid, dim3(128), 0, stream, (const unsigned short*)x, nodes, HW, C, R);
+        else hipLaunchKernelGGL((xgn_partial_kernel<2>), grid, dim3(128), 0, stream, (const unsigned short*)x, nodes, HW, C, R);
+        rc = check_launch("xgn_partial_kernel");
+        if (rc) return rc;
+        hipLaunchKernelGGL(xgn_finish_kernel, dim3((BG * 8 + 63) / 64), dim3(64), 0, stream, nodes, (const unsigned short*)gamma, (const unsigned short*)beta, scale, bias, stats,
+                           BG, C, groups, R, HW, 32 * nch, eps);
+        rc = check_launch("xgn_finish_kernel");
+    } else {
+        const long nvec = (long)D * HW / 16;
+        const int m = (int)((nvec + 15) / 16);
+        if (m > 512) { set_last_error("vx_groupnorm: more than 512 chunks per group on the raw route"); return SELFTOK_EINVAL; }
+        if (HW % 256 == 0) {
+            hipLaunchKernelGGL(xgn_chunk_kernel, dim3(HW / 256, C / 128, B), dim3(128), 0, stream, (const unsigned short*)x, nodes, HW, C, HW / 256);
+            rc = check_launch("xgn_chunk_kernel");
+        } else {
+            const long total = (long)BG * m * 16;
+            hipLaunchKernelGGL(xgn_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const unsigned short*)x, nodes, HW, C, groups, m, nvec, total);
+            rc = check_launch("xgn_gather_kernel");
+        }
+        if (rc) return rc;
+        hipLaunchKernelGGL(xgn_finish_raw_kernel, dim3((BG * 8 + 63) / 64), dim3(64), 0, stream, nodes, (const unsigned short*)gamma, (const unsigned short*)beta, scale, bias, stats,
+                           BG, C, groups, m, nvec, HW, eps);
+        rc = check_launch("xgn_finish_raw_kernel");
+    }
     if (rc) return rc;
     const long n8 = (long)B * HW * C / 8;
     hipLaunchKernelGGL(xgn_apply_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, (const unsigned short*)x, scale, bias, (const unsigned short*)silu_table,
@@ -672,21 +829,24 @@ int selftok_vx_silu_table_bf16(void* table, hipStream_t stream)
 
 size_t selftok_vx_attention_workspace_bytes(int B, int T, int C)
 {
-    if (B <= 0) return 0;
-    return (size_t)B * T * T * 4 + (size_t)B * T * T * 2 + (size_t)B * T * C * 2 + (size_t)2 * B * T * 4;
+    if (B <= 0 || T <= 0) return 0;
+    const size_t nblk = (size_t)(T + 511) / 512;
+    return (size_t)B * T * T * 4 + (size_t)B * T * T * 2 + (size_t)B * T * C * 2 + (nblk + 1) * B * T * 4;
 }
 
 int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void* out, void* workspace, int B, int T, int C, hipStream_t stream)
 {
     if (B == 0) return SELFTOK_OK;
-    if (!q || !k || !v || !out || !workspace || B < 0 || T != 1024 || C % 128 || C > 4096) {
-        set_last_error("vx_attention: one head, T == 1024 (two kv blocks of 512, the SD3 VAE at 256 x 256), C % 128 == 0"); return SELFTOK_EINVAL;
+    if (!q || !k || !v || !out || !workspace || B < 0 || T <= 0 || T % 32 || C % 128 || C > 4096) {
+        set_last_error("vx_attention: one head, T % 32 == 0 (kv blocks of 512 keys, the last one shorter; 256 / 1024 / 1600 tokens = the SD3 VAE at 128 / 256 / 320 px), C % 128 == 0");
+        return SELFTOK_EINVAL;
     }
+    const int nblk = (T + 511) / 512;
     float* s = (float*)workspace;
     unsigned short* p = (unsigned short*)((char*)workspace + (size_t)B * T * T * 4);
     unsigned short* vt = p + (size_t)B * T * T;
-    float* rescale = (float*)(vt + (size_t)B * T * C);
-    float* rowscale = rescale + (size_t)B * T;
+    float* rescale = (float*)(vt + (size_t)B * T * C);               // [nblk][B * T]
+    float* rowscale = rescale + (size_t)nblk * B * T;
     XConvArgs a{};
     // scores: rows = queries (per image), "output channels" = keys; fp32 C * 1/sqrt(C)
     a.x = (const unsigned short*)q; a.w = (const unsigned short*)k; a.y = s; a.H = 1; a.W = T; a.IC = C; a.OC = T; a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.OH = 1; a.OW = T;
@@ -694,16 +854,16 @@ int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void*
     a.x_bs = (long)T * C; a.w_bs = (long)T * C; a.y_bs = (long)T * T; a.v_bs = T;
     int rc = launch_xconv(a, T, B, false, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(xattn_softmax_kernel, dim3((unsigned)((long)B * T / 8)), dim3(256), 0, stream, s, p, rescale, rowscale, (long)B * T, T);
+    hipLaunchKernelGGL(xattn_softmax_kernel, dim3((unsigned)(((long)B * T + 15) / 16)), dim3(256), 0, stream, s, p, rescale, rowscale, (long)B * T, T);
     rc = check_launch("xattn_softmax_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(xtranspose_kernel, dim3(T / 32, C / 32, B), dim3(256), 0, stream, (const unsigned short*)v, vt, T, C);
     rc = check_launch("xtranspose_kernel");
     if (rc) return rc;
-    // P V: rows = queries, reduction over the 1024 keys in 32 chunks; C *= rescale before chunk 16; bf16(C * 1/sum)
+    // P V: rows = queries, reduction over the keys in chunks of 32; C *= rescale[block] before chunk 16 * block; bf16(C * 1/sum)
     XConvArgs g{};
     g.x = p; g.w = vt; g.y = out; g.H = 1; g.W = T; g.IC = T; g.OC = C; g.KH = g.KW = 1; g.stride = 1; g.pad = 0; g.OH = 1; g.OW = T;
-    g.rescale = rescale; g.rowscale = rowscale; g.split = 16; g.mode = 2;
+    g.rescale = nblk > 1 ? rescale : nullptr; g.rs_stride = (long)B * T; g.rowscale = rowscale; g.split = 16; g.mode = 2;
     g.x_bs = (long)T * T; g.w_bs = (long)C * T; g.y_bs = (long)T * C; g.v_bs = T;
     return launch_xconv(g, T, B, false, stream);
 }

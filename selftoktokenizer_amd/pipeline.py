@@ -230,7 +230,7 @@ class SelftokPipeline():
 
         vsd = vae_state_dict if vae_state_dict is not None else W.load_vae_checkpoint(sd3_path)
         W.check_vae_state_dict(vsd)
-        self.vae = AutoencoderKLGPU(vsd, self.device, dtype, mode=vae_mode or ("exact" if int(self.datasize) == 256 else "parity"))
+        self.vae = AutoencoderKLGPU(vsd, self.device, dtype, mode=vae_mode or ("exact" if int(self.datasize) in AutoencoderKLGPU.EXACT_SIZES else "parity"))
 
         self.verbose = verbose
         self._say("Loading all...")

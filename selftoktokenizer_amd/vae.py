@@ -186,7 +186,7 @@ class AutoencoderKLGPU(ModuleSurface):
         ATen's statistics, the four projections as 1x1 convolutions in oneDNN's chunk order, the attention as ATen's flash kernel
         evaluates it (T = 1024 tokens: the VAE at 256 x 256).  Other token counts keep the torch-op formulation of `_attn_tokens`."""
         B, H, W, C = x.shape
-        if H * W != 1024 or not self.xw:
+        if not self.xw or (H * W != 1024 and not (self.mode == "exact" and (H * W) % 32 == 0)):
             h = self._n_gn(p + ".group_norm", x, act=False).reshape(B, H * W, C)
             return x + self._attn_tokens(p, h).reshape(B, H, W, C)
         n = self._x_gn(p + ".group_norm", x, act=False)
@@ -210,18 +210,28 @@ class AutoencoderKLGPU(ModuleSurface):
         return h.permute(0, 3, 1, 2).contiguous()
 
     # ---- exact-order encoder (mode 'exact'): every reduction in the reference's torch-CPU order -------------------------------------
+    EXACT_SIZES = (128, 256, 320)          # square image sizes whose every layer shape was probed against oneDNN (tools/probe_cpu_bf16/) and has goldens
+
     @staticmethod
-    def _x_order(cin: int, stride: int) -> int:
-        """the chunk order oneDNN's AMX convolution kernel uses for this layer of the encoder at 256 x 256 (probed per layer shape,
-        tools/probe_cpu_bf16/; include/selftok_hip.h): conv_in is one 27-element chunk; the 128- and 256-channel Downsample layers run
-        channel-block major with private partial sums; everything else (kh, kw, channel-block)"""
+    def _x_order(cin: int, stride: int, width: int) -> int:
+        """the chunk order oneDNN's AMX convolution kernel uses for a layer of the VAE (probed per layer shape at 128 / 256 / 320 px,
+        tools/probe_cpu_bf16/, profiles/r5_cpu_bf16_resolution_orders.txt; include/selftok_hip.h): conv_in is one 27-element chunk; a stride-2
+        (Downsample) layer whose INPUT is at least 102 pixels wide runs channel-block major with private partial sums -- whatever its height,
+        batch and channel count (at 256 px: the 128- and 256-channel ones; at 128 px only the first; at 320 px the same two as at 256);
+        everything else, and every layer of the decoder, (kh, kw, channel-block)"""
         if cin < 32:
             return 2
-        return 3 if (stride == 2 and cin in (128, 256)) else 0
+        return 3 if (stride == 2 and width >= 102) else 0
+
+    @classmethod
+    def _x_check_size(cls, h: int, w: int):
+        if h != w or h not in cls.EXACT_SIZES:
+            raise NotImplementedError(f"vae_mode='exact' reproduces oneDNN's summation orders as probed for the VAE's layer shapes at {cls.EXACT_SIZES} px square "
+                                      f"images (got {h} x {w}); use vae_mode='parity' for other sizes")
 
     def _x_conv(self, name, x, stride=1, residual=None, upsample=False, bias=None):
         w = self.xw[name]
-        order = 0 if name.startswith("decoder.") else self._x_order(w.shape[3], stride)       # every decoder layer: (kh, kw, channel-block) chunks
+        order = 0 if name.startswith("decoder.") else self._x_order(w.shape[3], stride, x.shape[2])       # every decoder layer: (kh, kw, channel-block) chunks
         return ops.vx_conv2d(x, w, self.w[name + ".bias"] if bias is None else bias, stride=stride, residual=residual, order=order, upsample=upsample)
 
     def _x_gn(self, name, x, act=True):
@@ -233,9 +243,7 @@ class AutoencoderKLGPU(ModuleSurface):
         return self._x_conv(p + ".conv2", self._x_gn(p + ".norm2", h), residual=sc)
 
     def _x_encode_moments(self, img):
-        if tuple(img.shape[-2:]) != (256, 256):
-            raise NotImplementedError("vae_mode='exact' reproduces oneDNN's summation orders as probed for the encoder's layer shapes at 256 x 256; "
-                                      "use vae_mode='parity' for other resolutions")
+        self._x_check_size(int(img.shape[-2]), int(img.shape[-1]))
         x = img.to(self.device, self.dtype).permute(0, 2, 3, 1)
         h = F.pad(x, (0, 8 - x.shape[-1])).contiguous()                                # 3 -> 8 channels: 16-byte pixels
         h = self._x_conv("encoder.conv_in", h)
@@ -253,9 +261,7 @@ class AutoencoderKLGPU(ModuleSurface):
     def _x_decode(self, z):
         """`VAEDecoder.forward` (sd3_impls.py:427-444) with every reduction in the reference's torch-CPU order (round 5): pixels equal the
         reference's decode of the same latents bit for bit (tests/golden/decode_b16.npz, vae_b1.npz; CPU twin oracle/vae_exact.py decode)"""
-        if tuple(z.shape[-2:]) != (32, 32):
-            raise NotImplementedError("vae_mode='exact' reproduces oneDNN's summation orders as probed for the decoder's layer shapes at 256 x 256; "
-                                      "use vae_mode='parity' for other resolutions")
+        self._x_check_size(8 * int(z.shape[-2]), 8 * int(z.shape[-1]))
         h = z.to(self.device, self.dtype).permute(0, 2, 3, 1)
         h = F.pad(h, (0, 32 - h.shape[-1])).contiguous()                               # 16 -> 32 channels (zeros): one chunk per tap
         h = self._x_conv("decoder.conv_in", h)
@@ -386,7 +392,7 @@ class AutoencoderKLGPU(ModuleSurface):
 
     @torch.no_grad()
     def decode(self, z, return_dict=False):
-        if self.mode == "exact" and tuple(z.shape[-2:]) == (32, 32):
+        if self.mode == "exact":
             return (self._x_decode(z),)
         if self.mode in ("parity", "exact"):
             return (self._n_decode(z),)

@@ -77,6 +77,33 @@ def test_groupnorm_equals_aten(B, Cn, H):
     assert int((act != _nhwc_bits(F.silu(ref))).sum()) == 0
 
 
+# ---- other image sizes (round 5): oneDNN's order is a function of the layer's spatial size; ATen's GroupNorm / flash kernel at the new shapes ----
+SHAPES_RES = [("128 px down128 (128 wide: order 3)", 128, 128, 128, 3, 2), ("128 px down256 (64 wide: order 0)", 256, 256, 64, 3, 2),
+              ("width 100: order 0", 128, 128, 100, 3, 2), ("width 102: order 3", 128, 128, 102, 3, 2), ("128 px 512@16", 512, 512, 16, 3, 1),
+              ("320 px down512 (80 wide: order 0)", 512, 512, 80, 3, 2), ("320 px 512@40", 512, 512, 40, 3, 1), ("320 px conv_out", 512, 32, 40, 3, 1)]
+
+
+@needs_amx
+@pytest.mark.parametrize("name,cin,cout,H,k,stride", SHAPES_RES, ids=[s[0] for s in SHAPES_RES])
+def test_conv_order_equals_onednn_other_sizes(name, cin, cout, H, k, stride):
+    test_conv_order_equals_onednn(name, cin, cout, H, k, stride)
+
+
+@needs_amx
+@pytest.mark.parametrize("B,Cn,H", [(1, 256, 80), (2, 512, 40), (2, 512, 16), (1, 128, 160)])
+def test_groupnorm_equals_aten_other_sizes(B, Cn, H):
+    test_groupnorm_equals_aten(B, Cn, H)
+
+
+@needs_amx
+@pytest.mark.parametrize("T", [256, 1600])
+def test_attention_equals_aten_flash_kernel_other_token_counts(T):
+    q, k, v = _rand(0x31 + T, (1, 1, T, 512), 1.5), _rand(0x32 + T, (1, 1, T, 512), 1.5), _rand(0x33 + T, (1, 1, T, 512))
+    ref = F.scaled_dot_product_attention(q, k, v)
+    mine = VX.attention(VX.bf16_bits(q[:, 0]), VX.bf16_bits(k[:, 0]), VX.bf16_bits(v[:, 0]))
+    assert int((mine != VX.bf16_bits(ref[:, 0])).sum()) == 0
+
+
 def test_silu_table_is_torch_cpu_silu_and_the_flush_rule():
     tab = VX.silu_table()
     allb = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(torch.bfloat16)

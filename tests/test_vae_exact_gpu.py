@@ -40,7 +40,7 @@ def test_conv_exact_order(name, cin, cout, H, k, stride, order, B):
     x = _rand_bf16(0xC0 + cin + H, (B, H, H, cin), 1.3, 0.1)
     w = _rand_bf16(0xC1 + cout, (cout, k, k, cin), (1.0 / (cin * k * k)) ** 0.5)
     b = _rand_bf16(0xC2, (cout,), 0.1)
-    assert VX.conv_order(cin, k, stride) == order
+    assert VX.conv_order(cin, k, stride, H) == order
     Ho = H // stride
     res = _rand_bf16(0xC3, (B, Ho, Ho, cout)) if (k == 3 and stride == 1 and cin == cout) else None
     ref = VX.conv2d(_bits(x), _bits(w), _bits(b), stride=stride, pad=1 if (k == 3 and stride == 1) else 0, residual=None if res is None else _bits(res))
@@ -107,6 +107,52 @@ def test_attention_exact_order():
     ref = VX.attention(_bits(q), _bits(k), _bits(v))
     out = ops.vx_attention(q.cuda(), k.cuda(), v.cuda())
     _same(out, ref, "attention")
+
+
+# ---- other image sizes (round 5): the layer shapes of the VAE at 128 and 320 px -------------------------------------------------
+# oneDNN's chunk order is a function of the layer's spatial size (tools/probe_cpu_bf16/, profiles/r5_cpu_bf16_resolution_orders.txt): a stride-2
+# layer is channel-block major iff its input is >= 102 wide.  Row counts that are not a multiple of the kernel's 64 / 128-row tile (1600 = 40 x 40).
+CONVS_RES = [("128 px: Downsample 256 @64 -> order 0", 256, 256, 64, 3, 2, 0, 1), ("128 px: Downsample 128 @128", 128, 128, 128, 3, 2, 3, 1),
+             ("128 px: 512->512 @16", 512, 512, 16, 3, 1, 0, 1), ("128 px: conv_out 512->32 @16", 512, 32, 16, 3, 1, 0, 1),
+             ("320 px: Downsample 256 @160", 256, 256, 160, 3, 2, 3, 1), ("320 px: Downsample 512 @80 -> order 0", 512, 512, 80, 3, 2, 0, 1),
+             ("320 px: 512->512 @40, 1600 rows", 512, 512, 40, 3, 1, 0, 1), ("320 px: conv_out 512->32 @40, 1600 rows on 128-row tiles", 512, 32, 40, 3, 1, 0, 1),
+             ("320 px: 1x1 @40, 3 images = 4800 rows", 512, 512, 40, 1, 1, 0, 3), ("320 px: 128->128 @320", 128, 128, 320, 3, 1, 0, 1)]
+
+
+@pytest.mark.parametrize("name,cin,cout,H,k,stride,order,B", CONVS_RES, ids=[c[0] for c in CONVS_RES])
+def test_conv_exact_order_other_sizes(name, cin, cout, H, k, stride, order, B):
+    test_conv_exact_order(name, cin, cout, H, k, stride, order, B)
+
+
+def test_decoder_upsampling_conv_ragged_rows():
+    """nearest-2x input addressing at 20 -> 40 (1600 output rows per image)"""
+    x = _rand_bf16(0xC7, (1, 20, 20, 512), 1.3, 0.1)
+    w = _rand_bf16(0xC8, (512, 3, 3, 512), (1.0 / (512 * 9)) ** 0.5)
+    b = _rand_bf16(0xC9, (512,), 0.1)
+    ref = VX.conv2d(VX.upsample2x(_bits(x)), _bits(w), _bits(b), order=0)
+    out = ops.vx_conv2d(x.cuda(), w.cuda(), b.cuda(), order=0, upsample=True)
+    _same(out, ref, "upsampling conv 20 -> 40")
+
+
+# (B, C, H): the pass-1 routes of the exact GroupNorm -- aligned nodes of 16 / 4 / 2 chunks (H*W % 512 == 0; 25 ranges per channel at 320 / 160 px,
+# 400 nodes per group at C = 512), raw half-moments per chunk (an odd number of chunks per channel: 80 x 80, 16 x 16), gathered chunks that straddle
+# channel boundaries (40 x 40 = 6.25 chunks per channel)
+GN_RES = [(1, 128, 320), (1, 256, 160), (1, 512, 160), (1, 256, 320), (2, 512, 80), (1, 256, 80), (2, 512, 40), (3, 512, 16), (1, 128, 64), (1, 256, 48)]
+
+
+@pytest.mark.parametrize("B,C,H", GN_RES)
+def test_groupnorm_exact_other_sizes(B, C, H):
+    test_groupnorm_exact_statistics_and_output(B, C, H)
+
+
+@pytest.mark.parametrize("B,T", [(2, 256), (1, 1600), (1, 576), (1, 32)])
+def test_attention_exact_order_other_token_counts(B, T):
+    """one kv block of 256 (128 px); three of 512 and one of 64 (320 px: the running maximum / sum / accumulator rescaled at every block); 512 + 64"""
+    C = 512
+    q, k, v = (_rand_bf16(0xA4 + i + T, (B, T, C), 1.5 if i < 2 else 1.0) for i in range(3))
+    ref = VX.attention(_bits(q), _bits(k), _bits(v))
+    out = ops.vx_attention(q.cuda(), k.cuda(), v.cuda())
+    _same(out, ref, f"attention T={T}")
 
 
 def test_encoder_latents_equal_the_reference_pipeline_bit_for_bit():

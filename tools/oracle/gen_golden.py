@@ -493,6 +493,71 @@ def stage_decode16():
                         head=bits.reshape(16, -1)[:, :256].copy())
 
 
+def stage_res(R, B=16):
+    """The reference SelftokPipeline end to end at another image size (`datasize` = R, `enable_enc_variable_size`; models_ours.py:183-202,
+    SelftokPipeline.py:262) on B = 16 synthetic R x R images in one batch: VAE latents (bf16-exact), pre-quantizer features, ids, the 50-step
+    loop's final latents, a crc32 of every reconstructed image's bf16 pixels and its PSNR -- what `vae_mode='exact'`, `encoder_mode='exact'`
+    and `gemm='exact'` are checked against at 128 / 320 px."""
+    import zlib
+    H.install()
+    import mimogpt.infer.SelftokPipeline as SP
+    cfg = H.load_cfg(CFG_256)
+    SP.AutoencoderKL = _MirrorVAE
+    shapes = W.expected_shapes(512)
+    real_load = torch.load
+    torch.load = lambda *a, **k: W.synthetic_state_dict(shapes)
+    try:
+        with H.fast_init():
+            pipe = SP.SelftokPipeline(cfg=cfg, ckpt_path="synthetic", sd3_path="synthetic", datasize=R, device="cpu")
+    finally:
+        torch.load = real_load
+    images = synth.synthetic_images(B, size=R)
+    cap = {}
+    hk1 = pipe.model.encoder.register_forward_pre_hook(lambda m, args: cap.setdefault("x0", args[0].detach().clone()))
+    hk2 = pipe.model.encoder.quantizer.project_in.register_forward_hook(lambda m, i, o: cap.setdefault("z", o.detach().clone()))
+    t0 = time.time()
+    tokens = pipe.encoding(images, device="cpu")
+    hk1.remove(); hk2.remove()
+    print(f"[ref] encoding {R} px B={B} {time.time() - t0:.1f}s", flush=True)
+    x0, z = cap["x0"], cap["z"]
+    assert torch.equal(x0, x0.to(torch.bfloat16).float()) and tuple(x0.shape) == (B, 16, R // 8, R // 8)
+    sd = dict(pipe.model.state_dict())
+    cb = sd["encoder.quantizer._codebook.embed"][0]
+    xn = torch.nn.functional.normalize(z.reshape(-1, 16), dim=-1)
+    top2 = (xn @ cb.T).topk(2, dim=-1)
+    gap = (top2.values[:, 0] - top2.values[:, 1]).reshape(B, 512)
+    np.savez_compressed(os.path.join(GOLD, f"res{R}_b16.npz"), tokens=tokens.numpy().astype(np.int16), gap=gap.numpy(),
+                        x0_bf16=x0.to(torch.bfloat16).view(torch.int16).numpy(), z=z.numpy())          # the encode half first: the decode takes most of an hour
+    noise = synth.hash_normalish(0xA0 + R, (B, 16, R // 8, R // 8), "cpu")
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: noise.clone()
+    real_loop = pipe.flow.p_sample_loop
+
+    def loop(*a, **k):
+        cap["lat"] = real_loop(*a, **k)
+        return cap["lat"]
+    pipe.flow.p_sample_loop = loop
+    t0 = time.time()
+    try:
+        rec = pipe.decoding(tokens.numpy(), device="cpu")
+    finally:
+        torch.randn = real_randn
+        pipe.flow.p_sample_loop = real_loop
+    print(f"[ref] decoding {R} px B={B} {time.time() - t0:.1f}s", flush=True)
+    lat = cap["lat"].detach().float()
+    assert tuple(rec.shape) == (B, 3, R, R)
+    bits = rec.to(torch.bfloat16).contiguous().view(torch.int16).numpy().view(np.uint16)
+    assert torch.equal(rec.to(torch.bfloat16).float(), rec.float())                      # the pipeline's pixels are bf16 values
+    crc = np.array([zlib.crc32(np.ascontiguousarray(bits[i]).tobytes()) for i in range(B)], dtype=np.uint32)
+    orig = (images + 1.0) / 2.0
+    mse = ((rec.float() - orig) ** 2).reshape(B, -1).double().mean(dim=1)
+    psnr = (10.0 * torch.log10(1.0 / mse)).numpy()
+    report(f"res{R}", images=B, min_gap=float(gap.min()), psnr_ref_mean=float(psnr.mean()), pixel_mean=float(rec.float().mean()))
+    np.savez_compressed(os.path.join(GOLD, f"res{R}_b16.npz"), tokens=tokens.numpy().astype(np.int16), gap=gap.numpy(),
+                        x0_bf16=x0.to(torch.bfloat16).view(torch.int16).numpy(), z=z.numpy(), lat=lat.numpy(), crc=crc, psnr_ref=psnr,
+                        head=bits.reshape(B, -1)[:, :256].copy())
+
+
 def stage_config():
     """the hot-path keys of the reference's two shipped YAMLs (configs/res256/256-eval.yml, configs/renderer/renderer-eval.yml) as the REFERENCE's own
     `parse_args_from_yaml` (infer_utils.py:165-168) returns them: the values `selftoktokenizer_amd.config.default_config` must reproduce (VERDICT r4
@@ -896,7 +961,7 @@ def stage_rmsnorm_rotary():
     report("rmsnorm_rotary", arrays=sorted(out), rms_absmax=float(np.abs(out["rms_affine"]).max()), rot_absmax=float(np.abs(out["rot_full"]).max()))
 
 
-STAGES = dict(k1024_16=stage_k1024_16, cfg16=stage_cfg16, dit4=stage_dit4, config=stage_config, decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
+STAGES = dict(res128=lambda: stage_res(128), res320=lambda: stage_res(320), k1024_16=stage_k1024_16, cfg16=stage_cfg16, dit4=stage_dit4, config=stage_config, decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
               vae=stage_vae, pipeline=stage_pipeline, pipeline16=stage_pipeline16, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024, vqtrain=stage_vqtrain)
 
 if __name__ == "__main__":
