@@ -276,8 +276,10 @@ int selftok_groupnorm_silu_nhwc_bf16(const void* x, const void* weight, const vo
  * permuted, no packing), bias [Cout], out / residual [B, Ho, Wo, Cout].  ksize 3: padding 1; stride 2 (ksize 3) = Downsample's
  * F.pad(x, (0,1,0,1)) + stride-2 convolution.  residual: out = bf16(bf16(conv + bias) + residual).
  * order = the chunk order of oneDNN's kernel for that layer: 0: 32-channel chunks in (kh, kw, channel-block) order; 3: channel-block
- * major, every block's 9 taps summed privately and then added to the total (the 128- and 256-channel Downsample layers);
- * 2: conv_in (Cin = 3): one chunk of 27 elements in (kw, kh, ic) order.  Cin % 32 == 0, Cout % 32 == 0, B*Ho*Wo % 128 == 0 (orders 0, 3).
+ * major, every block's 9 taps summed privately and then added to the total (a stride-2 layer whose input is >= 102 pixels wide: the 128- and
+ * 256-channel Downsample layers at 256 and 320 px, the 128-channel one at 128 px -- oneDNN decides by the layer's width, whatever H, B, C);
+ * 2: conv_in (Cin = 3): one chunk of 27 elements in (kw, kh, ic) order.  Cin % 32 == 0, Cout % 32 == 0 (orders 0, 3); any row count
+ * B*Ho*Wo (the last 64- / 128-row tile may be ragged: 40 x 40 = 1600 rows).
  * order | SELFTOK_VX_UPSAMPLE2X (round 5, the decoder's Upsample: F.interpolate(nearest, x2) + 3x3 convolution, sd3_impls.py:308-311): x is
  * [B, H/2, W/2, Cin] in memory and is read as its nearest-2x upsampled view of size H x W (H, W even, stride 1).  The decoder's layers all
  * use order 0 (tools/probe_cpu_bf16/check_decoder_convs.py); its conv_in (16 channels: one 16-channel chunk per tap) and conv_out (3 output
@@ -288,14 +290,18 @@ int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const
 /* GroupNorm(groups, eps, affine) [+ SiLU] with ATen's statistics (Welford in 8 fp32 lanes over 16-element vectors, chunks of 16
  * vectors, binary cascade; elements in NCHW order) and y = bf16(fma(rstd * gamma, x, fma(-rstd * gamma, mean, beta))).
  * silu_table: 65536 bf16 entries from selftok_vx_silu_table_bf16, or NULL for no activation.  stats (may be NULL): [B, groups, 2] fp32
- * mean, rstd.  C % 128 == 0, H*W a multiple of 1024 (4096 above 4096), power-of-two channels per group. */
+ * mean, rstd.  C % 128 == 0, H*W % 16 == 0, power-of-two channels per group, at most 512 cascade nodes per group (every layer of the VAE at
+ * 128 / 256 / 320 px: 16 / 4 / 2 aligned chunks are pre-combined per thread where a channel holds a multiple of them, otherwise -- 80 x 80,
+ * 16 x 16: an odd number of chunks per channel; 40 x 40: chunks straddle channels -- every chunk's two half-moments are stored and the whole
+ * loop is replayed per group). */
 size_t selftok_vx_groupnorm_workspace_bytes(int B, int HW, int C);
 int selftok_vx_groupnorm_bf16(const void* x, const void* gamma, const void* beta, void* out, void* workspace, const void* silu_table, float* stats, int B, int HW,
                               int C, int groups, double eps, hipStream_t stream);
 /* torch-CPU's `SiLU` on every bf16 bit pattern (it is a function of the input alone): table[bits(x)] = bits(silu(x)). */
 int selftok_vx_silu_table_bf16(void* table, hipStream_t stream);
-/* AttnBlock's scaled_dot_product_attention (sd3_impls.py:274-284), one head of C channels over T = 1024 tokens, as ATen's CPU flash
- * kernel evaluates it: q, k, v, out [B, T, C] bf16. */
+/* AttnBlock's scaled_dot_product_attention (sd3_impls.py:274-284), one head of C channels over T tokens, as ATen's CPU flash kernel
+ * evaluates it (kv blocks of 512 keys, the last one shorter; running maximum / sum / accumulator rescaled at every block): q, k, v, out
+ * [B, T, C] bf16, T % 32 == 0 (256 / 1024 / 1600 tokens = the VAE at 128 / 256 / 320 px), C % 128 == 0. */
 size_t selftok_vx_attention_workspace_bytes(int B, int T, int C);
 int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void* out, void* workspace, int B, int T, int C, hipStream_t stream);
 /* glibc's expf (what `std::exp(float)` evaluates inside the flash kernel), element-wise; exposed for the parity tests. */

@@ -138,6 +138,43 @@ def test_pipeline_16_images_pixels_equal_the_reference_bit_for_bit():
     print("pixels of all 16 images equal the reference's; PSNR identical:", psnr[:4])
 
 
+@pytest.mark.parametrize("R", [128, 320])
+def test_pipeline_at_other_image_sizes_equals_the_reference_bit_for_bit(R):
+    """`datasize` = 128 / 320 (`enable_enc_variable_size`: cropped position embeddings, 64 / 400 image tokens; models_ours.py:183-202, SelftokPipeline.py:262):
+    the reference pipeline's own 16-image run at that size (tests/golden/res{R}_b16.npz, tools/oracle/gen_golden.py res{R}) -- VAE latents, ids from
+    pixels, the final latents of the 50-step loop, every image's pixels and PSNR EQUAL the reference's with the three exact modes.  oneDNN's chunk
+    order, ATen's GroupNorm cascade and the flash kernel's kv blocks all depend on the layer sizes: DESIGN.md section 15.9."""
+    from mimogpt.infer.SelftokPipeline import SelftokPipeline
+    from selftoktokenizer_amd import evaluate as E
+    g = np.load(os.path.join(GOLD, f"res{R}_b16.npz"))
+    sd = W.synthetic_state_dict(W.expected_shapes(512), device="cuda")
+    pipe = SelftokPipeline(default_config(512), None, None, datasize=R, device="cuda", state_dict=sd, vae_state_dict=W.synthetic_vae_state_dict(device="cuda"), verbose=False,
+                           gemm="exact")
+    assert pipe.vae.mode == "exact"
+    imgs = synth.synthetic_images(16, size=R, device="cuda")
+    x0 = pipe.encode_latents(imgs)
+    ref = torch.from_numpy(g["x0_bf16"]).view(torch.bfloat16).float()
+    bad = int((x0.cpu() != ref).sum())
+    assert bad == 0, f"{R} px: {bad} of {ref.numel()} VAE latent elements differ from the reference pipeline's"
+    ids = pipe.encoding(imgs)
+    flips = int((ids.cpu().numpy() != g["tokens"].astype(np.int64)).sum())
+    print(f"\n{R} px: VAE latents bit-equal; token ids from pixels vs the reference: {ids.numel() - flips} / {ids.numel()}")
+    assert flips == 0
+    assert torch.equal(pipe.encode_latents(imgs[5:6]), x0[5:6])                        # batch independent
+    if "lat" not in g.files:                                                           # the golden's decode half (an hour of CPU) is still being generated
+        pytest.skip(f"res{R}_b16.npz holds the encode half only")
+    noise = synth.hash_normalish(0xA0 + R, (16, 16, R // 8, R // 8), "cpu")
+    rec, lat = pipe.decoding(ids.cpu().numpy(), noise=noise, return_latent=True)
+    diff = int((lat.cpu() != torch.from_numpy(g["lat"])).sum())
+    print(f"{R} px: final latents after 50 exact-order steps: {diff} differing elements")
+    assert diff == 0
+    assert tuple(rec.shape) == (16, 3, R, R)
+    bits = rec.cpu().view(torch.int16).numpy().view(np.uint16)
+    crc = np.array([zlib.crc32(np.ascontiguousarray(bits[i]).tobytes()) for i in range(16)], dtype=np.uint32)
+    assert np.array_equal(crc, g["crc"]), f"{R} px: pixels differ from the reference's"
+    assert np.array_equal(E.psnr_each(rec, imgs), g["psnr_ref"])
+
+
 def test_guided_steps_16_images_equal_the_reference(models):
     """classifier-free guidance (sd3/rectified_flow.py:280-289: MMDiT.cfg_inference -- integer-floored timestep, no context key visible -- and the conditional
     call without context_see_xt, mixed as u + s (c - u)): the latents after one and two guided steps at B = 16 have the reference's crc32 (tests/golden/cfg_b16.npz)"""
