@@ -948,7 +948,7 @@ int selftok_vx_silu_table_bf16(void* table, hipStream_t s)
 size_t selftok_vx_attention_workspace_bytes(int B, int T, int C)
 {
     if (B <= 0 || T <= 0) return 0;
-    return (size_t)B * T * T * 4 + (size_t)B * T * T * 2 + (size_t)B * T * C * 2 + ((size_t)(T + 511) / 512 + 1) * B * T * 4;
+    return (size_t)B * T * T * 4 + (size_t)B * T * T * 2 + (size_t)B * T * C * 2 + ((size_t)(T + 511) / 512 + 1) * B * T * 4 + 512;
 }
 int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void* out, void* workspace, int B, int T, int C, hipStream_t s)
 {

@@ -71,7 +71,7 @@ struct XConvArgs {
 typedef float xf32x2 __attribute__((ext_vector_type(2)));
 
 template <int NT, int WM, int WN, bool PARTIAL>
-__global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
+__global__ __launch_bounds__(64 * WM * WN) void xconv_kernel(XConvArgs a)
 {
     // workgroup tile: RA = 32 WM pixel rows x RB = 32 NT WN output channels; one chunk = 32 bf16 channels of every row, staged as fp32:
     // round 5 -- the bf16 -> fp32 expansion happens ONCE per staged element (a shift / a mask on the packed pair, by the thread that copies it to
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
     // [16 even elements | 16 odd elements] so that a lane reads the 16 operands of ITS chain (block 0: even, block 1: odd) as four ds_read_b128.
     // fp32-input MFMAs and VALU instructions share the issue slot (tools/microbench/mfma_valu.hip: 0 / 4 / 9 VALU per MFMA -> 151 / 125 / 93 TF),
     // so the kernel's rate is set by the VALU instructions beside its MFMAs: 3.5 per MFMA before, 1.75 now (with the packed fold below).
-    constexpr int RA = 32 * WM, RB = 32 * NT * WN;
-    constexpr int NPA = (RA * 4 + 255) / 256, NPB = (RB * 4 + 255) / 256;          // 16-byte (8 x bf16) global pieces per thread
+    constexpr int RA = 32 * WM, RB = 32 * NT * WN, NTHR = 64 * WM * WN;
+    constexpr int NPA = (RA * 4 + NTHR - 1) / NTHR, NPB = (RB * 4 + NTHR - 1) / NTHR;          // 16-byte (8 x bf16) global pieces per thread
     __shared__ u32x4 lds[2][(RA + RB) * 8];                                        // 128 bytes per row: 8 pieces of 4 fp32
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
     bool aon[NPA];
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
-        const int idx = tid + 256 * j, row = idx >> 2, q = idx & 3;
+        const int idx = tid + NTHR * j, row = idx >> 2, q = idx & 3;
         aon[j] = idx < RA * 4 && pwg + row < a.P;
         const long pa = pwg + (aon[j] ? row : 0);
         const int ohw = a.OH * a.OW;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
     bool bon[NPB];
 #pragma unroll
     for (int j = 0; j < NPB; ++j) {
-        const int idx = tid + 256 * j, row = idx >> 2, q = idx & 3;
+        const int idx = tid + NTHR * j, row = idx >> 2, q = idx & 3;
         bon[j] = idx < RB * 4;
         brow[j] = w + (size_t)(nwg + (bon[j] ? row : 0)) * KT * IC + q * 8;
         bsw[j] = ((RA + row) >> 1) & 7;
@@ -213,11 +213,13 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs a)
         const bool more = c + 1 < nchunks;
         if (more) fetch();                                       // the next chunk's 12 KB are in flight during this chunk's MFMAs
         if (a.rescale != nullptr && c > 0 && c % a.split == 0) {  // the flash kernel's `dst *= exp(old max - new max)` when a new kv block starts
-            const float* rs = a.rescale + (size_t)(c / a.split) * a.rs_stride + (size_t)z * a.v_bs;
+            // rows beyond P of a ragged last tile read past their image's entries: the next image's, the next block's or the row-scale array's
+            // (the workspace carries 128 floats of slack behind it) -- their products are never stored.  No clamp: a loop-invariant min() per
+            // accumulator row is hoisted out of the chunk loop into 30 live registers (152 -> 182 VGPRs, one wave per SIMD less).
+            const float* rs = a.rescale + (size_t)(c / a.split) * a.rs_stride + (size_t)z * a.v_bs + p0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long pr = p0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float f = rs[pr < a.P ? pr : a.P - 1];
+                const float f = rs[(r & 3) + 8 * (r >> 2) + 4 * h];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) C[t][r] = C[t][r] * f;
             }
@@ -710,10 +712,13 @@ __global__ void xtranspose_kernel(const unsigned short* __restrict__ v, unsigned
 static int launch_xconv(XConvArgs a, long P, int nz, bool partial, hipStream_t stream)
 {
     a.P = P;
+#ifndef XCONV_WM
+#define XCONV_WM 2
+#endif
     if (a.OC % 128 == 0) {
-        dim3 grid((unsigned)((P + 63) / 64), a.OC / 128, nz);
-        if (partial) hipLaunchKernelGGL((xconv_kernel<2, 2, 2, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((xconv_kernel<2, 2, 2, false>), grid, dim3(256), 0, stream, a);
+        dim3 grid((unsigned)((P + 32 * XCONV_WM - 1) / (32 * XCONV_WM)), a.OC / 128, nz);
+        if (partial) hipLaunchKernelGGL((xconv_kernel<2, XCONV_WM, 2, true>), grid, dim3(128 * XCONV_WM), 0, stream, a);
+        else hipLaunchKernelGGL((xconv_kernel<2, XCONV_WM, 2, false>), grid, dim3(128 * XCONV_WM), 0, stream, a);
     } else if (a.OC % 64 == 0 && !partial) {                 // the scores of a 1600-token attention: 1600 keys = 25 x 64
         dim3 grid((unsigned)((P + 63) / 64), a.OC / 64, nz);
         hipLaunchKernelGGL((xconv_kernel<1, 2, 2, false>), grid, dim3(256), 0, stream, a);
@@ -831,7 +836,7 @@ size_t selftok_vx_attention_workspace_bytes(int B, int T, int C)
 {
     if (B <= 0 || T <= 0) return 0;
     const size_t nblk = (size_t)(T + 511) / 512;
-    return (size_t)B * T * T * 4 + (size_t)B * T * T * 2 + (size_t)B * T * C * 2 + (nblk + 1) * B * T * 4;
+    return (size_t)B * T * T * 4 + (size_t)B * T * T * 2 + (size_t)B * T * C * 2 + (nblk + 1) * B * T * 4 + 512;          // + 128 floats of slack: see the rescale read of xconv_kernel
 }
 
 int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void* out, void* workspace, int B, int T, int C, hipStream_t stream)
