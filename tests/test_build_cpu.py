@@ -31,6 +31,14 @@ def test_kernels_compile_for_gfx950_without_scratch(tmp_path):
     spilled = [n for n, s in zip(names, scratch) if s != 0]
     assert not spilled, f"kernels spilling to scratch: {spilled}"
     assert max(vgprs) <= 256
+    # occupancy guards: both exact-order matrix kernels lost a wave per SIMD once to loop-invariant index clamps hoisted into live registers
+    # (DESIGN.md sections 15.5, 15.8): xconv's main variant must stay at 3 waves per SIMD (<= 168 VGPRs), xe_gemm128 at 4 (<= 128)
+    per = dict(zip(names, vgprs))
+    assert len(names) == len(vgprs)
+    xconv = [v for n, v in per.items() if "xconv_kernelILi2ELi2ELi2ELb0" in n]
+    xgemm = [v for n, v in per.items() if "xe_gemm128_kernel" in n]
+    assert xconv and max(xconv) <= 168, xconv
+    assert xgemm and max(xgemm) <= 128, xgemm
     # the hot kernels exist under their documented names
     joined = " ".join(names)
     for k in ("linear_f16x2_kernel", "attn64_f16x2_kernel", "vq_f16_kernel", "vq_mfma_kernel", "vq_valu_kernel", "vq_finalize_packed_kernel", "attn64_kernel", "residual_ln_mod_kernel",

@@ -31,12 +31,14 @@ def ev(fn, reps=50):
     return s.elapsed_time(e) / reps
 
 
-for rt in (1, 2, 4):
-    for sp in (4, 8, 16, 32):
+ONE = bool(os.environ.get("SWEEP_COARSE1"))          # the one-MFMA pass (round 4's default) instead of the three-MFMA one
+SHAPES = [(4, 16)] if os.environ.get("SWEEP_DEFAULT_ONLY") else [(rt, sp) for rt in (1, 2, 4) for sp in (4, 8, 16, 32)]
+for rt, sp in SHAPES:
+    if True:
         zz = z.contiguous()
         ids = torch.empty(n, dtype=torch.int64, device="cuda")
         ws = torch.empty(lib.selftok_vq_workspace_bytes(n, 32768), dtype=torch.uint8, device="cuda")
-        flags = ops.VQ_F16COARSE | (rt << 8) | (sp << 16)
+        flags = ops.VQ_F16COARSE | (ops.VQ_F16COARSE1 if ONE else 0) | (rt << 8) | (sp << 16)
         ns = ctypes.c_int(0)
         st = torch.cuda.current_stream().cuda_stream
 
@@ -57,7 +59,7 @@ for rt in (1, 2, 4):
             torch.cuda.synchronize()
             if lib.selftok_tune_vq_stamp(st2, 2 + 3 * 4096) == 0 and st2[1] > 0:
                 ghz = st2[0] / (st2[1] * 10.0)                   # shader cycles per 10 ns tick
-                mfma_cyc = (32768 // 32 // sp) * rt * 3 * 32      # matrix-pipe cycles one wave of the workgroup issues (tiles x row blocks x 3 MFMAs x 32)
+                mfma_cyc = (32768 // 32 // sp) * rt * (1 if ONE else 3) * 32      # matrix-pipe cycles one wave of the workgroup issues (tiles x row blocks x 3 MFMAs x 32)
                 import numpy as np
                 a = np.array(st2[2:2 + 3 * nwg], dtype=np.uint64).reshape(nwg, 3)
                 t0, t1 = a[:, 0].astype(np.int64), a[:, 1].astype(np.int64)
