@@ -99,9 +99,7 @@ class MMDiTGPU(ModuleSurface):
     def _build_exact(self):
         """the input-independent pieces of the exact mode, once: the context adaLN tables through the exact Linear / SiLU from the reference's
         position table (selftoktokenizer_amd/data), the PatchEmbed convolution as a Linear over the (kh, kw, ic)-ordered patch"""
-        if self._tables_exact is not None or self.renderer:
-            if self.renderer:
-                raise NotImplementedError("gemm='exact' covers MMDiT.forward (the 50-step decode); the renderer keeps fp32 / f16x2")
+        if self._tables_exact is not None:
             return
         from .encoder import encoder_pos_embedding
         pos_emb = encoder_pos_embedding(self.K).to(self.device)
@@ -114,6 +112,14 @@ class MMDiTGPU(ModuleSurface):
             h = ex(p + ".t_embedder.mlp.2", silu(ex(p + ".t_embedder.mlp.0", pos_emb)))
             tabs.append(ex(p + ".adaLN_modulation.1", silu(h)).contiguous())
         self._tables_exact = tabs
+        if self.renderer:
+            # MMDiT_Renderer.forward (sd3/mmdit.py:1511-1620): no PatchEmbed (mask_token + positional_embedding), t = 1000 for every sample -- its
+            # sinusoid is the first row of the sampler's table (scheduled_t[0] * 1000 = 1000.0: the same function of the same input; torch.cos / sin are
+            # MKL VML on the reference host, shipped as data: tools/oracle/gen_pos_table.py)
+            import os
+            tab = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "flow50_t_sincos.npy"))
+            self._t1000_exact = torch.from_numpy(tab[0, 0:1].copy()).to(self.device)
+            return
         self.pe_w_exact = w["model.x_embedder.proj.weight"].permute(0, 2, 3, 1).reshape(DIT_HIDDEN, -1).contiguous()
         self._pe_perm = torch.arange(64, device=self.device).reshape(16, 2, 2).permute(1, 2, 0).reshape(-1)
 
@@ -382,7 +388,10 @@ class MMDiTGPU(ModuleSurface):
         if self.renderer:
             g = int(round(math.sqrt(self.w["model.positional_embedding"].shape[0])))
             xe = (self.w["model.mask_token"].expand(B, g * g, -1) + self.w["model.positional_embedding"]).contiguous()
-            t_freq = sinusoid_host(torch.full((B,), 1000.0)).to(self.device)       # t = ones*1000 (sd3/mmdit.py:1525)
+            if self.gemm == "exact":
+                t_freq = self._t1000_exact.expand(B, -1).contiguous()
+            else:
+                t_freq = sinusoid_host(torch.full((B,), 1000.0)).to(self.device)       # t = ones*1000 (sd3/mmdit.py:1525)
             out = self.core(xe, self.time_embed(t_freq), self.embed_context(ehs), kwargs.get("context_see_xt", False))
             _, v = ops.unpatchify_cfg_euler(out, C=16, hp=g, wp=g)
             return v, torch.zeros(B, dtype=torch.bool)

@@ -161,8 +161,6 @@ def test_pipeline_at_other_image_sizes_equals_the_reference_bit_for_bit(R):
     print(f"\n{R} px: VAE latents bit-equal; token ids from pixels vs the reference: {ids.numel() - flips} / {ids.numel()}")
     assert flips == 0
     assert torch.equal(pipe.encode_latents(imgs[5:6]), x0[5:6])                        # batch independent
-    if "lat" not in g.files:                                                           # the golden's decode half (an hour of CPU) is still being generated
-        pytest.skip(f"res{R}_b16.npz holds the encode half only")
     noise = synth.hash_normalish(0xA0 + R, (16, 16, R // 8, R // 8), "cpu")
     rec, lat = pipe.decoding(ids.cpu().numpy(), noise=noise, return_latent=True)
     diff = int((lat.cpu() != torch.from_numpy(g["lat"])).sum())
@@ -173,6 +171,28 @@ def test_pipeline_at_other_image_sizes_equals_the_reference_bit_for_bit(R):
     crc = np.array([zlib.crc32(np.ascontiguousarray(bits[i]).tobytes()) for i in range(16)], dtype=np.uint32)
     assert np.array_equal(crc, g["crc"]), f"{R} px: pixels differ from the reference's"
     assert np.array_equal(E.psnr_each(rec, imgs), g["psnr_ref"])
+
+
+def test_renderer_16_images_equals_the_reference_bit_for_bit():
+    """`decoding_with_renderer` (SelftokPipeline.py:296-322; MMDiT_Renderer.forward sd3/mmdit.py:1511-1620: mask_token + positional_embedding, t = 1000,
+    context rows cannot see the image rows, one pass) with gemm='exact': the reference's own 16-row run (tests/golden/renderer_b16.npz,
+    tools/oracle/gen_golden.py renderer16) -- the one-pass latent and every image's pixels EQUAL the reference's"""
+    from mimogpt.infer.SelftokPipeline import SelftokPipeline
+    g = np.load(os.path.join(GOLD, "renderer_b16.npz"))
+    sd = W.synthetic_state_dict(W.expected_shapes(512, renderer=True), device="cuda")
+    pipe = SelftokPipeline(default_config(512, renderer=True), None, None, device="cuda", state_dict=sd, vae_state_dict=W.synthetic_vae_state_dict(device="cuda"),
+                           verbose=False, gemm="exact")
+    assert pipe.model.model.gemm == "exact" and pipe.model.model.renderer
+    rec, lat = pipe.decoding_with_renderer(g["ids"], return_latent=True)
+    diff = int((lat.cpu() != torch.from_numpy(g["latent"])).sum())
+    print(f"\nrenderer, 16 id rows: {diff} of {lat.numel()} latent elements differ from the reference's")
+    assert diff == 0
+    bits = rec.cpu().view(torch.int16).numpy().view(np.uint16)
+    crc = np.array([zlib.crc32(np.ascontiguousarray(bits[i]).tobytes()) for i in range(16)], dtype=np.uint32)
+    assert np.array_equal(crc, g["crc"]), "renderer pixels differ from the reference's"
+    # rows are independent: 3 of the 16 alone give the same latents (the reference would not: MKL's path below 16 rows)
+    _, lat3 = pipe.decoding_with_renderer(g["ids"][4:7], return_latent=True)
+    assert torch.equal(lat3, lat[4:7])
 
 
 def test_guided_steps_16_images_equal_the_reference(models):

@@ -554,8 +554,40 @@ def stage_res(R, B=16):
     psnr = (10.0 * torch.log10(1.0 / mse)).numpy()
     report(f"res{R}", images=B, min_gap=float(gap.min()), psnr_ref_mean=float(psnr.mean()), pixel_mean=float(rec.float().mean()))
     np.savez_compressed(os.path.join(GOLD, f"res{R}_b16.npz"), tokens=tokens.numpy().astype(np.int16), gap=gap.numpy(),
-                        x0_bf16=x0.to(torch.bfloat16).view(torch.int16).numpy(), z=z.numpy(), lat=lat.numpy(), crc=crc, psnr_ref=psnr,
+                        x0_bf16=x0.to(torch.bfloat16).view(torch.int16).numpy(), lat=lat.numpy(), crc=crc, psnr_ref=psnr,
                         head=bits.reshape(B, -1)[:, :256].copy())
+
+
+def stage_renderer16(B=16):
+    """The reference `SelftokPipeline.decoding_with_renderer` (SelftokPipeline.py:296-322; MMDiT_Renderer.forward sd3/mmdit.py:1511-1620) on B = 16 id
+    rows in one batch with the renderer config: the one-pass latent and a crc32 of every image's bf16 pixels -- what `gemm='exact'` on the renderer
+    is checked against (16 rows: below that MKL takes another path for the conditioning Linears)."""
+    import zlib
+    H.install()
+    import mimogpt.infer.SelftokPipeline as SP
+    cfg = H.load_cfg(CFG_RND)
+    SP.AutoencoderKL = _MirrorVAE
+    shapes = W.expected_shapes(512, renderer=True)
+    real_load = torch.load
+    torch.load = lambda *a, **k: W.synthetic_state_dict(shapes)
+    try:
+        with H.fast_init():
+            pipe = SP.SelftokPipeline(cfg=cfg, ckpt_path="synthetic", sd3_path="synthetic", datasize=256, device="cpu")
+    finally:
+        torch.load = real_load
+    ids = synth.synthetic_token_ids(B)
+    cap = {}
+    hk = pipe.model.model.register_forward_hook(lambda m, i, o: cap.setdefault("lat", o[0].detach().clone()))
+    t0 = time.time()
+    rec = pipe.decoding_with_renderer(ids, device="cpu")
+    hk.remove()
+    print(f"[ref] decoding_with_renderer B={B} {time.time() - t0:.1f}s", flush=True)
+    lat = cap["lat"].float()
+    assert tuple(rec.shape) == (B, 3, 256, 256) and rec.dtype == torch.bfloat16
+    bits = rec.contiguous().view(torch.int16).numpy().view(np.uint16)
+    crc = np.array([zlib.crc32(np.ascontiguousarray(bits[i]).tobytes()) for i in range(B)], dtype=np.uint32)
+    report("renderer16", images=B, latent_absmax=float(lat.abs().max()), pixel_mean=float(rec.float().mean()))
+    np.savez_compressed(os.path.join(GOLD, "renderer_b16.npz"), ids=ids, latent=lat.numpy(), crc=crc, head=bits.reshape(B, -1)[:, :256].copy())
 
 
 def stage_config():
@@ -961,7 +993,7 @@ def stage_rmsnorm_rotary():
     report("rmsnorm_rotary", arrays=sorted(out), rms_absmax=float(np.abs(out["rms_affine"]).max()), rot_absmax=float(np.abs(out["rot_full"]).max()))
 
 
-STAGES = dict(res128=lambda: stage_res(128), res320=lambda: stage_res(320), k1024_16=stage_k1024_16, cfg16=stage_cfg16, dit4=stage_dit4, config=stage_config, decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
+STAGES = dict(renderer16=stage_renderer16, res128=lambda: stage_res(128), res320=lambda: stage_res(320), k1024_16=stage_k1024_16, cfg16=stage_cfg16, dit4=stage_dit4, config=stage_config, decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
               vae=stage_vae, pipeline=stage_pipeline, pipeline16=stage_pipeline16, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024, vqtrain=stage_vqtrain)
 
 if __name__ == "__main__":
