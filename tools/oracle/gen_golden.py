@@ -577,7 +577,9 @@ def stage_renderer16(B=16):
         torch.load = real_load
     ids = synth.synthetic_token_ids(B)
     cap = {}
-    hk = pipe.model.model.register_forward_hook(lambda m, i, o: cap.setdefault("lat", o[0].detach().clone()))
+    def keep(m, i, o):                      # (a hook that RETURNS something replaces the module's output)
+        cap["lat"] = o[0].detach().clone()
+    hk = pipe.model.model.register_forward_hook(keep)
     t0 = time.time()
     rec = pipe.decoding_with_renderer(ids, device="cpu")
     hk.remove()
