@@ -920,7 +920,11 @@ int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const
 size_t selftok_vx_groupnorm_workspace_bytes(int B, int HW, int C)
 {
     if (B <= 0 || HW <= 0 || HW % 16 || C % 128) return 0;
-    return ((size_t)B * C * HW / 256 + (size_t)B * C) * 16 * 8 + (size_t)2 * B * C * sizeof(float);          /* unused here: an upper bound of the HIP build's */
+    /* unused here; the HIP build's figure (csrc/vae_exact.hip xgn_plan): nodes of 16 / 4 / 2 aligned chunks, else raw half-moments per chunk */
+    int nch = 0;
+    if (HW % 256 == 0) { const int nc = HW / 256; nch = nc % 16 == 0 ? 16 : (nc % 4 == 0 ? 4 : (nc % 2 == 0 ? 2 : 0)); }
+    const size_t moms = nch ? (size_t)B * C * (HW / (256 * nch)) * 8 : ((size_t)B * C * HW / 256 + (size_t)B * C) * 16;
+    return moms * 8 + (size_t)2 * B * C * sizeof(float);
 }
 int selftok_vx_groupnorm_bf16(const void* x, const void* gamma, const void* beta, void* out, void* workspace, const void* silu_table, float* stats, int B, int HW,
                               int C, int groups, double eps, hipStream_t s)

@@ -190,7 +190,8 @@ def test_cpu_twin_exports_the_exact_entries_with_the_declared_signatures():
     ys = np.zeros_like(xs)
     assert twin.selftok_vx_expf_f32(xs.ctypes.data, ys.ctypes.data, 3, None) == 0
     assert np.array_equal(ys.view(np.uint32), np.array([VX.expf(float(v)) for v in xs], dtype=np.float32).view(np.uint32))
-    assert twin.selftok_vx_attention_workspace_bytes(2, 1024, 512) == 2 * 1024 * 1024 * 6 + 2 * 1024 * 512 * 2 + 2 * 2 * 1024 * 4
+    # scores fp32 + probabilities bf16 + V transposed + (kv blocks + 1) x rows of rescale / row scale + 128 floats of slack behind them
+    assert twin.selftok_vx_attention_workspace_bytes(2, 1024, 512) == 2 * 1024 * 1024 * 6 + 2 * 1024 * 512 * 2 + 3 * 2 * 1024 * 4 + 512
 
 
 # ---- round 5: the decoder ---------------------------------------------------------------------------------------------------------------
