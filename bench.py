@@ -290,6 +290,17 @@ def vq_roofline(n_vq, C, Dm, main_ms, fin_ms, launches, traffic, traffic_note, f
                     "kernel runs on; frac_executed = the f16 MFMA FLOPs it issues (%s) / the same "
                     "time and peak = pipe utilisation (N*C*D = %d x %d x %d); recompute from profiles/*kernel_stats.csv: the vq_f16_kernel row's average duration"
                     % ("1 per product: hi*hi; the exact fp32 re-score of the candidates keeps ids bit-exact" if mfmas == 1 else "3 per product: hi*hi + hi*lo + lo*hi", n_vq, C, Dm)}
+    if mfmas == 1:
+        # what binds the one-MFMA pass is its VALU issue, not the matrix pipe (measured OFFLINE in round 5, profiles/r5_vq_bound.txt; constants, not live):
+        # per 32 x 32 scores one 32-cycle MFMA and 12 VALU instructions (48 issue cycles); the pattern sustains 59 cycles per tile with four waves per SIMD
+        # (tools/microbench/mfma_f16_valu.hip) and the chip clocks 1.66 GHz under this kernel (in-kernel stamps, tools/sweep_vq_f16.py)
+        tiles_per_simd = (n_vq / 32.0) * (C / 32.0) / 1024.0
+        pattern_ms = tiles_per_simd * 59.0 / 1.66e9 * 1e3
+        roof["issue_roof"] = {"valu_instructions_per_tile": 12, "mfma_cycles_per_tile": 32, "pattern_cycles_per_tile_4_waves_per_simd": 59, "shader_ghz_under_kernel": 1.66,
+                              "pattern_ms": round(pattern_ms, 4), "frac_of_pattern": round(pattern_ms / main_ms, 4),
+                              "ceiling_frac_of_f16_peak": round(32.0 / 59.0 * 1.66 / 2.4, 4),
+                              "note": "offline constants (profiles/r5_vq_bound.txt), live avg_launch_ms: the kernel's own roof is the VALU issue of its tile-maximum scan; "
+                                      "`frac` above stays against the f16 matrix peak the contract names"}
     if fp32_main_ms:
         a32 = flops / (fp32_main_ms * 1e-3) / 1e12
         roof["fp32_mfma_kernel"] = {"kernel": "vq_mfma_kernel<RT> (round-1 kernel: exact fp32 products on v_mfma_f32_32x32x2_f32; same ids, bit for bit)",

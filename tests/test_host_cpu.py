@@ -349,6 +349,12 @@ def test_bench_roofline_object_is_a_fraction_of_the_pipe_the_kernel_runs_on(tmp_
     assert m.measured_vq_traffic(65536, True, str(p))[0] is None and m.measured_vq_traffic(32768, True, str(tmp_path / "nope.json"))[0] is None
     r = m.vq_roofline(32768, 32768, 16, 0.0922, 0.0100, 20, t, note)
     assert r["traffic"] == 30000000 and abs(r["traffic_over_algorithmic_bytes"] - 30000000 / 4456448) < 0.01
+    assert "issue_roof" not in r                                       # the three-MFMA pass is matrix-pipe bound
+    # round 5: the one-MFMA pass carries its own (VALU issue) roof beside the contract's fraction of the matrix peak
+    r1 = m.vq_roofline(32768, 32768, 16, 0.0505, 0.0169, 2, None, "none", mfmas=1)
+    ir = r1["issue_roof"]
+    assert abs(ir["pattern_ms"] - 1024 * 59 / 1.66e9 * 1e3) < 1e-4 and abs(ir["frac_of_pattern"] - ir["pattern_ms"] / 0.0505) < 1e-3
+    assert r1["frac"] < ir["ceiling_frac_of_f16_peak"] < 0.4 and r1["bound"] == "mfma"
 
 
 def test_gemm_tune_row_counts_and_file_format(tmp_path):
