@@ -264,6 +264,17 @@ def test_k1024_vs_reference_and_renderer_config():
         d = float((lat256[:2] - lat).abs().max())
         print(f"configs[3] full size (B=256 renderer) [{gemm}]: latents of images 0-1 vs the B=2 fp32 call, max abs diff {d:.3e}")
         assert d < 2e-4
+    # ... and its ENCODE leg at B = 256: 256 images in one call through the exact VAE + encoder; the first 16 are the images of the
+    # reference pipeline's run, and an exact-order path is batch-invariant by construction: their ids must be the reference's, whatever rides along
+    imgs = synth.synthetic_images(256, device="cuda")
+    ids256 = r.encoding(imgs)
+    assert tuple(ids256.shape) == (256, 512) and ids256.dtype == torch.int64
+    g16 = np.load(os.path.join(GOLD, "pipeline_b16.npz"))
+    assert np.array_equal(ids256[:16].cpu().numpy(), g16["tokens"].astype(np.int64)), "ids of the first 16 of 256 images differ from the reference's 16-image run"
+    g64 = np.load(os.path.join(GOLD, "encode_b64.npz"))
+    assert np.array_equal(ids256[:64].cpu().numpy(), g64["tokens"].astype(np.int64))
+    rec256, _ = r.decoding_with_renderer(ids256.cpu().numpy(), return_latent=True)
+    assert tuple(rec256.shape) == (256, 3, 256, 256)
 
 
 def test_ema_decoder_option(pipe):
