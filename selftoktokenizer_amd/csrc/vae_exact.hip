@@ -135,20 +135,32 @@ __global__ __launch_bounds__(64 * WM * WN) void xconv_kernel(XConvArgs a)
 
     int kh = 0, kw = 0, icb = 0;
     u32x4 sa[NPA], sb[NPB];
-    auto fetch = [&]() {                 // global -> registers for the chunk (kh, kw, icb), then step to the next chunk
+    // the input pixel of a staged row moves only when the TAP (kh, kw) does: its element offset and bounds flag are kept per piece and recomputed
+    // on a tap change -- every chunk in channel-block-major order, every IC / 32 chunks otherwise (15 VALU instructions per piece and chunk
+    // less beside the fp32 MFMAs, which share their issue slot)
+    int aoff[NPA];
+    bool aok[NPA];
+    auto retap = [&]() {
 #pragma unroll
         for (int j = 0; j < NPA; ++j) {
             const int iy = aiy0[j] + kh, ix = aix0[j] + kw;
-            const bool ok = aon[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            aok[j] = aon[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            aoff[j] = aok[j] ? (((iy >> a.up) * (W >> a.up) + (ix >> a.up)) * IC) : 0;
+        }
+    };
+    retap();
+    auto fetch = [&]() {                 // global -> registers for the chunk (kh, kw, icb), then step to the next chunk
+#pragma unroll
+        for (int j = 0; j < NPA; ++j) {
             const u32x4 zero = {0u, 0u, 0u, 0u};
-            const u32x4 v = *reinterpret_cast<const u32x4*>(arow[j] + ((size_t)((ok ? iy : 0) >> a.up) * (W >> a.up) + ((ok ? ix : 0) >> a.up)) * IC + icb * 32);
-            sa[j] = ok ? v : zero;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(arow[j] + (size_t)(unsigned)aoff[j] + icb * 32);
+            sa[j] = aok[j] ? v : zero;
         }
         const size_t woff = (size_t)(kh * KW + kw) * IC + icb * 32;
 #pragma unroll
         for (int j = 0; j < NPB; ++j) sb[j] = *reinterpret_cast<const u32x4*>(brow[j] + woff);
-        if (!PARTIAL) { if (++icb == nicb) { icb = 0; if (++kw == KW) { kw = 0; ++kh; } } }
-        else { if (++kw == KW) { kw = 0; if (++kh == KH) { kh = 0; ++icb; } } }
+        if (!PARTIAL) { if (++icb == nicb) { icb = 0; if (++kw == KW) { kw = 0; ++kh; } retap(); } }
+        else { if (++kw == KW) { kw = 0; if (++kh == KH) { kh = 0; ++icb; } } retap(); }
     };
     auto expand = [&](const u32x4& v, u32x4& ev, u32x4& od) {      // 4 packed bf16 pairs -> their low halves and their high halves as fp32 bit patterns
 #pragma unroll
