@@ -137,7 +137,7 @@ def test_decoder_upsampling_conv_ragged_rows():
 # (B, C, H): the pass-1 routes of the exact GroupNorm -- aligned nodes of 16 / 4 / 2 chunks (H*W % 512 == 0; 25 ranges per channel at 320 / 160 px,
 # 400 nodes per group at C = 512), raw half-moments per chunk (an odd number of chunks per channel: 80 x 80, 16 x 16), gathered chunks that straddle
 # channel boundaries (40 x 40 = 6.25 chunks per channel)
-GN_RES = [(1, 128, 320), (1, 256, 160), (1, 512, 160), (1, 256, 320), (2, 512, 80), (1, 256, 80), (2, 512, 40), (3, 512, 16), (1, 128, 64), (1, 256, 48)]
+GN_RES = [(1, 128, 320), (1, 256, 160), (1, 512, 160), (1, 256, 320), (2, 512, 80), (1, 256, 80), (2, 512, 40), (3, 512, 16), (1, 128, 64), (1, 256, 48), (2, 128, 12)]       # 12 x 12, 4 channels per group: 36 vectors = two chunks and a quarter
 
 
 @pytest.mark.parametrize("B,C,H", GN_RES)
