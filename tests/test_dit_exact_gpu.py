@@ -195,6 +195,31 @@ def test_renderer_16_images_equals_the_reference_bit_for_bit():
     assert torch.equal(lat3, lat[4:7])
 
 
+def test_pipeline_k1024_16_images_equals_the_reference_bit_for_bit():
+    """BASELINE configs[2] end to end (K = 1024; stage split 384,368,144,96,32): the reference pipeline's own 16-image run
+    (tests/golden/k1024_pipe_b16.npz, tools/oracle/gen_golden.py k1024_pipe16) -- ids from pixels, final latents of the 50-step loop, pixels, PSNR"""
+    from mimogpt.infer.SelftokPipeline import SelftokPipeline
+    from selftoktokenizer_amd import evaluate as E
+    g = np.load(os.path.join(GOLD, "k1024_pipe_b16.npz"))
+    sd = W.synthetic_state_dict(W.expected_shapes(1024), device="cuda")
+    pipe = SelftokPipeline(default_config(1024), None, None, device="cuda", state_dict=sd, vae_state_dict=W.synthetic_vae_state_dict(device="cuda"), verbose=False, gemm="exact")
+    imgs = synth.synthetic_images(16, device="cuda")
+    ids = pipe.encoding(imgs)
+    flips = int((ids.cpu().numpy() != g["tokens"].astype(np.int64)).sum())
+    print(f"\nK = 1024: token ids from pixels vs the reference: {ids.numel() - flips} / {ids.numel()}")
+    assert flips == 0
+    if "lat" not in g.files:
+        pytest.skip("k1024_pipe_b16.npz holds the encode half only")
+    rec, lat = pipe.decoding(ids.cpu().numpy(), noise=synth.synthetic_noise(16), return_latent=True)
+    diff = int((lat.cpu() != torch.from_numpy(g["lat"])).sum())
+    print(f"K = 1024: final latents after 50 exact-order steps: {diff} differing elements")
+    assert diff == 0
+    bits = rec.cpu().view(torch.int16).numpy().view(np.uint16)
+    crc = np.array([zlib.crc32(np.ascontiguousarray(bits[i]).tobytes()) for i in range(16)], dtype=np.uint32)
+    assert np.array_equal(crc, g["crc"]), "K = 1024: pixels differ from the reference's"
+    assert np.array_equal(E.psnr_each(rec, imgs), g["psnr_ref"])
+
+
 def test_guided_steps_16_images_equal_the_reference(models):
     """classifier-free guidance (sd3/rectified_flow.py:280-289: MMDiT.cfg_inference -- integer-floored timestep, no context key visible -- and the conditional
     call without context_see_xt, mixed as u + s (c - u)): the latents after one and two guided steps at B = 16 have the reference's crc32 (tests/golden/cfg_b16.npz)"""
