@@ -385,6 +385,21 @@ def parity_16(pipe, exact_leg=True):
                                  "psnr_delta_max_dB": float(np.abs(psnr_each(rec_x) - g["psnr_ref"]).max()),
                                  "note": "the same 16 ids and noise through the exact-order MMDiT + exact VAE decoder: crc32 of every image's bf16 pixels against the reference "
                                          "pipeline run's (tests/golden/decode_b16.npz)"}
+            g64p, e64p = os.path.join(os.path.dirname(GOLD16), "pipeline_b64.npz"), os.path.join(os.path.dirname(GOLD16), "encode_b64.npz")
+            if os.path.exists(g64p) and os.path.exists(e64p):
+                # BASELINE configs[1] at its configured batch: the reference's own run of 64 images in ONE batch (tools/oracle/gen_golden.py pipeline64)
+                g64, ids64 = np.load(g64p), np.load(e64p)["tokens"].astype(np.int64)
+                pipe.set_gemm("exact")
+                try:
+                    rec64, lat64 = pipe.decoding(ids64, noise=synth.synthetic_noise(64), return_latent=True)
+                finally:
+                    pipe.set_gemm(dit_mode)
+                b64 = rec64.cpu().view(torch.int16).numpy().view(np.uint16)
+                l64 = lat64.float().cpu().contiguous().numpy()
+                out["exact_mode_b64"] = {"images": 64, "images_with_final_latents_bit_equal_to_the_reference": int(sum(zlib.crc32(l64[i].tobytes()) == int(g64["lat_crc"][i]) for i in range(64))),
+                                         "images_with_pixels_bit_equal_to_the_reference": int(sum(zlib.crc32(np.ascontiguousarray(b64[i]).tobytes()) == int(g64["crc"][i]) for i in range(64))),
+                                         "note": "configs[1] at its configured batch: the reference pipeline's own run of the 64 bench images in one batch (ids of encode_b64.npz, hash noise), "
+                                                 "50 steps + VAE decode in the exact modes, crc32 per image of the final latents and of the bf16 pixels (tests/golden/pipeline_b64.npz)"}
     return out
 
 

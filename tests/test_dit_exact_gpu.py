@@ -218,6 +218,31 @@ def test_pipeline_k1024_16_images_equals_the_reference_bit_for_bit():
     assert np.array_equal(E.psnr_each(rec, imgs), g["psnr_ref"])
 
 
+def test_pipeline_64_images_in_one_batch_equals_the_reference_bit_for_bit():
+    """BASELINE configs[1] at its configured batch: the reference pipeline's own run of 64 images in ONE batch (tests/golden/pipeline_b64.npz,
+    tools/oracle/gen_golden.py pipeline64: ~3 h of CPU) -- a crc32 of every image's final latent after 50 steps and of its bf16 pixels, PSNR of every image"""
+    from mimogpt.infer.SelftokPipeline import SelftokPipeline
+    from selftoktokenizer_amd import evaluate as E
+    path = os.path.join(GOLD, "pipeline_b64.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/pipeline_b64.npz has not been generated (tools/oracle/gen_golden.py pipeline64)")
+    g, g64 = np.load(path), np.load(os.path.join(GOLD, "encode_b64.npz"))
+    sd = W.synthetic_state_dict(W.expected_shapes(512), device="cuda")
+    pipe = SelftokPipeline(default_config(512), None, None, device="cuda", state_dict=sd, vae_state_dict=W.synthetic_vae_state_dict(device="cuda"), verbose=False, gemm="exact")
+    imgs = synth.synthetic_images(64, device="cuda")
+    ids = pipe.encoding(imgs)
+    assert np.array_equal(ids.cpu().numpy(), g64["tokens"].astype(np.int64))
+    rec, lat = pipe.decoding(ids.cpu().numpy(), noise=synth.synthetic_noise(64), return_latent=True)
+    l = lat.float().cpu().contiguous().numpy()
+    lat_ok = np.array([zlib.crc32(l[i].tobytes()) == int(g["lat_crc"][i]) for i in range(64)])
+    print(f"\n64 images in one batch: final latents of {int(lat_ok.sum())} / 64 images equal the reference's; first four: {int((l[:4] != g['lat4']).sum())} differing elements")
+    assert lat_ok.all(), np.nonzero(~lat_ok)[0]
+    bits = rec.cpu().view(torch.int16).numpy().view(np.uint16)
+    crc = np.array([zlib.crc32(np.ascontiguousarray(bits[i]).tobytes()) for i in range(64)], dtype=np.uint32)
+    assert np.array_equal(crc, g["crc"]), "pixels differ from the reference's"
+    assert np.array_equal(E.psnr_each(rec, imgs), g["psnr_ref"])
+
+
 def test_guided_steps_16_images_equal_the_reference(models):
     """classifier-free guidance (sd3/rectified_flow.py:280-289: MMDiT.cfg_inference -- integer-floored timestep, no context key visible -- and the conditional
     call without context_see_xt, mixed as u + s (c - u)): the latents after one and two guided steps at B = 16 have the reference's crc32 (tests/golden/cfg_b16.npz)"""

@@ -644,6 +644,59 @@ def stage_k1024_pipe16(B=16):
     np.savez_compressed(os.path.join(GOLD, "k1024_pipe_b16.npz"), tokens=tokens.numpy().astype(np.int16), lat=lat.numpy(), crc=crc, psnr_ref=psnr)
 
 
+def stage_pipeline64(B=64):
+    """BASELINE configs[1] at its configured batch: the reference SelftokPipeline end to end on B = 64 synthetic images IN ONE BATCH (encode + 50-step
+    decode + VAE decode; ~3 h on 8 cores) -- a crc32 of every image's final latent and of its bf16 pixels, the latents of the first four images in full,
+    the PSNR of every image.  The ids must be encode_b64.npz's.  What `bench.py`'s exact leg and the GPU suite check the timed batch against."""
+    import zlib
+    H.install()
+    import mimogpt.infer.SelftokPipeline as SP
+    cfg = H.load_cfg(CFG_256)
+    SP.AutoencoderKL = _MirrorVAE
+    shapes = W.expected_shapes(512)
+    real_load = torch.load
+    torch.load = lambda *a, **k: W.synthetic_state_dict(shapes)
+    try:
+        with H.fast_init():
+            pipe = SP.SelftokPipeline(cfg=cfg, ckpt_path="synthetic", sd3_path="synthetic", datasize=256, device="cpu")
+    finally:
+        torch.load = real_load
+    images = synth.synthetic_images(B)
+    t0 = time.time()
+    tokens = pipe.encoding(images, device="cpu")
+    print(f"[ref] encoding B={B} {time.time() - t0:.1f}s", flush=True)
+    g64 = np.load(os.path.join(GOLD, "encode_b64.npz"))
+    assert np.array_equal(tokens.numpy().astype(np.int16), g64["tokens"])
+    noise = synth.synthetic_noise(B)
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: noise.clone()
+    cap = {}
+    real_loop = pipe.flow.p_sample_loop
+
+    def loop(*a, **k):
+        cap["lat"] = real_loop(*a, **k)
+        return cap["lat"]
+    pipe.flow.p_sample_loop = loop
+    t0 = time.time()
+    try:
+        rec = pipe.decoding(tokens.numpy(), device="cpu")
+    finally:
+        torch.randn = real_randn
+        pipe.flow.p_sample_loop = real_loop
+    print(f"[ref] decoding B={B} {time.time() - t0:.1f}s", flush=True)
+    lat = cap["lat"].detach().float().contiguous()
+    bits = rec.to(torch.bfloat16).contiguous().view(torch.int16).numpy().view(np.uint16)
+    crc = np.array([zlib.crc32(np.ascontiguousarray(bits[i]).tobytes()) for i in range(B)], dtype=np.uint32)
+    lat_crc = np.array([zlib.crc32(lat[i].numpy().tobytes()) for i in range(B)], dtype=np.uint32)
+    orig = (images + 1.0) / 2.0
+    mse = ((rec.float() - orig) ** 2).reshape(B, -1).double().mean(dim=1)
+    psnr = (10.0 * torch.log10(1.0 / mse)).numpy()
+    b16 = np.load(os.path.join(GOLD, "pipeline_b16.npz"))
+    same16 = bool(np.array_equal(lat[:16].numpy(), b16["lat"]))
+    report("pipeline64", images=B, psnr_ref_mean=float(psnr.mean()), first16_latents_equal_the_b16_run=same16)
+    np.savez_compressed(os.path.join(GOLD, "pipeline_b64.npz"), lat_crc=lat_crc, crc=crc, psnr_ref=psnr, lat4=lat[:4].numpy(), first16_latents_equal_the_b16_run=np.bool_(same16))
+
+
 def stage_config():
     """the hot-path keys of the reference's two shipped YAMLs (configs/res256/256-eval.yml, configs/renderer/renderer-eval.yml) as the REFERENCE's own
     `parse_args_from_yaml` (infer_utils.py:165-168) returns them: the values `selftoktokenizer_amd.config.default_config` must reproduce (VERDICT r4
@@ -1047,7 +1100,7 @@ def stage_rmsnorm_rotary():
     report("rmsnorm_rotary", arrays=sorted(out), rms_absmax=float(np.abs(out["rms_affine"]).max()), rot_absmax=float(np.abs(out["rot_full"]).max()))
 
 
-STAGES = dict(k1024_pipe16=stage_k1024_pipe16, renderer16=stage_renderer16, res128=lambda: stage_res(128), res320=lambda: stage_res(320), k1024_16=stage_k1024_16, cfg16=stage_cfg16, dit4=stage_dit4, config=stage_config, decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
+STAGES = dict(pipeline64=stage_pipeline64, k1024_pipe16=stage_k1024_pipe16, renderer16=stage_renderer16, res128=lambda: stage_res(128), res320=lambda: stage_res(320), k1024_16=stage_k1024_16, cfg16=stage_cfg16, dit4=stage_dit4, config=stage_config, decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
               vae=stage_vae, pipeline=stage_pipeline, pipeline16=stage_pipeline16, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024, vqtrain=stage_vqtrain)
 
 if __name__ == "__main__":
