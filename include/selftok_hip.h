@@ -278,6 +278,8 @@ int selftok_groupnorm_silu_nhwc_bf16(const void* x, const void* weight, const vo
  * order = the chunk order of oneDNN's kernel for that layer: 0: 32-channel chunks in (kh, kw, channel-block) order; 3: channel-block
  * major, every block's 9 taps summed privately and then added to the total (a stride-2 layer whose input is >= 102 pixels wide: the 128- and
  * 256-channel Downsample layers at 256 and 320 px, the 128-channel one at 128 px -- oneDNN decides by the layer's width, whatever H, B, C);
+ * 1: channel-block major into the ONE running total (round 5: what oneDNN does once a 3x3 layer's bf16 input or output reaches 2^31 bytes -- the two
+ * decoder layers around the [64, 256, 256, 256] activation when 64 images are decoded in one call, BASELINE configs[1]);
  * 2: conv_in (Cin = 3): one chunk of 27 elements in (kw, kh, ic) order.  Cin % 32 == 0, Cout % 32 == 0 (orders 0, 3); any row count
  * B*Ho*Wo (the last 64- / 128-row tile may be ragged: 40 x 40 = 1600 rows).
  * order | SELFTOK_VX_UPSAMPLE2X (round 5, the decoder's Upsample: F.interpolate(nearest, x2) + 3x3 convolution, sd3_impls.py:308-311): x is

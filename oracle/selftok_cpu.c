@@ -895,8 +895,8 @@ int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const
     const int up = (order & SELFTOK_VX_UPSAMPLE2X) ? 1 : 0;
     order &= ~SELFTOK_VX_UPSAMPLE2X;
     if (up && (stride != 1 || ((H | W) & 1) || ldx != Cin)) return fail("vx_conv2d: SELFTOK_VX_UPSAMPLE2X needs stride 1 and even H, W");
-    if (order == 2 ? (Cin != 3 || ksize != 3 || stride != 1 || residual) : ((order != 0 && order != 3) || Cin % 32 || ldx != Cin || Cout % 32))
-        return fail("vx_conv2d: need Cin % 32 == 0, Cout % 32 == 0, order 0 / 2 / 3");
+    if (order == 2 ? (Cin != 3 || ksize != 3 || stride != 1 || residual) : ((order != 0 && order != 1 && order != 3) || Cin % 32 || ldx != Cin || Cout % 32))
+        return fail("vx_conv2d: need Cin % 32 == 0, Cout % 32 == 0, order 0 / 1 / 2 / 3");
     const int OH = stride == 2 ? H / 2 : H, OW = stride == 2 ? W / 2 : W;
     const uint16_t* xs = (const uint16_t*)x;
     uint16_t* tmp = NULL;

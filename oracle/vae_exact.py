@@ -179,7 +179,11 @@ def decode(pw, z_bits, trace=None):
     tab = silu_table()
 
     def conv(name, x, **kw):
-        y = conv2d(x, pw[name + ".weight"], pw[name + ".bias"], order=0, **kw)
+        w = pw[name + ".weight"]
+        # order 1 (channel-block major into the one running total) once a 3x3 layer's bf16 input or output reaches 2^31 bytes: 64 images of 256 channels
+        # at 256 x 256 (tools/probe_cpu_bf16/check_conv_batch64.py)
+        big = w.shape[1] == 3 and 2 * x.shape[0] * x.shape[1] * x.shape[2] * max(w.shape[0], w.shape[3]) >= 2 ** 31
+        y = conv2d(x, w, pw[name + ".bias"], order=1 if big else 0, **kw)
         if trace is not None:
             trace.append((name, y))
         return y

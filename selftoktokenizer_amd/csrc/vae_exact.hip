@@ -70,9 +70,12 @@ struct XConvArgs {
 
 typedef float xf32x2 __attribute__((ext_vector_type(2)));
 
-template <int NT, int WM, int WN, bool PARTIAL>
+// ORD: 0 = chunks in (kh, kw, channel-block) order; 3 = channel-block major, every block's taps summed privately (S) and then added to the total;
+// 1 = channel-block major into the ONE running total (what oneDNN does for the two decoder layers whose activation reaches 2^31 bytes: 64 images)
+template <int NT, int WM, int WN, int ORD>
 __global__ __launch_bounds__(64 * WM * WN) void xconv_kernel(XConvArgs a)
 {
+    constexpr bool PARTIAL = ORD == 3, ICB_MAJOR = ORD != 0;
     // workgroup tile: RA = 32 WM pixel rows x RB = 32 NT WN output channels; one chunk = 32 bf16 channels of every row, staged as fp32:
     // round 5 -- the bf16 -> fp32 expansion happens ONCE per staged element (a shift / a mask on the packed pair, by the thread that copies it to
     // LDS) instead of once per reading lane (v_perm per MFMA operand: 24 per 32 x 32 tile and chunk), and a row's chunk is laid out as
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(64 * WM * WN) void xconv_kernel(XConvArgs a)
         const size_t woff = (size_t)(kh * KW + kw) * IC + icb * 32;
 #pragma unroll
         for (int j = 0; j < NPB; ++j) sb[j] = *reinterpret_cast<const u32x4*>(brow[j] + woff);
-        if (!PARTIAL) { if (++icb == nicb) { icb = 0; if (++kw == KW) { kw = 0; ++kh; } retap(); } }
+        if (!ICB_MAJOR) { if (++icb == nicb) { icb = 0; if (++kw == KW) { kw = 0; ++kh; } retap(); } }
         else { if (++kw == KW) { kw = 0; if (++kh == KH) { kh = 0; ++icb; } } retap(); }
     };
     auto expand = [&](const u32x4& v, u32x4& ev, u32x4& od) {      // 4 packed bf16 pairs -> their low halves and their high halves as fp32 bit patterns
@@ -721,7 +724,7 @@ __global__ void xtranspose_kernel(const unsigned short* __restrict__ v, unsigned
     for (int r = ty; r < 32; r += 8) vt[((size_t)b * C + c0 + r) * T + t0 + tx] = tile[tx][r];
 }
 
-static int launch_xconv(XConvArgs a, long P, int nz, bool partial, hipStream_t stream)
+static int launch_xconv(XConvArgs a, long P, int nz, int order, hipStream_t stream)
 {
     a.P = P;
 #ifndef XCONV_WM
@@ -729,15 +732,17 @@ static int launch_xconv(XConvArgs a, long P, int nz, bool partial, hipStream_t s
 #endif
     if (a.OC % 128 == 0) {
         dim3 grid((unsigned)((P + 32 * XCONV_WM - 1) / (32 * XCONV_WM)), a.OC / 128, nz);
-        if (partial) hipLaunchKernelGGL((xconv_kernel<2, XCONV_WM, 2, true>), grid, dim3(128 * XCONV_WM), 0, stream, a);
-        else hipLaunchKernelGGL((xconv_kernel<2, XCONV_WM, 2, false>), grid, dim3(128 * XCONV_WM), 0, stream, a);
-    } else if (a.OC % 64 == 0 && !partial) {                 // the scores of a 1600-token attention: 1600 keys = 25 x 64
+        if (order == 3) hipLaunchKernelGGL((xconv_kernel<2, XCONV_WM, 2, 3>), grid, dim3(128 * XCONV_WM), 0, stream, a);
+        else if (order == 1) hipLaunchKernelGGL((xconv_kernel<2, XCONV_WM, 2, 1>), grid, dim3(128 * XCONV_WM), 0, stream, a);
+        else hipLaunchKernelGGL((xconv_kernel<2, XCONV_WM, 2, 0>), grid, dim3(128 * XCONV_WM), 0, stream, a);
+    } else if (a.OC % 64 == 0 && order == 0) {                 // the scores of a 1600-token attention: 1600 keys = 25 x 64
         dim3 grid((unsigned)((P + 63) / 64), a.OC / 64, nz);
-        hipLaunchKernelGGL((xconv_kernel<1, 2, 2, false>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((xconv_kernel<1, 2, 2, 0>), grid, dim3(256), 0, stream, a);
     } else {
         dim3 grid((unsigned)((P + 127) / 128), a.OC / 32, nz);
-        if (partial) hipLaunchKernelGGL((xconv_kernel<1, 4, 1, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((xconv_kernel<1, 4, 1, false>), grid, dim3(256), 0, stream, a);
+        if (order == 3) hipLaunchKernelGGL((xconv_kernel<1, 4, 1, 3>), grid, dim3(256), 0, stream, a);
+        else if (order == 1) hipLaunchKernelGGL((xconv_kernel<1, 4, 1, 1>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((xconv_kernel<1, 4, 1, 0>), grid, dim3(256), 0, stream, a);
     }
     return check_launch("xconv_kernel");
 }
@@ -766,14 +771,14 @@ int selftok_vx_conv2d_bf16(const void* x, const void* w, const void* bias, const
     const int up = (order & SELFTOK_VX_UPSAMPLE2X) ? 1 : 0;
     order &= ~SELFTOK_VX_UPSAMPLE2X;
     if (up && (stride != 1 || ((H | W) & 1))) { set_last_error("vx_conv2d: SELFTOK_VX_UPSAMPLE2X needs stride 1 and even H, W (the upsampled size)"); return SELFTOK_EINVAL; }
-    if ((order != 0 && order != 3) || Cin % 32 || ldx != Cin || Cout % 32 || (stride == 2 && ((H | W) & 1))) {
-        set_last_error("vx_conv2d: need Cin % 32 == 0, Cout % 32 == 0, order 0 / 2 / 3"); return SELFTOK_EINVAL;
+    if ((order != 0 && order != 1 && order != 3) || Cin % 32 || ldx != Cin || Cout % 32 || (stride == 2 && ((H | W) & 1))) {
+        set_last_error("vx_conv2d: need Cin % 32 == 0, Cout % 32 == 0, order 0 / 1 / 2 / 3"); return SELFTOK_EINVAL;
     }
     XConvArgs a{};
     a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.bias = (const unsigned short*)bias; a.res = (const unsigned short*)residual; a.y = out;
     a.H = H; a.W = W; a.IC = Cin; a.OC = Cout; a.KH = a.KW = ksize; a.stride = stride; a.pad = (ksize == 3 && stride == 1) ? 1 : 0; a.OH = OH; a.OW = OW;
     a.split = -1; a.mode = 0; a.up = up;
-    return launch_xconv(a, P, 1, order == 3, stream);
+    return launch_xconv(a, P, 1, order, stream);
 }
 
 // pass-1 plan of the exact GroupNorm: chunks of 256 elements per channel (nc); NCH = 16 / 4 / 2 aligned chunks pre-combined per thread when nc is
@@ -869,7 +874,7 @@ int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void*
     a.x = (const unsigned short*)q; a.w = (const unsigned short*)k; a.y = s; a.H = 1; a.W = T; a.IC = C; a.OC = T; a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.OH = 1; a.OW = T;
     a.split = -1; a.mode = 1; a.out_scale = (float)(1.0 / sqrt((double)C));
     a.x_bs = (long)T * C; a.w_bs = (long)T * C; a.y_bs = (long)T * T; a.v_bs = T;
-    int rc = launch_xconv(a, T, B, false, stream);
+    int rc = launch_xconv(a, T, B, 0, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(xattn_softmax_kernel, dim3((unsigned)(((long)B * T + 15) / 16)), dim3(256), 0, stream, s, p, rescale, rowscale, (long)B * T, T);
     rc = check_launch("xattn_softmax_kernel");
@@ -882,7 +887,7 @@ int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void*
     g.x = p; g.w = vt; g.y = out; g.H = 1; g.W = T; g.IC = T; g.OC = C; g.KH = g.KW = 1; g.stride = 1; g.pad = 0; g.OH = 1; g.OW = T;
     g.rescale = nblk > 1 ? rescale : nullptr; g.rs_stride = (long)B * T; g.rowscale = rowscale; g.split = 16; g.mode = 2;
     g.x_bs = (long)T * T; g.w_bs = (long)C * T; g.y_bs = (long)T * C; g.v_bs = T;
-    return launch_xconv(g, T, B, false, stream);
+    return launch_xconv(g, T, B, 0, stream);
 }
 
 int selftok_vx_expf_f32(const float* x, float* y, long n, hipStream_t stream)

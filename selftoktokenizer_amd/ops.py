@@ -669,7 +669,7 @@ VX_UPSAMPLE2X = 8
 def vx_conv2d(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, stride: int = 1, residual: Optional[torch.Tensor] = None, order: int = 0,
               cin: Optional[int] = None, upsample: bool = False) -> torch.Tensor:
     """x [B,H,W,ldx] bf16 channels-last, w [Cout,k,k,Cin] bf16 (the checkpoint's tensor permuted), bias [Cout] bf16 -> [B,Ho,Wo,Cout] bf16 with the
-    summation order of the reference's CPU convolution (oneDNN AMX chunks; include/selftok_hip.h).  `order`: 0 / 3 / 2 (conv_in, cin = 3).
+    summation order of the reference's CPU convolution (oneDNN AMX chunks; include/selftok_hip.h).  `order`: 0 / 3 / 1 / 2 (conv_in, cin = 3).
     `upsample`: the convolution reads the nearest-2x upsampled view of x (the decoder's Upsample layer; output [B,2H,2W,Cout])."""
     _need_cuda(x, w, bias, residual)
     assert x.dtype == w.dtype == bias.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous() and x.dim() == 4 and w.dim() == 4

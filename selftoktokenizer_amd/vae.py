@@ -232,6 +232,13 @@ class AutoencoderKLGPU(ModuleSurface):
     def _x_conv(self, name, x, stride=1, residual=None, upsample=False, bias=None):
         w = self.xw[name]
         order = 0 if name.startswith("decoder.") else self._x_order(w.shape[3], stride, x.shape[2])       # every decoder layer: (kh, kw, channel-block) chunks
+        if name.startswith("decoder.") and w.shape[1] == 3:
+            # ... until the convolution's bf16 input or output reaches 2^31 bytes -- 64 images of 256 channels at 256 x 256, the reference's own batch of
+            # BASELINE configs[1]: oneDNN then walks the chunks channel-block major into the one running total (order 1; probed layer by layer,
+            # tools/probe_cpu_bf16/check_conv_batch64.py: the reference's decode of 64 images differs from its decode of 48 in exactly these two layers)
+            B, Hin, Win = x.shape[0], x.shape[1] * (2 if upsample else 1), x.shape[2] * (2 if upsample else 1)
+            if 2 * B * Hin * Win * max(w.shape[3], w.shape[0]) >= 2 ** 31:
+                order = 1
         return ops.vx_conv2d(x, w, self.w[name + ".bias"] if bias is None else bias, stride=stride, residual=residual, order=order, upsample=upsample)
 
     def _x_gn(self, name, x, act=True):

@@ -223,10 +223,7 @@ def test_pipeline_64_images_in_one_batch_equals_the_reference_bit_for_bit():
     tools/oracle/gen_golden.py pipeline64: ~3 h of CPU) -- a crc32 of every image's final latent after 50 steps and of its bf16 pixels, PSNR of every image"""
     from mimogpt.infer.SelftokPipeline import SelftokPipeline
     from selftoktokenizer_amd import evaluate as E
-    path = os.path.join(GOLD, "pipeline_b64.npz")
-    if not os.path.exists(path):
-        pytest.skip("tests/golden/pipeline_b64.npz has not been generated (tools/oracle/gen_golden.py pipeline64)")
-    g, g64 = np.load(path), np.load(os.path.join(GOLD, "encode_b64.npz"))
+    g, g64 = np.load(os.path.join(GOLD, "pipeline_b64.npz")), np.load(os.path.join(GOLD, "encode_b64.npz"))
     sd = W.synthetic_state_dict(W.expected_shapes(512), device="cuda")
     pipe = SelftokPipeline(default_config(512), None, None, device="cuda", state_dict=sd, vae_state_dict=W.synthetic_vae_state_dict(device="cuda"), verbose=False, gemm="exact")
     imgs = synth.synthetic_images(64, device="cuda")

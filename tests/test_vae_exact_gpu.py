@@ -124,6 +124,19 @@ def test_conv_exact_order_other_sizes(name, cin, cout, H, k, stride, order, B):
     test_conv_exact_order(name, cin, cout, H, k, stride, order, B)
 
 
+@pytest.mark.parametrize("cin,cout,H,up", [(256, 128, 64, False), (256, 256, 32, True), (512, 32, 16, False)])
+def test_conv_order_1_channel_block_major_into_one_total(cin, cout, H, up):
+    """order 1: what oneDNN does for a 3x3 layer whose bf16 activation reaches 2^31 bytes (64 images decoded in one call: the two layers around
+    [64, 256, 256, 256]; tools/probe_cpu_bf16/check_conv_batch64.py) -- the kernel's third traversal against the C oracle at small sizes"""
+    x = _rand_bf16(0xCA + cin, (2, H, H, cin), 1.3, 0.1)
+    w = _rand_bf16(0xCB + cout, (cout, 3, 3, cin), (1.0 / (cin * 9)) ** 0.5)
+    b = _rand_bf16(0xCC, (cout,), 0.1)
+    ref = VX.conv2d(VX.upsample2x(_bits(x)) if up else _bits(x), _bits(w), _bits(b), order=1)
+    out = ops.vx_conv2d(x.cuda(), w.cuda(), b.cuda(), order=1, upsample=up)
+    _same(out, ref, f"order 1, {cin}->{cout}")
+    assert int((_bits(out) != VX.conv2d(VX.upsample2x(_bits(x)) if up else _bits(x), _bits(w), _bits(b), order=0)).sum()) > 0      # and it is another order
+
+
 def test_decoder_upsampling_conv_ragged_rows():
     """nearest-2x input addressing at 20 -> 40 (1600 output rows per image)"""
     x = _rand_bf16(0xC7, (1, 20, 20, 512), 1.3, 0.1)
