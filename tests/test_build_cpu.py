@@ -35,7 +35,7 @@ def test_kernels_compile_for_gfx950_without_scratch(tmp_path):
     # (DESIGN.md sections 15.5, 15.8): xconv's main variant must stay at 3 waves per SIMD (<= 168 VGPRs), xe_gemm128 at 4 (<= 128)
     per = dict(zip(names, vgprs))
     assert len(names) == len(vgprs)
-    xconv = [v for n, v in per.items() if "xconv_kernelILi2ELi2ELi2ELb0" in n]
+    xconv = [v for n, v in per.items() if "xconv_kernelILi2ELi2ELi2ELi0E" in n]
     xgemm = [v for n, v in per.items() if "xe_gemm128_kernel" in n]
     assert xconv and max(xconv) <= 168, xconv
     assert xgemm and max(xgemm) <= 128, xgemm
