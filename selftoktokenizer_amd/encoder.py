@@ -132,7 +132,10 @@ class QformerEncoderGPU(ModuleSurface):
         """fused codebook[ids] -> final_layer_norm3 (SelftokPipeline.py:236-240).  exact mode: the gather is a copy, the LayerNorm(16) runs in ATen's
         arithmetic (csrc/encoder_exact.hip) -- the fused kernel's own LayerNorm is within 7e-7 of it, which is the decoder's conditioning"""
         if self.mode == "exact":
-            codes = self.codebook[ids.reshape(-1).long()].reshape(*ids.shape, -1).contiguous()
+            flat = ids.reshape(-1).long()
+            if flat.numel() and (int(flat.min()) < 0 or int(flat.max()) >= self.codebook.shape[0]):     # the fused kernel path refuses them too
+                raise ValueError(f"token ids must lie in [0, {self.codebook.shape[0]}): got [{int(flat.min())}, {int(flat.max())}]")
+            codes = self.codebook[flat].reshape(*ids.shape, -1).contiguous()
             return ops.ex_layernorm_mod(codes, gamma=self.w["encoder.final_layer_norm3.weight"], beta=self.w["encoder.final_layer_norm3.bias"])
         return ops.code_gather_ln(ids, self.codebook, self.w["encoder.final_layer_norm3.weight"], self.w["encoder.final_layer_norm3.bias"])
 

@@ -45,8 +45,7 @@ def evaluate(pipe, load_batch: Callable[[int, int], torch.Tensor], n_images: int
     (dist.shard_range) in batches of `batch`; per-image values are gathered to every rank (one all_gather_into_tensor per decoder at the end).
     load_batch(lo, hi) -> float tensor [hi-lo, 3, H, W] in [-1, 1] (host or device).  noise_fn(lo, hi) -> [hi-lo, 16, h, w] replaces the
     reference's `torch.randn` draw (global CPU generator, seeded here with `seed` + rank when given)."""
-    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+    world, rank = D.world_size(), D.rank()       # the dist module's view: sharding and the gather below must agree (ADVICE r5)
     lo, hi = D.shard_range(n_images, rank, world)
     counts = [D.shard_range(n_images, r, world)[1] - D.shard_range(n_images, r, world)[0] for r in range(world)]
     if seed is not None:
@@ -73,7 +72,7 @@ def evaluate(pipe, load_batch: Callable[[int, int], torch.Tensor], n_images: int
     out = {"images": int(n_images), "ranks": world, "batch": int(batch), "shard": [int(lo), int(hi)]}
     for d in decoders:
         mine = torch.from_numpy(np.concatenate(vals[d]) if vals[d] else np.zeros(0)).to(torch.float64)
-        allv = D.all_gather_rows(mine.to(pipe.device), counts).cpu().numpy() if world > 1 else mine.numpy()
+        allv = D.all_gather_rows(mine.to(pipe.device), counts).cpu().numpy()      # returns `mine` when there is no exchange to perform
         out[d] = {"psnr_mean_dB": float(allv.mean()) if allv.size else float("nan"), "psnr_each_dB": [round(float(v), 6) for v in allv]}
     out["token_ids_first_image"] = ids_all[0][0, :8].tolist() if ids_all else []
     return out

@@ -284,7 +284,8 @@ class MMDiTGPU(ModuleSurface):
                 # the joint attention as ATen's fp32 flash kernel evaluates `attention(q, k, v, heads, mask)` (sd3/other_impls.py:37-45) on the
                 # FULL key sequence [K context slots | image tokens] with the prefix mask: the n live context keys keep their positions (kv blocks
                 # of 512, MKL's K-blocks of 256 inside), the masked ones contribute exact zeros -- the same bits, not the truncated sequence's
-                assert kvis is None, "gemm='exact': one visibility prefix per call (the sampler's case)"
+                if kvis is not None:
+                    raise NotImplementedError("gemm='exact': one visibility prefix per call (the sampler's case); a per-sample `kvis` needs gemm='fp32' / 'f16x2'")
                 xk, xv = xqkv[..., H:2 * H], xqkv[..., 2 * H:]
                 if has_ctx:
                     cqkv = cqkv0[:, :n].contiguous() if (i == 0 and cqkv0 is not None) else self.lin(pc + ".attn.qkv", cn)
@@ -398,15 +399,48 @@ class MMDiTGPU(ModuleSurface):
         mask = kwargs.get("mask", None)
         see = kwargs.get("context_see_xt", False)
         Hh, Ww = x.shape[-2:]
-        t_freq = ops.timestep_embed(t.to(self.device).float(), self.freqs, 1000.0)
+        exact = self.gemm == "exact"
+        t_freq = self._t_freq_exact(t) if exact else ops.timestep_embed(t.to(self.device).float(), self.freqs, 1000.0)
         ctx = self.embed_context(ehs)
         kvis = None
         if mask is not None:
             m = mask.to(self.device).bool()
             # the reference's masks are prefixes (arange(K) <= k); anything else is outside the hot path
             cnt = m.sum(dim=1)
-            assert bool((m == (torch.arange(m.shape[1], device=m.device)[None] < cnt[:, None])).all()), "non-prefix mask"
-            kvis = (cnt - 1).to(torch.int32).contiguous()
+            if not bool((m == (torch.arange(m.shape[1], device=m.device)[None] < cnt[:, None])).all()):
+                raise NotImplementedError("MMDiTGPU.__call__: `mask` must be a prefix mask (arange(K) <= k, models_ours.py:353); decode other visibility "
+                                          "patterns through SelftokPipeline.decoding(super_mask=)")
+            if exact:
+                # gemm='exact' keeps every context key at its position in the reference's key sequence and takes ONE visibility prefix per call (the
+                # sampler's case): a batch-uniform mask is that prefix; a per-sample one would need the per-sample key walk the exact attention does not have
+                if not bool((cnt == cnt[0]).all()):
+                    raise NotImplementedError("gemm='exact': the mask must be the same prefix for every sample of the call (decode mixed prefixes in groups, or "
+                                              "with gemm='fp32' / 'f16x2')")
+                n_live = int(cnt[0])
+                ctx = ctx[:, :n_live].contiguous() if n_live > 0 else None
+            else:
+                kvis = (cnt - 1).to(torch.int32).contiguous()
         out = self.core(self.embed_image(x.to(self.device).float()), self.time_embed(t_freq), ctx, see, kvis)
         _, v = ops.unpatchify_cfg_euler(out, C=16, hp=Hh // 2, wp=Ww // 2)
         return v, torch.zeros(B, dtype=torch.bool)
+
+    def _t_freq_exact(self, t: torch.Tensor) -> torch.Tensor:
+        """gemm='exact': sinusoidal embedding of t * 1000 with the reference's bits.  The reference evaluates it with torch.cos / sin on the CPU (MKL VML on
+        its host class: closed source, not correctly rounded, host dependent), so the rows of the default sampler schedule ship as data
+        (data/flow50_t_sincos.npy, tools/oracle/gen_pos_table.py) and are used when t is one of those 50 timesteps; any other t is evaluated with the same
+        torch-CPU formula on THIS host -- the reference's bits only on a host of its class (documented deviation of this entry point; the pipeline's own
+        sampler always hits the table)."""
+        import os
+        from .schedule import FlowSchedule
+        if getattr(self, "_flow50", None) is None:
+            tab = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "flow50_t_sincos.npy"))
+            self._flow50 = (FlowSchedule(50, 1.0).scheduled_t.copy(), torch.from_numpy(tab[0].copy()))
+        sched, tab = self._flow50
+        tc = t.detach().float().cpu()
+        rows = sinusoid_host(tc * 1000.0)
+        tn = tc.numpy()
+        for b in range(tn.shape[0]):
+            hit = np.nonzero(sched == tn[b])[0]
+            if hit.size:
+                rows[b] = tab[int(hit[0])]
+        return rows.to(self.device).contiguous()

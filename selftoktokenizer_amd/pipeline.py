@@ -24,6 +24,7 @@ from .vae import AutoencoderKLGPU
 
 SD3_SCALE, SD3_SHIFT = 1.5305, 0.0609     # SD3LatentFormat (sd3/sd3_impls.py:136-138)
 DEFAULT_GEMM = "fp32"                     # see MMDiTGPU.set_gemm
+DEFAULT_VAE_DECODE = "parity"             # decoder arithmetic outside gemm='exact' (see SelftokPipeline.__init__: vae_decode_mode)
 
 
 class NormalizeToTensor(object):
@@ -169,17 +170,21 @@ class SelftokPipeline():
     def __init__(self, cfg, ckpt_path, sd3_path, datasize=256, start=1.0, cfg_scale=1, model_type='sd3',
                  dtype=torch.bfloat16, ema_decoder=False, device=None, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, verbose: bool = True, gemm: Optional[str] = None,
-                 vae_mode: Optional[str] = None, tune_gemm: Optional[bool] = None, encoder_mode: Optional[str] = None):
+                 vae_mode: Optional[str] = None, tune_gemm: Optional[bool] = None, encoder_mode: Optional[str] = None,
+                 vae_encode_mode: Optional[str] = None, vae_decode_mode: Optional[str] = None):
         """cfg: parse_args_from_yaml(...) ; ckpt_path: tokenizer .pth ; sd3_path: diffusers SD3 folder (…/vae/…).
         `state_dict` / `vae_state_dict` (extensions) bypass the files, e.g. with weights.synthetic_state_dict().
         `gemm` (extension): arithmetic of the MMDiT block Linears, 'fp32' (hipBLASLt fp32) or 'f16x2' (fp32-equivalent
         split GEMM on the f16 matrix cores, csrc/gemm_split.hip); default DEFAULT_GEMM.
-        `vae_mode` (extension): 'exact' (default at datasize 256: the encoder reproduces the summation ORDER of every reduction of the
-        reference's torch-CPU run, csrc/vae_exact.hip -- latents and token ids from pixels equal the reference's bit for bit; decoder as
-        'parity'), 'parity' (default otherwise: every convolution / GroupNorm through csrc/conv.hip -- fp32 accumulation with the
-        bias inside, one rounding, the reference's CPU arithmetic; no MIOpen, bit-stable, batch independent), 'miopen' (the same
-        arithmetic coaxed out of MIOpen's GEMM algorithm, 3x slower) or 'fast' (MIOpen's searched solvers with a separate bias add:
-        looser parity, not bit-stable; see vae.AutoencoderKLGPU).
+        `vae_encode_mode` / `vae_decode_mode` (extensions; `vae_mode` sets both): arithmetic of the two halves of the SD3 VAE (vae.AutoencoderKLGPU).
+        'exact': every reduction in the summation ORDER of the reference's torch-CPU run (csrc/vae_exact.hip, fp32 matrix cores) -- encoder: latents and
+        token ids from pixels equal the reference's bit for bit; decoder: pixels equal the reference's decode of the same latents, incl. its batch
+        dependence (a 3x3 layer whose bf16 activation reaches 2^31 bytes -- 64 images per call at 256 x 256 -- takes oneDNN's order 1: probed at 48 / 64
+        images per call, extrapolated above).  'parity': every convolution / GroupNorm through csrc/conv.hip -- fp32 accumulation with the bias inside, one
+        rounding, the reference's CPU arithmetic in its own summation order; no MIOpen, bit-stable, batch independent, 5x faster.  'miopen' / 'fast': the
+        rounds 1-3 routes through MIOpen (both halves).  Defaults (round 6): encode 'exact' at the probed sizes (128 / 256 / 320 px; token ids need it),
+        'parity' elsewhere; decode 'parity' (pixels within the north star's 1e-3 dB of the reference either way), and 'exact' while gemm == 'exact'
+        (the mode whose pixels ARE the reference's) unless `vae_decode_mode` / `vae_mode` was given.
         `encoder_mode` (extension): 'exact' (default: the Q-Former encoder in the summation order of every reduction and the polynomial of every
         transcendental torch-CPU executes for the reference, csrc/encoder_exact.hip -- pre-quantizer features and token ids equal the reference's
         bit for bit at every batch size) or 'fast' (hipBLASLt GEMMs + the fused rounds 1-3 kernels: features within 6e-5, ~2x faster encoder).
@@ -204,9 +209,11 @@ class SelftokPipeline():
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         with torch.cuda.device(self.device):                                  # our launches use the current device's stream
-            self._build(cfg, ckpt_path, sd3_path, start, cfg_scale, dtype, ema_decoder, state_dict, vae_state_dict, verbose, gemm, vae_mode, encoder_mode)
+            self._build(cfg, ckpt_path, sd3_path, start, cfg_scale, dtype, ema_decoder, state_dict, vae_state_dict, verbose, gemm, vae_mode, encoder_mode,
+                        vae_encode_mode, vae_decode_mode)
 
-    def _build(self, cfg, ckpt_path, sd3_path, start, cfg_scale, dtype, ema_decoder, state_dict, vae_state_dict, verbose, gemm, vae_mode=None, encoder_mode=None):
+    def _build(self, cfg, ckpt_path, sd3_path, start, cfg_scale, dtype, ema_decoder, state_dict, vae_state_dict, verbose, gemm, vae_mode=None, encoder_mode=None,
+               vae_encode_mode=None, vae_decode_mode=None):
         p = cfg.tokenizer.params
         p.noise_schedule_config.is_eval = cfg.common.is_eval
         # configuration knobs the reference honours but this hot path does not implement: refuse, never ignore silently
@@ -230,7 +237,12 @@ class SelftokPipeline():
 
         vsd = vae_state_dict if vae_state_dict is not None else W.load_vae_checkpoint(sd3_path)
         W.check_vae_state_dict(vsd)
-        self.vae = AutoencoderKLGPU(vsd, self.device, dtype, mode=vae_mode or ("exact" if int(self.datasize) in AutoencoderKLGPU.EXACT_SIZES else "parity"))
+        probed = int(self.datasize) in AutoencoderKLGPU.EXACT_SIZES
+        enc_mode = vae_encode_mode or vae_mode or ("exact" if probed else "parity")
+        self._vae_decode_explicit = (vae_decode_mode or vae_mode) is not None
+        dec_mode = vae_decode_mode or vae_mode or ("exact" if (probed and (gemm or DEFAULT_GEMM) == "exact" and enc_mode in ("exact", "parity")) else
+                                                   (enc_mode if enc_mode in ("miopen", "fast") else DEFAULT_VAE_DECODE))
+        self.vae = AutoencoderKLGPU(vsd, self.device, dtype, mode=enc_mode, decode_mode=dec_mode)
 
         self.verbose = verbose
         self._say("Loading all...")
@@ -325,8 +337,15 @@ class SelftokPipeline():
         return gemm_tune.enabled() if (self.tune_gemm and self.gemm_tune_report and self.model.model.gemm == "fp32") else contextlib.nullcontext()
 
     def set_gemm(self, mode: str) -> str:
-        """switch the MMDiT block Linears between 'fp32' and 'f16x2' (see MMDiTGPU.set_gemm); returns the mode in force"""
-        return self.model.model.set_gemm(mode)
+        """switch the MMDiT between 'fp32', 'f16x2' and 'exact' (see MMDiTGPU.set_gemm); returns the mode in force.  Unless the decoder's arithmetic was
+        chosen explicitly (`vae_decode_mode` / `vae_mode`), 'exact' brings the exact-order VAE decoder with it (the mode whose pixels are the reference's
+        bit for bit) and the other modes return to the default decoder."""
+        got = self.model.model.set_gemm(mode)
+        if not self._vae_decode_explicit and self.vae.mode in ("exact", "parity"):
+            want = "exact" if (got == "exact" and int(self.datasize) in AutoencoderKLGPU.EXACT_SIZES) else DEFAULT_VAE_DECODE
+            if self.vae.decode_mode != want:
+                self.vae.set_decode_mode(want)
+        return got
 
     @torch.no_grad()
     def _checked(self, run):

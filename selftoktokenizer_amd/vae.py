@@ -12,12 +12,18 @@ exact-order kernels of csrc/vae_exact.hip -- no torch arithmetic is left in the 
 that rounds where the CPU flash kernel rounds, remains for other token counts and the 'miopen' / 'fast' modes).  No MIOpen, bit-stable by construction, 103 ms per 64 images (encode +
 decode) against 331 ms for the MIOpen route below and 185 ms for MIOpen's fastest (inaccurate) solvers.
 
-`mode="exact"` (round 4, the pipeline's default at 256 x 256): the ENCODER additionally reproduces the ORDER of every reduction of the
-reference's torch-CPU run -- oneDNN's AMX convolution chunks, ATen's GroupNorm cascade, SiLU table, flash-attention row pass
-(csrc/vae_exact.hip; orders probed and restated in oracle/vae_exact.c) -- so the latents, and with them the token ids from pixels, are the
-reference's BIT FOR BIT (tests/test_vae_exact_gpu.py: 16 images of the reference pipeline's own run, 8192 / 8192 ids).  It runs on the fp32
-matrix cores (a prescribed order cannot use a bf16 MFMA's internal one): ~6x the `parity` encoder's time, still < 1 % of a 50-step decode.
-The decoder stays on the `parity` kernels (pixels are within 1e-3 dB either way; the 50-step fp32 sampler upstream is not bit-reproducible).
+`mode="exact"` (round 4 encoder, round 5 decoder): every reduction in the ORDER of the reference's torch-CPU run -- oneDNN's AMX convolution
+chunks, ATen's GroupNorm cascade, SiLU table, flash-attention row pass (csrc/vae_exact.hip; orders probed and restated in
+oracle/vae_exact.c) -- so the ENCODER's latents, and with them the token ids from pixels, are the reference's BIT FOR BIT
+(tests/test_vae_exact_gpu.py: 16 images of the reference pipeline's own run, 8192 / 8192 ids), and the DECODER's pixels equal the reference's
+decode of the same latents (tests/golden/decode_b16.npz).  It runs on the fp32 matrix cores (a prescribed order cannot use a bf16 MFMA's
+internal one): ~5x the `parity` kernels' time.
+The two halves are independent (round 6: `mode` = the encoder's arithmetic, `decode_mode` = the decoder's, default the same): token ids need the
+exact ENCODER; pixels meet the north star's 1e-3 dB with the `parity` DECODER too (the 50-step fp32 sampler upstream is not bit-reproducible
+outside gemm='exact'), so the pipeline's default is exact encode + parity decode and gemm='exact' selects the exact decoder.
+The exact decoder follows the reference's batch dependence: a 3x3 layer whose bf16 input or output reaches 2^31 bytes (64 images at 256 x 256)
+switches to oneDNN's order 1 (`_x_conv`), so its pixels at 64 images per call differ from those at 48 -- as the reference's do; probed at 48 / 64
+images per call, an extrapolation of that threshold above 64.
 
 `mode="miopen"` keeps the route rounds 1-3 used to reach the same arithmetic through PyTorch-ROCm, `mode="fast"` the rounds 1-2 arithmetic.
 Two properties of PyTorch-ROCm's bf16 convolution path matter for parity with the reference's CPU run and are handled by `mode="miopen"`
@@ -108,8 +114,9 @@ class AutoencoderKLGPU(ModuleSurface):
     _sd_prefix = ""
     MODES = ("exact", "parity", "miopen", "fast")
 
-    def __init__(self, vsd: Dict[str, torch.Tensor], device, dtype=torch.bfloat16, mode: str = "parity"):
-        """mode 'parity' (default since the end of round 3): channels-last, every convolution through the implicit-GEMM kernel of
+    def __init__(self, vsd: Dict[str, torch.Tensor], device, dtype=torch.bfloat16, mode: str = "parity", decode_mode: str = None):
+        """`mode`: arithmetic of `encode`; `decode_mode`: arithmetic of `decode` (default: the same; `set_decode_mode` switches it later).
+        mode 'parity' (default since the end of round 3): channels-last, every convolution through the implicit-GEMM kernel of
         csrc/conv.hip (fp32 accumulation incl. the bias, one rounding; residual add, nearest upsample and Downsample's padding fused),
         GroupNorm by the fp64-statistics kernel: the reference's CPU arithmetic, bit-stable by construction, no MIOpen.  mode 'miopen':
         the same arithmetic as rounds 1-3 reached it -- bias inside the accumulation + MIOpen's GEMM algorithm (module docstring).  mode 'fast': the
@@ -117,9 +124,14 @@ class AutoencoderKLGPU(ModuleSurface):
         convolutions, but 40 instead of 11 flipped tokens per 8192 and a 6e-3 instead of 3e-4 dB PSNR delta against the reference, and
         latents that are not bit-stable from call to call.  For throughput runs that do not compare against the reference."""
         assert dtype == torch.bfloat16, "the HIP GroupNorm+SiLU epilogue is bf16 (the reference runs the VAE in bf16)"
-        if mode not in self.MODES:
-            raise ValueError(f"VAE mode {mode!r}: expected one of {self.MODES}")
-        self.mode = mode
+        decode_mode = decode_mode or mode
+        for m in (mode, decode_mode):
+            if m not in self.MODES:
+                raise ValueError(f"VAE mode {m!r}: expected one of {self.MODES}")
+        if (mode in ("miopen", "fast")) != (decode_mode in ("miopen", "fast")) or (mode in ("miopen", "fast") and mode != decode_mode):
+            raise ValueError(f"VAE modes {mode!r} (encode) / {decode_mode!r} (decode): the MIOpen routes ('miopen', 'fast') cover both halves or neither")
+        self.mode = mode                      # the ENCODER's arithmetic (token ids depend on it)
+        self.decode_mode = decode_mode        # the DECODER's
         self.device, self.dtype = device, dtype
         # no benchmarking Find (see the module docstring); a value the caller exported wins.  MIOpen reads it when it first searches.
         os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
@@ -138,30 +150,50 @@ class AutoencoderKLGPU(ModuleSurface):
         # native path: packed weight images of csrc/conv.hip (built on first use of mode 'parity')
         self.pc = {}
         self.xw = {}
-        if mode in ("exact", "parity"):
+        native = mode in ("exact", "parity")
+        if native:
             # the checkpoint's tensors, permuted to [Cout, k, k, Cin] (no packing): the exact-order kernels read 64 contiguous bytes per
             # (output channel, tap, 32-channel block).  diffusers stores the attention projections as Linear [O, I] = a 1x1 convolution.
             # 'exact': the whole encoder; both modes: the mid-block attention of encoder AND decoder (AttnBlock, sd3_impls.py:274-284)
             # runs on these kernels -- GroupNorm, q / k / v / out projections and the flash-kernel row pass in the reference's order
             for k, v in self.w.items():
-                if k.endswith(".weight") and v.dim() in (2, 4) and (".attentions." in k or mode == "exact"):
+                if k.endswith(".weight") and v.dim() in (2, 4) and (".attentions." in k or (mode == "exact" and not k.startswith("decoder."))):
                     v4 = v.reshape(v.shape[0], v.shape[1], 1, 1) if v.dim() == 2 else v
                     self.xw[k[:-len(".weight")]] = v4.permute(0, 2, 3, 1).contiguous()
-            if mode == "exact":
-                # the decoder's two odd layers on the 32-channel-chunk kernel: conv_in (16 input channels = one 16-channel chunk per tap in
-                # oneDNN) with zero input channels 16..31, conv_out (3 output channels) with 29 zero output channels -- a zero product
-                # leaves an fp32 chain's bits unchanged, so the padded layers compute the unpadded layers' bits
-                wi = self.xw["decoder.conv_in"]                                               # [512,3,3,16]
-                self.xw["decoder.conv_in"] = F.pad(wi, (0, 32 - wi.shape[3])).contiguous()
-                wo = self.xw["decoder.conv_out"]                                              # [3,3,3,128]
-                self.xw["decoder.conv_out"] = F.pad(wo, (0, 0, 0, 0, 0, 0, 0, 32 - wo.shape[0])).contiguous()
-                self.xb_out = F.pad(self.w["decoder.conv_out.bias"], (0, 32 - wo.shape[0])).contiguous()
             self.silu_table = ops.vx_silu_table(device)
-        if mode in ("parity", "exact"):
+            if decode_mode == "exact":
+                self._prepare_exact_decoder()
+        if native:
             for k, v in self.w.items():
                 if k.endswith(".weight") and v.dim() == 4:
                     name = k[:-len(".weight")]
                     self.pc[name] = ops.PackedConv(v, self.w[name + ".bias"])
+
+    def _prepare_exact_decoder(self):
+        """the decoder's weights in the exact-order kernels' layout ([Cout, k, k, Cin]), once"""
+        if getattr(self, "xb_out", None) is not None:
+            return
+        for k, v in self.w.items():
+            if k.startswith("decoder.") and k.endswith(".weight") and v.dim() in (2, 4) and k[:-len(".weight")] not in self.xw:
+                v4 = v.reshape(v.shape[0], v.shape[1], 1, 1) if v.dim() == 2 else v
+                self.xw[k[:-len(".weight")]] = v4.permute(0, 2, 3, 1).contiguous()
+        # the decoder's two odd layers on the 32-channel-chunk kernel: conv_in (16 input channels = one 16-channel chunk per tap in
+        # oneDNN) with zero input channels 16..31, conv_out (3 output channels) with 29 zero output channels -- a zero product
+        # leaves an fp32 chain's bits unchanged, so the padded layers compute the unpadded layers' bits
+        wi = self.xw["decoder.conv_in"]                                               # [512,3,3,16]
+        self.xw["decoder.conv_in"] = F.pad(wi, (0, 32 - wi.shape[3])).contiguous()
+        wo = self.xw["decoder.conv_out"]                                              # [3,3,3,128]
+        self.xw["decoder.conv_out"] = F.pad(wo, (0, 0, 0, 0, 0, 0, 0, 32 - wo.shape[0])).contiguous()
+        self.xb_out = F.pad(self.w["decoder.conv_out.bias"], (0, 32 - wo.shape[0])).contiguous()
+
+    def set_decode_mode(self, decode_mode: str) -> str:
+        """switch the decoder between 'parity' and 'exact' (native modes only); weights of the new mode are prepared on first use"""
+        if decode_mode not in ("parity", "exact") or self.mode not in ("parity", "exact"):
+            raise ValueError(f"set_decode_mode({decode_mode!r}) with encoder mode {self.mode!r}: only the native modes 'parity' / 'exact' can be mixed")
+        if decode_mode == "exact":
+            self._prepare_exact_decoder()
+        self.decode_mode = decode_mode
+        return decode_mode
 
     # ---- native channels-last path (mode 'parity') ----------------------------------------------------------------------------
     def _n_gn(self, name, x, act=True):
@@ -186,7 +218,8 @@ class AutoencoderKLGPU(ModuleSurface):
         ATen's statistics, the four projections as 1x1 convolutions in oneDNN's chunk order, the attention as ATen's flash kernel
         evaluates it (T = 1024 tokens: the VAE at 256 x 256).  Other token counts keep the torch-op formulation of `_attn_tokens`."""
         B, H, W, C = x.shape
-        if not self.xw or (H * W != 1024 and not (self.mode == "exact" and (H * W) % 32 == 0)):
+        exact_here = (self.decode_mode if p.startswith("decoder.") else self.mode) == "exact"
+        if not self.xw or (H * W != 1024 and not (exact_here and (H * W) % 32 == 0)):
             h = self._n_gn(p + ".group_norm", x, act=False).reshape(B, H * W, C)
             return x + self._attn_tokens(p, h).reshape(B, H, W, C)
         n = self._x_gn(p + ".group_norm", x, act=False)
@@ -399,9 +432,9 @@ class AutoencoderKLGPU(ModuleSurface):
 
     @torch.no_grad()
     def decode(self, z, return_dict=False):
-        if self.mode == "exact":
+        if self.decode_mode == "exact":
             return (self._x_decode(z),)
-        if self.mode in ("parity", "exact"):
+        if self.decode_mode == "parity":
             return (self._n_decode(z),)
         with self._flags():
             return self._decode(z)

@@ -86,6 +86,23 @@ def test_one_collective_per_step_world2_gloo():
         assert all(ok for _, ok, _ in res), res
 
 
+def test_one_collective_per_step_world8_gloo():
+    """the world size the driver launches (8 ranks: configs[4] = 8 x 64 images): shard sizes exchanged once, ONE collective per step, even
+    (16 = 8 x 2) and uneven (13 = 5 x 2 + 3 x 1) shards, every rank ends with the full id matrix"""
+    for total in (16, 13):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = 37500 + (os.getpid() % 2000) + total
+        procs = [ctx.Process(target=_step_worker, args=(r, 8, port, total, q)) for r in range(8)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=300) for _ in procs]
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        assert len(res) == 8 and all(ok for _, ok, _ in res), res
+
+
 def _resharding_worker(rank, world, port, totals, q):
     """the global batch changes between calls such that ONE rank's shard keeps its size and the other's does not
     (5 -> (3,2), 6 -> (3,3), 4 -> (2,2), 5 again).  Every rank must issue the same collectives and get the right matrix each time."""
@@ -193,6 +210,10 @@ def test_bench_gpus_n_spawns_n_ranks_itself():
     assert line["allgather_bytes"] == 2 * 3 * 512 * 4 and line["allgather_ms"] > 0
     rc, line, _ = _bench("--gpus", "1", "--selftest-dist", "--batch", "2")
     assert rc == 0 and line["n_gpus"] == 1 and line["backend"] is None
+    # the driver's world size: 8 ranks respawned by `python bench.py --gpus 8`, one gather with world = 8
+    rc, line, err = _bench("--gpus", "8", "--selftest-dist", "--batch", "2", env={"SELFTOK_DIST_BACKEND": "gloo"}, timeout=600)
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 8 and line["ranks"] == 8 and line["allgather_ok"] is True and line["allgather_bytes"] == 8 * 2 * 512 * 4
 
 
 def test_bench_refuses_world_size_mismatch():

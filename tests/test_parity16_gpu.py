@@ -181,3 +181,32 @@ def test_psnr_16_images_vs_reference(pipe, gemm):
     # the same decoder on the same latents (second CPU implementation vs reference: mean 3.9e-4, max 1.09e-3 dB; measured here: mean 2.9e-4, max 8.8e-4;
     # rounds 1-2, separate bias add + solver search: mean 6.1e-3)
     assert d_e2e.mean() < 5e-4 and d_e2e.max() < 1e-3, (d_e2e.mean(), d_e2e.max(), d_or.mean(), d_or.max())   # north star: 1e-3 dB, every image (measured mean 2.5e-4, max 8.4e-4)
+
+
+def test_psnr_64_images_headline_modes_vs_reference(pipe):
+    """the arithmetics the reported images/s are measured in (gemm 'fp32' = the headline, 'f16x2') pinned AT THE CONFIGURED BATCH of BASELINE
+    configs[1]: the 64 ids + hash noise of the reference pipeline's own one-batch run (SelftokPipeline.py:227-294; tests/golden/encode_b64.npz, pipeline_b64.npz)
+    through 50 steps.  The comparison latents are the exact mode's, proven to be the reference's by the golden crc32 of every image.  Gates = the north star:
+    every image within 1e-3 dB of the reference's PSNR, mean below 5e-4 -- end to end with the mode's own decoder and through the same decoder.  `bench.py`
+    reports the same object as `parity_64`."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    r = bench.parity_64(pipe)
+    assert "error" not in r, r
+    ex = r["exact"]
+    assert ex["images_with_final_latents_bit_equal_to_the_reference"] == 64 and ex["images_with_pixels_bit_equal_to_the_reference"] == 64 and ex["psnr_identical_to_the_reference"]
+    assert pipe.model.model.gemm == "fp32" and pipe.vae.decode_mode == "parity"          # the leg restores the pipeline's mode and decoder
+    for mode in ("fp32", "f16x2"):
+        m = r[mode]
+        e2e, same = m["end_to_end"], m[f"same_decoder_{m['vae_decode']}"]
+        print(f"\n[{mode}, decoder {m['vae_decode']}] 64 images vs the reference's one-batch run: final latents max |delta| {m['final_latent_max_abs_delta']:.3e}")
+        print(f"   end to end  : mean {e2e['mean_dB']:.2e} max {e2e['max_dB']:.2e} dB (image {e2e['image_of_max']})")
+        for dec in ("parity", "exact"):
+            s = m[f"same_decoder_{dec}"]
+            print(f"   same decoder ({dec}): mean {s['mean_dB']:.2e} max {s['max_dB']:.2e} dB (image {s['image_of_max']}; floor there {s['floor']['at_the_image_of_max_dB']:.2e}, "
+                  f"floor mean {s['floor']['mean_dB']:.2e} max {s['floor']['max_dB']:.2e}); end to end with it: mean {s['end_to_end_with_this_decoder']['mean_dB']:.2e} "
+                  f"max {s['end_to_end_with_this_decoder']['max_dB']:.2e}")
+        assert m["final_latent_max_abs_delta"] < 2e-5
+        assert e2e["mean_dB"] < 5e-4 and e2e["max_dB"] < 1e-3, e2e
+        assert same["mean_dB"] < 5e-4 and same["max_dB"] < 1e-3, same

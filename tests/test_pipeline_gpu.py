@@ -239,7 +239,7 @@ def test_k1024_vs_reference_and_renderer_config():
     # the FULL-SIZE leg of configs[2] (B = 64 x 1024 tokens; two of the 50 sampler steps keep the test short): same per-image results
     # as the B = 2 call up to GEMM-tiling noise, in both arithmetics
     tok64 = p.encoding(synth.synthetic_images(64, device="cuda"))
-    assert tuple(tok64.shape) == (64, 1024) and float((tok64[:2] == tok).float().mean()) >= 0.99
+    assert tuple(tok64.shape) == (64, 1024) and torch.equal(tok64[:2], tok)      # the exact-order encoder is batch invariant: B = 2 and B = 64 give the same ids
     ids64 = tok64.cpu().numpy()
     ids64[:2] = tok.cpu().numpy()
     for gemm in ("fp32", "f16x2"):
