@@ -309,6 +309,28 @@ int selftok_vx_attention_bf16(const void* q, const void* k, const void* v, void*
 /* glibc's expf (what `std::exp(float)` evaluates inside the flash kernel), element-wise; exposed for the parity tests. */
 int selftok_vx_expf_f32(const float* x, float* y, long n, hipStream_t stream);
 
+/* ---- fp32 Linear on the fp32-input matrix cores, both operands staged by LDS-DMA (round 6; csrc/gemm_fp32.hip) ----
+ * out[m][n] = epilogue(sum_k x[m][k] w[n][k]): nn.Linear / F.linear of the MMDiT joint blocks (mimogpt/models/selftok/sd3/mmdit.py:266-307 qkv / proj,
+ * :413-419 + sd3/other_impls.py:82-90 Mlp fc1 / fc2) and the wide Linears of the Q-Former (modules.py:186-199, 293).  x rows at stride ldx (16-byte aligned),
+ * w [N][K] contiguous, N % 128 == 0, K % 32 == 0.  flags:
+ *   SELFTOK_LINEAR_MKL_ORDER  the summation order of torch-CPU's MKL sgemm (K <= 384 or K >= 768: sequential fmaf chains per K-block of 384,
+ *                             out = ((bias + c0) + c1) + ...): bit-identical to selftok_ex_linear_f32, the kernel of gemm='exact'.  Without it the order is
+ *                             free: ONE k-ascending chain per output over the whole K (tail tiles: a few, see below), bias added last -- the kernel of gemm='fp32'
+ *                             where it beats the library's.
+ *   SELFTOK_LINEAR_GELU       out = GELU_tanh(out), ATen / Sleef arithmetic (as SELFTOK_EX_GELU)
+ *   SELFTOK_LINEAR_BIAS_LAST  as SELFTOK_EX_BIAS_LAST
+ *   SELFTOK_LINEAR_SPLIT(n)   tools / tests: force the tail split to n units (0: planned)
+ * res / gate / res_mod / gate_mod / aliasing: as selftok_ex_linear_f32.
+ * workspace: the tiles left over after the last full round of 256 workgroups are computed as several K-range units whose raw sums go through
+ * `workspace` and are added in K order by a second kernel (MKL order: one plane per K-block, so the result is unchanged bit for bit).  NULL / too small:
+ * no split (correct, the tail round then runs at partial occupancy).  selftok_linear_f32_workspace_bytes = the most any plan for the shape takes. */
+#define SELFTOK_LINEAR_BIAS_LAST 2
+#define SELFTOK_LINEAR_MKL_ORDER 4
+#define SELFTOK_LINEAR_SPLIT(n) (((n) & 0xFF) << 8)
+size_t selftok_linear_f32_workspace_bytes(long M, int N, int K, int flags);
+int selftok_linear_f32(const float* x, long ldx, const float* w, const float* bias, const float* res, long ldr, int res_mod, const float* gate, long ldg,
+                       int gate_mod, float* out, long ldo, long M, int N, int K, int flags, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 /* ---- the fp32 Q-Former encoder in the reference's exact summation orders (round 5; csrc/encoder_exact.hip, CPU twin oracle/encoder_exact.c) ----
  * Replaces, bit for bit, what torch-CPU executes for `Encoder.forward` (mimogpt/models/selftok/models_ours.py:204-257, 315-343) and
  * `DualBlock` / `DualAttention` (modules.py:165-327): every nn.Linear / F.linear (MKL sgemm: sequential fmaf chains per K-block of 384,

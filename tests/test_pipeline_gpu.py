@@ -87,7 +87,7 @@ def _decoding_vs_reference(pipe):
     for j, step in enumerate(g["lat_steps"]):          # golden lats[j] = DiT input at step `step` = latent after `step` Euler steps
         err = float((trace[int(step) - 1].cpu() - torch.from_numpy(g["lats"][j])).abs().max())
         print(f"latent after {int(step)} steps: max abs err {err:.3e}")
-        assert err < 5e-3
+        assert err < 2e-5                  # measured (round 6): 2.4e-7 after one step .. 2.4e-6 after 49, both arithmetics
     ref = torch.from_numpy(g["rec_bf16"]).view(torch.bfloat16).float()
     mse = float(((rec.float().cpu() - ref) ** 2).mean())
     psnr = 10 * np.log10(1.0 / max(mse, 1e-12))
@@ -102,7 +102,7 @@ def _decoding_vs_reference(pipe):
     # 2.2e-3 dB here (MIOpen solver search + a separate bf16 bias add per convolution) under a 5e-3 gate; with the bias inside the
     # accumulation and the deterministic GEMM algorithm (vae.py) it is bit-stable from run to run and 16 images give mean 2.9e-4 /
     # max 8.8e-4 dB -- the spread between two CPU implementations of the same decoder is 3.9e-4 / 1.09e-3 (test_parity16_gpu.py)
-    assert abs(p_ref - p_our) < 2e-3
+    assert abs(p_ref - p_our) < 1e-3       # the north star's bound (measured: 4.8e-4 fp32, 2.6e-4 f16x2, parity decoder)
     # ... and the north star's 1e-3 dB criterion is checked where it is meaningful: the reference's latent and ours (both after
     # 49 of the 50 steps) through the SAME decoder in ONE batch, so that only the latent difference remains.
     both = torch.cat([torch.from_numpy(g["lats"][-1]).cuda(), trace[int(g["lat_steps"][-1]) - 1]])
@@ -110,7 +110,7 @@ def _decoding_vs_reference(pipe):
     q_ref = 10 * np.log10(1.0 / float(((px[0:1] - orig) ** 2).mean()))
     q_our = 10 * np.log10(1.0 / float(((px[1:2] - orig) ** 2).mean()))
     print(f"same-decoder PSNR vs original: reference latent {q_ref:.6f} dB, our latent {q_our:.6f} dB, delta {abs(q_ref - q_our):.2e} dB")
-    assert abs(q_ref - q_our) < 1.5e-3     # the metric's floor for latents that differ by 2e-6 is ~1e-3 dB on single images (test_parity16_gpu.py prints it)
+    assert abs(q_ref - q_our) < 1e-3       # the north star's bound (measured 1.4e-4; the metric's floor for latents that differ by 2e-6 reaches ~1e-3 dB on single images)
 
 
 def test_decode_is_deterministic_and_batch_independent(pipe):
@@ -220,7 +220,9 @@ def test_k1024_vs_reference_and_renderer_config():
     _, ids = p.model.encoder(x0, d=None)
     mism = ids.cpu().numpy() != g["ids"]
     print(f"K=1024 encoder z max abs err vs reference {err:.3e}; id mismatches {int(mism.sum())} / 1024, gaps {g['gap'][mism]}")
-    assert err < 3e-4 and mism.sum() <= 1 and (g["gap"][mism] < 2e-4).all()
+    # the golden is the reference's B = 1 run, whose MKL path differs from its B >= 8 runs (PINNING.json: encode64): the exact-order encoder reproduces the
+    # B >= 8 bits (test_dit_exact_gpu.py::test_k1024_tokenizer_equals_the_reference_at_16_images: 0 bits), against B = 1 it measures 2.1e-6 and 0 flipped ids
+    assert err < 2e-5 and int(mism.sum()) == 0
     x = synth.synthetic_noise(1, first_index=5, device="cuda")
     t = torch.full((1,), float(g["t"]), device="cuda")
     mask = torch.arange(1024, device="cuda")[None] <= int(g["k"])
@@ -230,7 +232,7 @@ def test_k1024_vs_reference_and_renderer_config():
         v, _ = p.model.model(x, t, encoder_hidden_states=ehs, mask=mask, context_see_xt=True)
         e = float((v.cpu() - torch.from_numpy(g["v"])).abs().max())
         print(f"K=1024 MMDiT.forward (k={int(g['k'])}) [{gemm}] max abs err vs reference {e:.3e}")
-        assert e < 1e-4
+        assert e < 5e-5                    # measured 1.5e-5 in both arithmetics
     p.set_gemm("fp32")
     tok = p.encoding(synth.synthetic_images(2))
     assert tuple(tok.shape) == (2, 1024)
