@@ -7,22 +7,28 @@
 // sequential fmaf chain per K-block of 384, out = ((bias + c0) + c1) + ... -- and (b) in gemm='fp32' the Linears for which hipBLASLt's kernels run at 0.79 - 0.90
 // of that peak (qkv, proj): there the order is free and the whole K is ONE chain per output.
 //
-// Design (why it is not xe_gemm128 with other constants):
+// Design:
 //   * v_mfma_f32_32x32x1_2b_f32: one k per instruction and TWO 32 x 32 blocks.  A lane supplies A[row 32 h + i][k] and B[col i][k] (h = lane / 32, i = lane % 32):
 //     the two blocks are the two row halves of a 64-row wave tile.  An fp32-input MFMA is fma(a, b, acc) per output, bit for bit (csrc/vq.hip, round 1), so a
 //     k-ascending instruction stream IS the sequential chain -- with the operands in their NATURAL row-major order.  The 32x32x2 form xe_gemm128 uses wants the even
 //     and the odd k of a row in different lane halves: a de-interleave while staging = global -> VGPR -> 8 v_mov -> ds_write_b128, on the VALU port the fp32 MFMAs
 //     share.  With the natural order a 16-byte piece of a row is what a lane needs as it lies in memory, so
 //   * both operand tiles reach LDS by `global_load_lds_dwordx4` (1 KiB = 8 rows x 128 bytes per wave instruction; uniform SGPR base + one constant per-lane offset
-//     register per piece; the 16-byte chunks of a row XOR-swizzled on the SOURCE side so that every ds_read_b128 lane group covers all 64 banks once): no staging
-//     registers, no ds_write, no VALU in the k-loop besides the K-block fold.
-//   * workgroup = 8 waves = 256 x 128 outputs (wave: 64 x 64 = two 2-block accumulators, 64 VGPRs), 32-k chunks, THREE stages of 48 KiB (144 of the CU's 160 KiB):
-//     chunk c + 2 is in flight while chunk c computes; one barrier per chunk = per 64 MFMAs (4096 matrix cycles) per wave.
-//   * XCD-aware 1-D tile order (bands of 4 row tiles: the 32 workgroups resident on an XCD cover 4 x 8 tiles = 4 A + 8 B operand tiles per chunk round).
-//   * the TAIL ROUND is split along K: the tiles left over after the last full round of 256 workgroups (proj: 4.2 rounds -> 5 at 0.84 efficiency, the figure
-//     hipBLASLt's proj sits at too) are computed as S units of 1 / S of the K range each, raw partial sums to a workspace, and a small second kernel adds
-//     the planes IN ORDER and runs the epilogue.  In MKL order a unit is a whole number of K-blocks and writes one plane per K-block, so the result is still
-//     ((bias + c0) + c1) + ... bit for bit; in free order a unit writes one plane.
+//     register per piece; the 16-byte chunks of a row XOR-swizzled on the SOURCE side so that every ds_read_b128 lane group covers all 64 banks once: 0 bank
+//     conflicts in the PMC pass): no staging registers, no ds_write, no VALU in the k-loop besides the K-block fold.
+//   * workgroup = FOUR compute waves = 128 x 128 outputs (wave: 64 x 64 = two 2-block accumulators, 64 VGPRs) + TWO LOADER waves (one issues the A tile's 16 DMA
+//     pieces of a chunk, the other the B tile's), 32-k chunks, two stages of 32 KiB -> TWO INDEPENDENT workgroups per CU.  A DMA piece costs the ISSUING wave 60 - 180
+//     cycles during which its MFMA stream pauses: with the pieces spread over the compute waves the kernel lost 6 - 8 % to them wherever they were placed
+//     (profiles/r6_sgemm_v3*.txt: "no DMA" 0.88 / 0.94, "DMA issued, waits removed" = the product); loader waves never touch the matrix pipe.  What the measurements of the first versions said (profiles/r6_sgemm_v2_*.txt, r6_mfma_f32_forms.txt):
+//     one 8-wave 256 x 128 workgroup per CU ran at 0.80 (K = 1536) / 0.87 (K = 6144) of the peak whether its two waves per SIMD stood at the chunk barrier together
+//     or half a chunk apart; the chip holds 2.39 GHz under this load and a bare MFMA + fragment-read + barrier loop reaches 0.92; without DMA and barriers the kernel
+//     still stopped at 0.86 / 0.93 -- the missing part is PER TILE, not per chunk: ~30 k cycles of prologue (first DMA round trip), epilogue (64 outputs per lane)
+//     and workgroup turnover during which a CU that holds ONE workgroup has nothing to issue.  Two independent workgroups cover each other's prologue, epilogue,
+//     barrier and DMA waits with no software at all (the library's kernel does it with one wave per SIMD and a hand-scheduled stream).
+//   * XCD-aware 1-D tile order (bands of 8 row tiles: the 64 workgroups resident on an XCD cover 8 x 8 tiles = 8 A + 8 B operand tiles per chunk round).
+//   * the TAIL ROUND is split along K: the tiles left over after the last full round of 512 workgroups are computed as S units of 1 / S of the K range each, raw
+//     partial sums to a workspace, and a small second kernel adds the planes IN ORDER and runs the epilogue.  In MKL order a unit is ONE K-block (S = the number of
+//     K-blocks), its plane the block's chain, so the result is still ((bias + c0) + c1) + ... bit for bit; in free order a unit is 1 / S of the chunks.
 //
 // Epilogue (both kernels): [+ bias last] -> [GELU(tanh), Sleef arithmetic] -> [gate * y] -> [res + y], each separately rounded (-ffp-contract=off), the
 // operation sequence of csrc/encoder_exact.hip's epilogue.
@@ -32,16 +38,26 @@
 
 #include <type_traits>
 
+#pragma clang diagnostic ignored "-Winline-asm"      // M0 on the clobber list of the LDS-DMA statement is deliberate (sg_dma16)
+
+// tools builds only (-DSG_ABL=n, tools/ablate_sgemm.sh): timing-only ablations of the k-loop -- 1: no DMA (no issue, no vmcnt waits), 2: DMA issued, vmcnt waits
+// removed, 3: no DMA and no barriers, 4: DMA + waits + barriers but no fragment reads (operands stay what the first piece held).  Results are garbage.
+#ifndef SG_ABL
+#define SG_ABL 0
+#endif
+
 namespace selftok {
 
 typedef float sg_f32x32 __attribute__((ext_vector_type(32)));
 typedef float sg_f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SG_BM = 256, SG_BN = 128, SG_BK = 32;
-constexpr int SG_A_BYTES = SG_BM * SG_BK * 4;                 // 32 KiB
-constexpr int SG_STAGE = (SG_BM + SG_BN) * SG_BK * 4;         // 48 KiB
-constexpr int SG_STAGES = 3;
+constexpr int SG_BM = 128, SG_BN = 128, SG_BK = 32;
+constexpr int SG_A_BYTES = SG_BM * SG_BK * 4;                 // 16 KiB
+constexpr int SG_STAGE = (SG_BM + SG_BN) * SG_BK * 4;         // 32 KiB
+constexpr int SG_STAGES = 2;
 constexpr int SG_PLANE = SG_BM * SG_BN;                       // floats per workspace plane
+constexpr int SG_THREADS = 384;                               // 4 compute waves + 2 loader waves
+constexpr int SG_ROUND = 64;                                  // workgroups resident per XCD: 32 CUs x 2
 
 struct SgArgs {
     const float* a; long lda;                   // x [M][K], row stride lda (floats, multiple of 4)
@@ -50,21 +66,22 @@ struct SgArgs {
     const float* bias;
     const float* res; long ldr; int res_mod;    // y = res[row(m, res_mod)][n] + (gate ? gate * y : y); row(m, d) = m % d (d > 0), m / -d (d < 0), m (0)
     const float* gate; long ldg; int gate_mod;
-    float* ws;                                  // tail planes: [xcd][tail tile][plane][256][128]
+    float* ws;                                  // tail planes: [xcd][tail tile][plane][128][128]
     int M, N, K;
     int gelu, bias_last;
     int mt, nt, tiles, per;                     // tile grid; per = ceil(tiles / 8) list entries per XCD
     int full_pos, tail_cnt, split, planes;      // entries < full_pos of every XCD's list: full tiles; the next tail_cnt: `split` units each; planes per tail tile
-    int blk_chunks;                             // MKL order: K-block length in chunks (12 = 384 / 32); free order: K / 32 (one block)
+    int blk_chunks;                             // MKL order: K-block length in chunks (12 = 384 / 32); free order: chunks per unit (K / 32 when nothing is split)
     int nchunks;                                // K / 32
+    int flat_prio;                              // tools: keep the raised priority through the k-loop
 };
 
-// list entry `sidx` (0 .. tiles-1) -> (row tile, column tile): bands of 4 row tiles, inside a band column tile by column tile
+// list entry `sidx` (0 .. tiles-1) -> (row tile, column tile): bands of 8 row tiles, inside a band column tile by column tile
 __host__ __device__ inline void sg_tile_of(int sidx, int MT, int NT, int& tm, int& tn)
 {
-    const int full = MT >> 2, rem = MT & 3, cut = full * 4 * NT;
-    if (sidx < cut) { const int band = sidx / (4 * NT), r = sidx - band * 4 * NT; tn = r >> 2; tm = band * 4 + (r & 3); }
-    else { const int r = sidx - cut; tn = r / rem; tm = full * 4 + (r - tn * rem); }
+    const int full = MT >> 3, rem = MT & 7, cut = full * 8 * NT;
+    if (sidx < cut) { const int band = sidx / (8 * NT), r = sidx - band * 8 * NT; tn = r >> 3; tm = band * 8 + (r & 7); }
+    else { const int r = sidx - cut; tn = r / rem; tm = full * 8 + (r - tn * rem); }
 }
 
 __device__ __forceinline__ void sg_dma16(const void* base, unsigned voff, unsigned lds)
@@ -83,11 +100,19 @@ __device__ __forceinline__ float sg_epilogue(const SgArgs& g, float v, int m, in
 }
 
 template <bool MKL>
-__global__ __launch_bounds__(512) void sg_gemm_kernel(SgArgs g)
+__global__ __launch_bounds__(SG_THREADS, 3) void sg_gemm_kernel(SgArgs g)
 {
     __shared__ __attribute__((aligned(1024))) char lds[SG_STAGES * SG_STAGE];
+    __shared__ int rowidx[2][SG_BM];           // epilogue: row of the gate / res table for every row of the tile (one integer division per row, not per output)
+    // Issue arbitration on a SIMD is by priority, then AGE: the older of the two workgroups of a CU issues its MFMAs back to back and the younger one gets the
+    // leftover slots -- for its prologue's VALU work (fp32 MFMAs and VALU share the port) that is almost none: measured, a workgroup lived 195 us of which 92 in its
+    // k-loop, the loops of the two workgroups of a CU never overlapped, and 9 us passed between the end of one loop and the start of the other
+    // (profiles/r6_sgemm_v4_stamps_census.txt).  So: the prologue and the loader waves run at raised priority (they are short and the DMA round trip they start is
+    // what the next loop waits for), the k-loop at priority 0 -- the younger workgroup then stands at its first MFMA with its first chunk landed when the older one
+    // leaves its loop.
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = wave & 1, wn = (wave >> 1) & 1;
     const int i = lane & 31, h = lane >> 5;
 
     // ---- which tile, which part of K ----
@@ -100,9 +125,8 @@ __global__ __launch_bounds__(512) void sg_gemm_kernel(SgArgs g)
             te = u / g.split;
             unit = u - te * g.split;
             e = g.full_pos + te;
-            const int per_unit = ((g.nchunks + g.blk_chunks - 1) / g.blk_chunks + g.split - 1) / g.split * g.blk_chunks;      // whole K-blocks per unit (free order: blk_chunks = chunks per unit)
-            c0 = unit * per_unit;
-            c1 = min(c0 + per_unit, g.nchunks);
+            c0 = unit * g.blk_chunks;                  // a unit = ONE K-block (MKL order: 12 chunks; free order: blk_chunks = nchunks / split)
+            c1 = min(c0 + g.blk_chunks, g.nchunks);
         }
         const int sidx = xcd * g.per + e;
         if (e >= g.per || sidx >= g.tiles || c0 >= c1) return;
@@ -113,33 +137,69 @@ __global__ __launch_bounds__(512) void sg_gemm_kernel(SgArgs g)
     c0 = __builtin_amdgcn_readfirstlane(c0); c1 = __builtin_amdgcn_readfirstlane(c1);
     unit = __builtin_amdgcn_readfirstlane(unit); te = __builtin_amdgcn_readfirstlane(te);
     const int row0 = tm * SG_BM, col0 = tn * SG_BN;
-
-    // ---- staging: wave w issues pieces w, w + 8, ..., w + 40 of a chunk (pieces 0..31 = A rows 8 p .. 8 p + 7, pieces 32..47 = B rows) ----
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)&lds[0];
-    const int pr = lane >> 3, pc = lane & 7;                                  // row inside a piece, 16-byte position inside the 128-byte row
-    const int psw = ((wave & 1) << 2) | (pr >> 1);                            // (tile row >> 1) & 7 of this lane's row, the same for all six pieces (p = w mod 8)
-    unsigned voa[4], vob[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (wave + 8 * j) * 8 + pr;
-        const int rg = min(row0 + r, g.M - 1) - row0;                         // ragged last row tile: fetch the matrix's last row instead (never stored)
-        voa[j] = (unsigned)rg * (unsigned)g.lda * 4u + (unsigned)((pc ^ psw) << 4);
+    const int nch = c1 - c0;
+    if (tid < SG_BM && unit < 0 && (g.gate != nullptr || g.res != nullptr)) {        // visible to everyone after the first chunk barrier
+        const int m = min(row0 + tid, g.M - 1);
+        rowidx[0][tid] = g.gate_mod > 0 ? m % g.gate_mod : (g.gate_mod < 0 ? m / -g.gate_mod : m);
+        rowidx[1][tid] = g.res_mod > 0 ? m % g.res_mod : (g.res_mod < 0 ? m / -g.res_mod : m);
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) vob[j] = (unsigned)((wave + 8 * j) * 8 + pr) * (unsigned)g.K * 4u + (unsigned)((pc ^ psw) << 4);
-    const char* abase = reinterpret_cast<const char*>(g.a + (size_t)row0 * g.lda);
-    const char* bbase = reinterpret_cast<const char*>(g.b + (size_t)col0 * g.K);
-    auto issue = [&](int chunk, int stage) {
-        const char* ab = abase + (size_t)chunk * (SG_BK * 4);
-        const char* bb = bbase + (size_t)chunk * (SG_BK * 4);
-        const unsigned l = lds0 + stage * SG_STAGE + wave * 1024;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sg_dma16(ab, voa[j], l + j * 8192);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) sg_dma16(bb, vob[j], l + SG_A_BYTES + j * 8192);
-    };
+#ifdef SG_STAMP
+    // tools: s_memtime at [before barrier, after barrier, after the chunk's MFMAs were issued] of the first 40 chunks, waves 0 (compute) and 4 (loader) of the
+    // workgroups at list positions 256 and 288 of XCD 0 (two workgroups of the fifth round: every CU holds two by then) -> g.ws as u64 [wg 2][wave 2][chunk 40][3]
+    unsigned long long* stamp = nullptr;
+    if (xcd == 0 && (pos == 256 || pos == 288) && (wave == 0 || wave == 4) && lane == 0)
+        stamp = reinterpret_cast<unsigned long long*>(g.ws) + ((pos == 288 ? 1 : 0) * 2 + (wave ? 1 : 0)) * 120;
+#define SG_TS(kc, j) do { if (stamp && (kc) < 40) stamp[(kc) * 3 + (j)] = __builtin_readcyclecounter(); } while (0)
+    // residency census: every workgroup's (start, end) in 100 MHz ticks and where it ran -> u64 [blockIdx][3] behind the first 8 KiB
+    struct SgCensus {
+        unsigned long long* p; unsigned long long t0;
+        __device__ SgCensus(unsigned long long* q) : p(q), t0(__builtin_amdgcn_s_memrealtime()) {}
+        __device__ ~SgCensus() {
+            if (!p) return;
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            p[0] = t0; p[1] = __builtin_amdgcn_s_memrealtime(); p[2] = ((unsigned long long)(xcc & 0xF) << 32) | hw;
+        }
+    } census((tid == 0 && blockIdx.x < 16384) ? reinterpret_cast<unsigned long long*>(g.ws) + 1024 + 3 * blockIdx.x : nullptr);
+#else
+#define SG_TS(kc, j) do { } while (0)
+#endif
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)&lds[0];
 
-    // ---- fragment addresses: A row 64 wm + lane, B rows 64 wn + 32 t + i; chunk q of a row sits at position q ^ ((lane >> 1) & 7) ----
+    if (wave >= 4) {
+        // ---- the two LOADER waves: wave 4 stages the A tile, wave 5 the B tile, 16 pieces of 8 rows x 128 bytes per chunk each.  They never touch the matrix
+        // pipe; the compute waves never issue a VMEM instruction.  Per chunk: [chunk kc landed] -> barrier kc -> issue chunk kc + 1 into the other stage (every
+        // compute wave finished reading chunk kc - 1 before it arrived at barrier kc). ----
+        const bool isA = wave == 4;
+        const char* base = isA ? reinterpret_cast<const char*>(g.a + (size_t)row0 * g.lda) : reinterpret_cast<const char*>(g.b + (size_t)col0 * g.K);
+        const unsigned rs = (unsigned)(isA ? g.lda : (long)g.K) * 4u;
+        const int rlast = isA ? g.M - 1 - row0 : SG_BN - 1;                      // ragged last row tile: fetch the matrix's last row instead (never stored)
+        const int pr = lane >> 3, pc = lane & 7;                                  // row inside a piece, 16-byte position inside the 128-byte row
+        const unsigned swz0 = (unsigned)((pc ^ (pr >> 1)) << 4), swz1 = (unsigned)((pc ^ (4 | (pr >> 1))) << 4);      // chunk (pc ^ ((tile row >> 1) & 7)): even / odd pieces
+        auto issue = [&](int chunk, int stage) {
+            if (SG_ABL == 1 || SG_ABL == 3) return;
+            const char* cb = base + (size_t)chunk * (SG_BK * 4);
+            const unsigned l = lds0 + stage * SG_STAGE + (isA ? 0 : SG_A_BYTES);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int rg = min(8 * p + pr, rlast);
+                sg_dma16(cb, (unsigned)rg * rs + ((p & 1) ? swz1 : swz0), l + p * 1024);
+            }
+        };
+        issue(c0, 0);
+        for (int kc = 0; kc < nch; ++kc) {
+            if (SG_ABL != 1 && SG_ABL != 2 && SG_ABL != 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SG_TS(kc, 0);
+            if (SG_ABL != 3) __syncthreads();
+            SG_TS(kc, 1);
+            if (kc + 1 < nch) issue(c0 + kc + 1, (kc + 1) & 1);
+            SG_TS(kc, 2);
+        }
+        return;
+    }
+
+    // ---- the four COMPUTE waves.  Fragment addresses: A row 64 wm + lane, B rows 64 wn + 32 t + i; chunk q of a row sits at position q ^ ((lane >> 1) & 7) ----
     const int sw16 = ((lane >> 1) & 7) << 4;
     const int a_row = (64 * wm + lane) * 128 + sw16;
     const int b_row = SG_A_BYTES + (64 * wn + i) * 128 + sw16;
@@ -159,33 +219,27 @@ __global__ __launch_bounds__(512) void sg_gemm_kernel(SgArgs g)
         }
     }
 
-    // a unit of a tail tile writes its raw K-block sums (MKL order: one plane per K-block; free order: one plane) to the workspace
-    float* wsp = g.ws + ((size_t)(xcd * g.tail_cnt + te) * g.planes) * SG_PLANE;
-    auto write_plane = [&](int plane) {
-        float* p = wsp + (size_t)plane * SG_PLANE;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    p[(64 * wm + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h) * SG_BN + 64 * wn + 32 * t + i] = acc[t][16 * b + r];
+    // ---- the k-loop: per chunk barrier (the chunk has landed, says the loaders' vmcnt(0) in front of it) -> 8 x (3 fragment reads of the next 4 k, 8 MFMAs) ----
+    int cb = 0;
+    sg_f32x4 va, vb0, vb1;
+    if (!g.flat_prio) __builtin_amdgcn_s_setprio(0);
+    auto ldq = [&](const char* la, int q, sg_f32x4& a, sg_f32x4& b0, sg_f32x4& b1) {
+        if (SG_ABL == 4 && q > 0) return;
+        a = *reinterpret_cast<const sg_f32x4*>(la + (a_row ^ (q << 4)));
+        b0 = *reinterpret_cast<const sg_f32x4*>(la + (b_row ^ (q << 4)));
+        b1 = *reinterpret_cast<const sg_f32x4*>(la + (b_row ^ (q << 4)) + 4096);
     };
-
-    auto compute = [&](auto STAGE) {
-        constexpr int st = decltype(STAGE)::value * SG_STAGE;
-        const char* la = lds + st;
-        sg_f32x4 va = *reinterpret_cast<const sg_f32x4*>(la + (a_row ^ 0));
-        sg_f32x4 vb0 = *reinterpret_cast<const sg_f32x4*>(la + (b_row ^ 0));
-        sg_f32x4 vb1 = *reinterpret_cast<const sg_f32x4*>(la + (b_row ^ 0) + 4096);
+    auto body = [&](int kc, auto STAGE) {
+        constexpr int s = decltype(STAGE)::value;
+        const char* la = lds + s * SG_STAGE;
+        SG_TS(kc, 0);
+        if (SG_ABL != 3) __syncthreads();
+        SG_TS(kc, 1);
+        ldq(la, 0, va, vb0, vb1);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             sg_f32x4 na = va, nb0 = vb0, nb1 = vb1;
-            if (q < 7) {                               // register double buffer over the eight 4-k pieces: piece q + 1 is read while piece q's 8 MFMAs issue
-                na = *reinterpret_cast<const sg_f32x4*>(la + (a_row ^ ((q + 1) << 4)));
-                nb0 = *reinterpret_cast<const sg_f32x4*>(la + (b_row ^ ((q + 1) << 4)));
-                nb1 = *reinterpret_cast<const sg_f32x4*>(la + (b_row ^ ((q + 1) << 4)) + 4096);
-            }
+            if (q < 7) ldq(la, q + 1, na, nb0, nb1);         // register double buffer over the 4-k pieces: piece q + 1 is read while piece q's 8 MFMAs issue
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x1f32(va[e], vb0[e], acc[0], 0, 0, 0);
@@ -193,57 +247,75 @@ __global__ __launch_bounds__(512) void sg_gemm_kernel(SgArgs g)
             }
             va = na; vb0 = nb0; vb1 = nb1;
         }
-    };
-
-    const int nch = c1 - c0;
-    int cb = 0, plane = (unit < 0 || !MKL) ? 0 : c0 / g.blk_chunks;
-    issue(c0, 0);
-    if (nch > 1) issue(c0 + 1, 1);
-    auto body = [&](int kc, auto STAGE) {
-        constexpr int s = decltype(STAGE)::value;
-        if (kc + 1 < nch) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // my six pieces of chunk kc have landed (chunk kc + 1's may still fly)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                                          // everyone's have; and the stage chunk kc + 2 goes to (read in iteration kc - 1) is free
-        if (kc + 2 < nch) issue(c0 + kc + 2, (s + 2) % SG_STAGES);
-        compute(STAGE);
-        if (MKL && (++cb == g.blk_chunks || kc + 1 == nch)) {                     // K-block done: C += chain, the next chain starts from 0
+        SG_TS(kc, 2);
+        if (MKL && unit < 0 && (++cb == g.blk_chunks || kc + 1 == nch)) {         // K-block done: C += chain, the next chain starts from 0 (a tail unit IS one K-block)
             cb = 0;
-            if (unit >= 0) { write_plane(plane); ++plane; }
-            else {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 32; ++r) C[t][r] = C[t][r] + acc[t][r];
-            }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 32; ++r) acc[t][r] = 0.f;
+                for (int r = 0; r < 32; ++r) { C[t][r] = C[t][r] + acc[t][r]; acc[t][r] = 0.f; }
         }
     };
-    for (int kc = 0; kc < nch; kc += 3) {
+    for (int kc = 0; kc < nch; kc += 2) {
         body(kc, std::integral_constant<int, 0>{});
         if (kc + 1 < nch) body(kc + 1, std::integral_constant<int, 1>{});
-        if (kc + 2 < nch) body(kc + 2, std::integral_constant<int, 2>{});
     }
     if (unit >= 0) {
-        if (!MKL) write_plane(unit);
+        // a unit of a tail tile: its raw sum (MKL order: K-block `unit`; free order: chunks c0 .. c1) goes to plane `unit` of the tile's workspace slot
+        float* p = g.ws + ((size_t)(xcd * g.tail_cnt + te) * g.planes + unit) * SG_PLANE;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    p[(64 * wm + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h) * SG_BN + 64 * wn + 32 * t + i] = acc[t][16 * b + r];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         return;
     }
 
-    // ---- epilogue: lane (col = 64 wn + 32 t + i, rows 64 wm + 32 b + (r & 3) + 8 (r >> 2) + 4 h) ----
+    // ---- epilogue: lane (col = 64 wn + 32 t + i, rows 64 wm + 32 b + (r & 3) + 8 (r >> 2) + 4 h).  The epilogue's VALU work shares the SIMD with the other
+    // workgroup's MFMAs (they do not overlap: same port), so it is kept short: uniform decisions hoisted, row addresses scalar (row base in SGPRs + one
+    // per-lane offset), the table rows of gate / res looked up in LDS. ----
+    __builtin_amdgcn_s_setprio(3);
+    const bool plain = !g.gelu && g.gate == nullptr && g.res == nullptr && !(g.bias_last && g.bias != nullptr);
+    const bool whole = row0 + SG_BM <= g.M;
+    const int ncol = col0 + 64 * wn + i;
+    if (plain && whole) {
+        const size_t loff = (size_t)(4 * h) * g.ldc + ncol;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float bfree = (!MKL && g.bias != nullptr) ? g.bias[ncol + 32 * t] : 0.f;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* rowp = g.c + (size_t)(row0 + 64 * wm + 32 * b + (r & 3) + 8 * (r >> 2)) * g.ldc;       // uniform: SGPR pair
+                    rowp[loff + 32 * t] = MKL ? C[t][16 * b + r] : acc[t][16 * b + r] + bfree;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        return;
+    }
+    const bool has_gate = g.gate != nullptr, has_res = g.res != nullptr, bias_l = g.bias_last && g.bias != nullptr, gelu = g.gelu != 0;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int n = col0 + 64 * wn + 32 * t + i;
+        const int n = ncol + 32 * t;
         const float bfree = (!MKL && g.bias != nullptr && !g.bias_last) ? g.bias[n] : 0.f;
+        const float blast = bias_l ? g.bias[n] : 0.f;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = row0 + 64 * wm + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= g.M) continue;
+                const int ml = 64 * wm + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h, m = row0 + ml;
+                if (!whole && m >= g.M) continue;
                 float v = MKL ? C[t][16 * b + r] : acc[t][16 * b + r] + bfree;
-                g.c[(size_t)m * g.ldc + n] = sg_epilogue(g, v, m, n);
+                if (bias_l) v = v + blast;
+                if (gelu) v = xe_gelu_tanh1(v);
+                if (has_gate) v = g.gate[(size_t)rowidx[0][ml] * g.ldg + n] * v;
+                if (has_res) v = g.res[(size_t)rowidx[1][ml] * g.ldr + n] + v;
+                g.c[(size_t)m * g.ldc + n] = v;
                 __builtin_amdgcn_sched_barrier(0);          // one output at a time: the unrolled epilogue must not set the kernel's register count
             }
     }
@@ -259,7 +331,7 @@ __global__ __launch_bounds__(256) void sg_tail_finish_kernel(SgArgs g)
     if (e >= g.per || sidx >= g.tiles) return;
     int tm, tn;
     sg_tile_of(sidx, g.mt, g.nt, tm, tn);
-    const int idx = blockIdx.x * 256 + threadIdx.x;     // 0 .. 256 * 32 - 1
+    const int idx = blockIdx.x * 256 + threadIdx.x;     // 0 .. 128 * 32 - 1
     const int r = idx >> 5, c4 = (idx & 31) << 2;
     const int m = tm * SG_BM + r;
     if (m >= g.M) return;
@@ -282,7 +354,7 @@ __global__ __launch_bounds__(256) void sg_tail_finish_kernel(SgArgs g)
     *reinterpret_cast<sg_f32x4*>(g.c + (size_t)m * g.ldc + n) = o;
 }
 
-// The launch plan (host): tile list split over the 8 XCDs, full rounds of 32 workgroups per XCD, the tail round split along K.
+// The launch plan (host): tile list split over the 8 XCDs, full rounds of 64 workgroups per XCD (two per CU), the tail round split along K.
 struct SgPlan { int mt, nt, tiles, per, full_pos, tail_cnt, split, planes, blk_chunks, nchunks; size_t ws_bytes; };
 
 static SgPlan sg_plan(long M, int N, int K, bool mkl, size_t ws_avail, int force_split)
@@ -292,21 +364,21 @@ static SgPlan sg_plan(long M, int N, int K, bool mkl, size_t ws_avail, int force
     p.nchunks = K / SG_BK;
     const int nblk = mkl ? (p.nchunks + 11) / 12 : 1;
     p.blk_chunks = mkl ? 12 : p.nchunks;
-    p.full_pos = p.per / 32 * 32; p.tail_cnt = p.per - p.full_pos; p.split = 1; p.planes = 1;
+    p.full_pos = p.per / SG_ROUND * SG_ROUND; p.tail_cnt = p.per - p.full_pos; p.split = 1; p.planes = 1;
     if (p.tail_cnt == 0) return p;
-    // cost of the tail in tile times: ceil(tail_cnt * S / 32) rounds of 1 / S each (+ ~4 % per unit for its pipeline fill, plane write and the finish pass)
+    // cost of the tail in tile times: ceil(tail_cnt * S / 64) rounds of 1 / S each (+ ~4 % per unit for its pipeline fill, plane write and the finish pass).
+    // MKL order: a unit is ONE K-block (S = the number of K-blocks: the planes are the blocks, added in order by the finish kernel)
     int best = 1; double bc = 1.0;
-    const int smax = mkl ? nblk : (p.nchunks < 8 ? p.nchunks : 8);
-    for (int S = 2; S <= smax; ++S) {
-        if (mkl ? (nblk % S != 0) : (p.nchunks % S != 0)) continue;
-        const size_t ws = (size_t)8 * p.tail_cnt * (mkl ? nblk : S) * SG_PLANE * 4;
+    for (int S = 2; S <= (mkl ? nblk : 8); ++S) {
+        if (mkl ? (S != nblk) : (p.nchunks % S != 0)) continue;
+        const size_t ws = (size_t)8 * p.tail_cnt * S * SG_PLANE * 4;
         if (ws > ws_avail) continue;
-        const double c = (double)((p.tail_cnt * S + 31) / 32) / S + 0.04;
+        const double c = (double)((p.tail_cnt * S + SG_ROUND - 1) / SG_ROUND) / S + 0.04;
         if (c < bc - 0.02) { bc = c; best = S; }
     }
     if (force_split > 0) best = force_split;
     if (best > 1) {
-        p.split = best; p.planes = mkl ? nblk : best;
+        p.split = best; p.planes = best;
         p.ws_bytes = (size_t)8 * p.tail_cnt * p.planes * SG_PLANE * 4;
     } else { p.full_pos = p.per; p.tail_cnt = 0; }
     return p;
@@ -318,12 +390,22 @@ using namespace selftok;
 
 extern "C" {
 
+#ifdef SG_STAMP
+int selftok_sg_occupancy(int mkl)       // tools: workgroups per CU the runtime admits for the kernel
+{
+    int n = -1;
+    if (mkl) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sg_gemm_kernel<true>, SG_THREADS, 0);
+    else hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sg_gemm_kernel<false>, SG_THREADS, 0);
+    return n;
+}
+#endif
+
 size_t selftok_linear_f32_workspace_bytes(long M, int N, int K, int flags)
 {
     if (M <= 0 || N <= 0 || K <= 0 || N % SG_BN || K % SG_BK) return 0;
     // the largest plan: every tail tile of every XCD split into all of its K-blocks (MKL order) or 8 units (free order)
     const bool mkl = (flags & SELFTOK_LINEAR_MKL_ORDER) != 0;
-    const long mt = (M + SG_BM - 1) / SG_BM, tiles = mt * (N / SG_BN), per = (tiles + 7) / 8, tail = per % 32;
+    const long mt = (M + SG_BM - 1) / SG_BM, tiles = mt * (N / SG_BN), per = (tiles + 7) / 8, tail = per % SG_ROUND;
     const int planes = mkl ? (K / SG_BK + 11) / 12 : 8;
     return (size_t)8 * tail * planes * SG_PLANE * 4;
 }
@@ -344,22 +426,23 @@ int selftok_linear_f32(const float* x, long ldx, const float* w, const float* bi
     if (force > 0) {
         p = sg_plan(M, N, K, mkl, (size_t)-1, force);
         if (p.ws_bytes > (workspace ? workspace_bytes : 0)) { set_last_error("linear_f32: forced tail split needs a larger workspace"); return SELFTOK_EINVAL; }
-        if (p.tail_cnt > 0 && (mkl ? ((p.nchunks + 11) / 12) % force : p.nchunks % force)) { set_last_error("linear_f32: forced split does not divide K"); return SELFTOK_EINVAL; }
+        if (p.tail_cnt > 0 && (mkl ? (p.nchunks + 11) / 12 != force : p.nchunks % force != 0)) { set_last_error("linear_f32: forced split must divide K / 32 (MKL order: equal the number of K-blocks)"); return SELFTOK_EINVAL; }
     }
     SgArgs g{};
     g.a = x; g.lda = ldx; g.b = w; g.c = out; g.ldc = ldo; g.bias = bias;
     g.res = res; g.ldr = ldr; g.res_mod = res_mod; g.gate = gate; g.ldg = ldg; g.gate_mod = gate_mod;
     g.ws = (float*)workspace;
+    g.flat_prio = (flags >> 16) & 1;
     g.M = (int)M; g.N = N; g.K = K; g.gelu = (flags & SELFTOK_LINEAR_GELU) ? 1 : 0; g.bias_last = (flags & SELFTOK_LINEAR_BIAS_LAST) ? 1 : 0;
     g.mt = p.mt; g.nt = p.nt; g.tiles = p.tiles; g.per = p.per; g.full_pos = p.full_pos; g.tail_cnt = p.tail_cnt; g.split = p.split; g.planes = p.planes;
     g.blk_chunks = (!mkl && p.split > 1) ? p.nchunks / p.split : p.blk_chunks; g.nchunks = p.nchunks;
     const unsigned grid = 8u * (unsigned)(p.full_pos + p.tail_cnt * p.split);
-    if (mkl) hipLaunchKernelGGL((sg_gemm_kernel<true>), dim3(grid), dim3(512), 0, stream, g);
-    else hipLaunchKernelGGL((sg_gemm_kernel<false>), dim3(grid), dim3(512), 0, stream, g);
+    if (mkl) hipLaunchKernelGGL((sg_gemm_kernel<true>), dim3(grid), dim3(SG_THREADS), 0, stream, g);
+    else hipLaunchKernelGGL((sg_gemm_kernel<false>), dim3(grid), dim3(SG_THREADS), 0, stream, g);
     int rc = check_launch("sg_gemm_kernel");
     if (rc || p.tail_cnt == 0) return rc;
-    if (mkl) hipLaunchKernelGGL((sg_tail_finish_kernel<true>), dim3(32, 8 * p.tail_cnt), dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((sg_tail_finish_kernel<false>), dim3(32, 8 * p.tail_cnt), dim3(256), 0, stream, g);
+    if (mkl) hipLaunchKernelGGL((sg_tail_finish_kernel<true>), dim3(16, 8 * p.tail_cnt), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((sg_tail_finish_kernel<false>), dim3(16, 8 * p.tail_cnt), dim3(256), 0, stream, g);
     return check_launch("sg_tail_finish_kernel");
 }
 

@@ -773,6 +773,48 @@ def ex_linear(x: torch.Tensor, weight: torch.Tensor, bias=None, *, gelu: bool = 
     return out
 
 
+LINEAR_BIAS_LAST, LINEAR_MKL_ORDER = 2, 4
+_LINEAR_WS = {}          # device index -> workspace tensor of the tail split (grown on demand, reused by every call on that device's stream order)
+
+
+def _linear_ws(device, nbytes: int):
+    ws = _LINEAR_WS.get(device.index)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _LINEAR_WS[device.index] = ws
+    return ws
+
+
+def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias=None, *, mkl_order: bool = False, gelu: bool = False, res=None, res_mod: int = 0, gate=None,
+               gate_mod: int = 0, out: Optional[torch.Tensor] = None, bias_last: bool = False, split: int = 0, use_workspace: bool = True, _flags: int = 0) -> torch.Tensor:
+    """F.linear on the LDS-DMA staged fp32-MFMA kernel (csrc/gemm_fp32.hip): N % 128 == 0, K % 32 == 0.  mkl_order: MKL sgemm's K-blocking, bit-identical to
+    `ex_linear` (gemm='exact'); otherwise one k-ascending chain per output (gemm='fp32').  Epilogue arguments as `ex_linear`.  `split` (tests / tools) forces the
+    tail split; `use_workspace=False` runs the tail round unsplit."""
+    _need_cuda(x, weight, bias, res, gate)
+    N, K = weight.shape
+    assert weight.dtype == torch.float32 and weight.is_contiguous() and x.shape[-1] == K
+    M, ldx = _rows2d(x)
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() or out.stride(-1) == 1
+    _, ldo = _rows2d(out)
+    ldr = _rows2d(res)[1] if res is not None else 0
+    ldg = _rows2d(gate)[1] if gate is not None else 0
+    flags = (1 if gelu else 0) | (LINEAR_BIAS_LAST if bias_last else 0) | (LINEAR_MKL_ORDER if mkl_order else 0) | ((int(split) & 0xFF) << 8) | int(_flags)
+    lib = _lib.load()
+    ws, nws = None, 0
+    if use_workspace:
+        nws = int(lib.selftok_linear_f32_workspace_bytes(M, N, K, flags))
+        ws = _linear_ws(x.device, nws) if nws else None
+    _lib.check(lib.selftok_linear_f32(_p(x), ldx, _p(weight), _p(bias), _p(res), ldr, int(res_mod), _p(gate), ldg, int(gate_mod), _p(out), ldo, M, N, K, flags,
+                                      _p(ws), (ws.numel() if ws is not None else 0), _stream()), "selftok_linear_f32")
+    return out
+
+
+def linear_f32_supported(N: int, K: int, mkl_order: bool = False) -> bool:
+    return N % 128 == 0 and K % 32 == 0 and not (mkl_order and 384 < K < 768)
+
+
 def ex_layernorm_mod(x: torch.Tensor, shift=None, scale=None, gamma=None, beta=None, eps: float = 1e-6, want_stats: bool = False, per_sample: bool = False):
     """nn.LayerNorm in ATen's arithmetic, then `* (1 + scale[tok]) + shift[tok]` (tok = row % T; shift / scale [T, N] views, equal row stride;
     per_sample: x [B, rows, N] with tables [B, N], tok = the sample)"""
