@@ -321,7 +321,7 @@ int selftok_vx_expf_f32(const float* x, float* y, long n, hipStream_t stream);
  *   SELFTOK_LINEAR_BIAS_LAST  as SELFTOK_EX_BIAS_LAST
  *   SELFTOK_LINEAR_SPLIT(n)   tools / tests: force the tail split to n units (0: planned)
  * res / gate / res_mod / gate_mod / aliasing: as selftok_ex_linear_f32.
- * workspace: the tiles left over after the last full round of 512 workgroups (two per CU) are computed as several K-range units whose raw sums go through
+ * workspace: the tiles left over after the last full round of 256 tiles (one per CU and tile time) are computed as several K-range units whose raw sums go through
  * `workspace` and are added in K order by a second kernel (MKL order: one plane per K-block, so the result is unchanged bit for bit).  NULL / too small:
  * no split (correct, the tail round then runs at partial occupancy).  selftok_linear_f32_workspace_bytes = the most any plan for the shape takes. */
 #define SELFTOK_LINEAR_BIAS_LAST 2

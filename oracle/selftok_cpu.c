@@ -1004,6 +1004,41 @@ int selftok_ex_linear_f32(const float* x, long ldx, const float* w, const float*
     return SELFTOK_OK;
 }
 
+/* csrc/gemm_fp32.hip on the CPU.  MKL order: the arithmetic of selftok_ex_linear_f32 (K <= 384 or K >= 768).  Free order: one k-ascending fmaf chain per output
+ * over the whole K, bias added last -- what the GPU kernel computes for every tile of a full round; its tail tiles are S shorter chains added in order (S is a
+ * property of the launch plan on a 256-CU chip), so the two builds agree to accumulation-order noise there, not bit for bit. */
+size_t selftok_linear_f32_workspace_bytes(long M, int N, int K, int flags)
+{
+    (void)M; (void)N; (void)K; (void)flags;
+    return 0;
+}
+
+int selftok_linear_f32(const float* x, long ldx, const float* w, const float* bias, const float* res, long ldr, int res_mod, const float* gate, long ldg,
+                       int gate_mod, float* out, long ldo, long M, int N, int K, int flags, void* workspace, size_t workspace_bytes, hipStream_t s)
+{
+    (void)workspace; (void)workspace_bytes;
+    if (M == 0) return SELFTOK_OK;
+    if (!x || !w || !out || M < 0 || N <= 0 || K <= 0 || N % 128 || K % 32 || ldx % 4 || ldx < K || ldo < N || ldo % 4 || (gate && !res)) return fail("linear_f32: bad argument");
+    if (flags & SELFTOK_LINEAR_MKL_ORDER) {
+        if (K > 384 && K < 768) return fail("linear_f32: MKL order for 384 < K < 768 is served by selftok_ex_linear_f32");
+        return selftok_ex_linear_f32(x, ldx, w, bias, res, ldr, res_mod, gate, ldg, gate_mod, out, ldo, M, N, K,
+                                     ((flags & SELFTOK_LINEAR_GELU) ? 1 : 0) | ((flags & SELFTOK_LINEAR_BIAS_LAST) ? 2 : 0), s);
+    }
+#pragma omp parallel for schedule(static)
+    for (long m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) {
+            const float *xr = x + (size_t)m * ldx, *wr = w + (size_t)n * K;
+            float v = 0.0f;
+            for (int k = 0; k < K; ++k) v = fmaf(xr[k], wr[k], v);
+            if (bias) v = v + bias[n];
+            if (flags & SELFTOK_LINEAR_GELU) v = xe_gelu_tanh1(v);
+            if (gate) v = gate[(size_t)(gate_mod > 0 ? m % gate_mod : (gate_mod < 0 ? m / -gate_mod : m)) * ldg + n] * v;
+            if (res) v = res[(size_t)(res_mod > 0 ? m % res_mod : (res_mod < 0 ? m / -res_mod : m)) * ldr + n] + v;
+            out[(size_t)m * ldo + n] = v;
+        }
+    return SELFTOK_OK;
+}
+
 int selftok_ex_layernorm_mod_f32(const float* x, long ldx, float* out, long ldo, const float* shift, const float* scale, long ldt, int T, const float* gamma,
                                  const float* beta, float* stats, long rows, int N, float eps, hipStream_t s)
 {

@@ -26,7 +26,7 @@
 //     and workgroup turnover during which a CU that holds ONE workgroup has nothing to issue.  Two independent workgroups cover each other's prologue, epilogue,
 //     barrier and DMA waits with no software at all (the library's kernel does it with one wave per SIMD and a hand-scheduled stream).
 //   * XCD-aware 1-D tile order (bands of 8 row tiles: the 64 workgroups resident on an XCD cover 8 x 8 tiles = 8 A + 8 B operand tiles per chunk round).
-//   * the TAIL ROUND is split along K: the tiles left over after the last full round of 512 workgroups are computed as S units of 1 / S of the K range each, raw
+//   * the TAIL ROUND is split along K: the tiles left over after the last full round of 256 tiles (one per CU) are computed as S units of 1 / S of the K range each, raw
 //     partial sums to a workspace, and a small second kernel adds the planes IN ORDER and runs the epilogue.  In MKL order a unit is ONE K-block (S = the number of
 //     K-blocks), its plane the block's chain, so the result is still ((bias + c0) + c1) + ... bit for bit; in free order a unit is 1 / S of the chunks.
 //
@@ -57,7 +57,8 @@ constexpr int SG_STAGE = (SG_BM + SG_BN) * SG_BK * 4;         // 32 KiB
 constexpr int SG_STAGES = 2;
 constexpr int SG_PLANE = SG_BM * SG_BN;                       // floats per workspace plane
 constexpr int SG_THREADS = 384;                               // 4 compute waves + 2 loader waves
-constexpr int SG_ROUND = 64;                                  // workgroups resident per XCD: 32 CUs x 2
+constexpr int SG_ROUND = 32;                                  // one tile per CU and tile time: the two workgroups of a CU run one BEHIND the other (issue priority by age), the
+                                                              // second one only fills the first one's prologue / epilogue / stalls (profiles/r6_sgemm_v4_stamps_census.txt)
 
 struct SgArgs {
     const float* a; long lda;                   // x [M][K], row stride lda (floats, multiple of 4)
@@ -299,25 +300,47 @@ __global__ __launch_bounds__(SG_THREADS, 3) void sg_gemm_kernel(SgArgs g)
         return;
     }
     const bool has_gate = g.gate != nullptr, has_res = g.res != nullptr, bias_l = g.bias_last && g.bias != nullptr, gelu = g.gelu != 0;
+    // 16 outputs (one 32 x 32 block's rows of this lane) at a time: their gate / res operands are loaded TOGETHER, then combined and stored -- one output at a
+    // time made every output wait for its own two loads (64 serial round trips per lane: proj ran at 0.65 of the peak, profiles/r6_sgemm_v6b_model_epilogues.txt)
+    // addresses as (uniform 64-bit base) + (32-bit per-lane byte offset): the launcher guarantees that the tables and the output stay below 4 GiB
+    const char* gbase = reinterpret_cast<const char*>(g.gate);
+    const char* rbase = reinterpret_cast<const char*>(g.res);
+    char* cbase = reinterpret_cast<char*>(g.c + (size_t)row0 * g.ldc);
+    const unsigned ldg4 = (unsigned)g.ldg * 4u, ldr4 = (unsigned)g.ldr * 4u, ldc4 = (unsigned)g.ldc * 4u;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int n = ncol + 32 * t;
+        const unsigned n4 = (unsigned)n * 4u;
         const float bfree = (!MKL && g.bias != nullptr && !g.bias_last) ? g.bias[n] : 0.f;
         const float blast = bias_l ? g.bias[n] : 0.f;
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
+            float gv[16], rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { gv[r] = 1.f; rv[r] = 0.f; }
+            if (has_gate) {                                 // the uniform decision OUTSIDE the 16 loads: inside, every load sat in its own branch with its own wait
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    gv[r] = *reinterpret_cast<const float*>(gbase + ((unsigned)rowidx[0][64 * wm + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h] * ldg4 + n4));
+            }
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rv[r] = *reinterpret_cast<const float*>(rbase + ((unsigned)rowidx[1][64 * wm + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h] * ldr4 + n4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ml = 64 * wm + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h, m = row0 + ml;
-                if (!whole && m >= g.M) continue;
+                const int ml = 64 * wm + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float v = MKL ? C[t][16 * b + r] : acc[t][16 * b + r] + bfree;
                 if (bias_l) v = v + blast;
                 if (gelu) v = xe_gelu_tanh1(v);
-                if (has_gate) v = g.gate[(size_t)rowidx[0][ml] * g.ldg + n] * v;
-                if (has_res) v = g.res[(size_t)rowidx[1][ml] * g.ldr + n] + v;
-                g.c[(size_t)m * g.ldc + n] = v;
-                __builtin_amdgcn_sched_barrier(0);          // one output at a time: the unrolled epilogue must not set the kernel's register count
+                if (has_gate) v = gv[r] * v;
+                if (has_res) v = rv[r] + v;
+                if (whole || row0 + ml < g.M) *reinterpret_cast<float*>(cbase + ((unsigned)ml * ldc4 + n4)) = v;
+                __builtin_amdgcn_sched_barrier(0);          // the arithmetic one output at a time (16 interleaved GELUs would set the kernel's register count)
             }
+        }
     }
 }
 
@@ -354,7 +377,7 @@ __global__ __launch_bounds__(256) void sg_tail_finish_kernel(SgArgs g)
     *reinterpret_cast<sg_f32x4*>(g.c + (size_t)m * g.ldc + n) = o;
 }
 
-// The launch plan (host): tile list split over the 8 XCDs, full rounds of 64 workgroups per XCD (two per CU), the tail round split along K.
+// The launch plan (host): tile list split over the 8 XCDs, full rounds of 32 tiles per XCD (one per CU and tile time), the tail round split along K.
 struct SgPlan { int mt, nt, tiles, per, full_pos, tail_cnt, split, planes, blk_chunks, nchunks; size_t ws_bytes; };
 
 static SgPlan sg_plan(long M, int N, int K, bool mkl, size_t ws_avail, int force_split)
@@ -366,15 +389,16 @@ static SgPlan sg_plan(long M, int N, int K, bool mkl, size_t ws_avail, int force
     p.blk_chunks = mkl ? 12 : p.nchunks;
     p.full_pos = p.per / SG_ROUND * SG_ROUND; p.tail_cnt = p.per - p.full_pos; p.split = 1; p.planes = 1;
     if (p.tail_cnt == 0) return p;
-    // cost of the tail in tile times: ceil(tail_cnt * S / 64) rounds of 1 / S each (+ ~4 % per unit for its pipeline fill, plane write and the finish pass).
+    // cost of the tail in tile times: ceil(tail_cnt * S / 32) rounds of 1 / S each (+ ~8 % of a tile per unit round for pipeline fill, plane write and the finish pass).
     // MKL order: a unit is ONE K-block (S = the number of K-blocks: the planes are the blocks, added in order by the finish kernel)
     int best = 1; double bc = 1.0;
     for (int S = 2; S <= (mkl ? nblk : 8); ++S) {
         if (mkl ? (S != nblk) : (p.nchunks % S != 0)) continue;
         const size_t ws = (size_t)8 * p.tail_cnt * S * SG_PLANE * 4;
         if (ws > ws_avail) continue;
-        const double c = (double)((p.tail_cnt * S + SG_ROUND - 1) / SG_ROUND) / S + 0.04;
-        if (c < bc - 0.02) { bc = c; best = S; }
+        const int rounds = (p.tail_cnt * S + SG_ROUND - 1) / SG_ROUND;
+        const double c = (double)rounds / S + 0.08 * rounds;
+        if (c < bc - 0.05) { bc = c; best = S; }
     }
     if (force_split > 0) best = force_split;
     if (best > 1) {
@@ -415,8 +439,9 @@ int selftok_linear_f32(const float* x, long ldx, const float* w, const float* bi
 {
     if (M == 0) return SELFTOK_OK;
     if (!x || !w || !out || M < 0 || M > 0x7fffffffL || N <= 0 || K <= 0 || N % SG_BN || K % SG_BK || ldx % 4 || ldx < K || ldo < N || ldo % 4 || (gate && !res) ||
-        (size_t)SG_BM * (size_t)ldx * 4 > 0xffffffffull) {
-        set_last_error("linear_f32: need N % 128 == 0, K % 32 == 0, 16-byte aligned rows (ldx % 4 == 0, ldo % 4 == 0), gate only with res");
+        (size_t)SG_BM * (size_t)ldx * 4 > 0xffffffffull || (size_t)SG_BM * (size_t)ldo * 4 > 0xffffffffull ||
+        (res && (size_t)M * (size_t)ldr * 4 > 0xffffffffull) || (gate && (size_t)M * (size_t)ldg * 4 > 0xffffffffull)) {
+        set_last_error("linear_f32: need N % 128 == 0, K % 32 == 0, 16-byte aligned rows (ldx % 4 == 0, ldo % 4 == 0), gate only with res, res / gate tables below 4 GiB");
         return SELFTOK_EINVAL;
     }
     const bool mkl = (flags & SELFTOK_LINEAR_MKL_ORDER) != 0;

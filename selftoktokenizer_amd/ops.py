@@ -753,13 +753,27 @@ def _rows2d(t: torch.Tensor):
     return rows, ld
 
 
+EX_LINEAR_SG_MIN_ROWS = 256     # from this many rows on `ex_linear` runs on the LDS-DMA staged kernel (csrc/gemm_fp32.hip, bit-identical results) where the shape allows
+
+
 def ex_linear(x: torch.Tensor, weight: torch.Tensor, bias=None, *, gelu: bool = False, res=None, res_mod: int = 0, gate=None, gate_mod: int = 0,
-              out: Optional[torch.Tensor] = None, bias_last: bool = False) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, bias_last: bool = False, kernel: str = "auto") -> torch.Tensor:
     """F.linear in MKL sgemm's summation order (bit-equal to torch-CPU's nn.Linear for M >= 512 rows), optional exact GELU(tanh),
     optional `res + gate * y` epilogue (res / gate rows taken modulo res_mod / gate_mod when positive: per-token tables; divided by
-    -mod when negative: per-sample tables).  bias_last: (sum of the K-blocks) + bias, what at::linear computes for a non-contiguous input."""
-    _need_cuda(x, weight, bias, res, gate)
+    -mod when negative: per-sample tables).  bias_last: (sum of the K-blocks) + bias, what at::linear computes for a non-contiguous input.
+    `kernel`: 'xe' = xe_gemm / xe_gemm128 (csrc/encoder_exact.hip, any shape), 'sg' = the LDS-DMA staged kernel of round 6 (csrc/gemm_fp32.hip: N % 128 == 0,
+    K % 32 == 0, K outside (384, 768)), 'auto' = 'sg' from EX_LINEAR_SG_MIN_ROWS rows on where the shape allows.  Same bits either way (tests/test_gemm_fp32_gpu.py)."""
     N, K = weight.shape
+    if kernel not in ("auto", "xe", "sg"):
+        raise ValueError(f"ex_linear kernel {kernel!r}: expected 'auto', 'xe' or 'sg'")
+    if kernel == "sg" or (kernel == "auto" and linear_f32_supported(N, K, mkl_order=True) and x.numel() // max(K, 1) >= EX_LINEAR_SG_MIN_ROWS):
+        if kernel == "auto" and gelu and res is None and (out is None or out.is_contiguous()):
+            # fc1 + GELU: the Sleef-arithmetic GELU costs ~80 VALU instructions per output; in the GEMM's epilogue four waves per CU work through it while the
+            # matrix pipe idles (measured +0.40 ms on a 2.28 ms Linear), as its own element-wise pass over every SIMD +0.2 ms.  Same bits: GELU of the same fp32 value.
+            y = linear_f32(x, weight, bias, mkl_order=True, out=out, bias_last=bias_last)
+            return ex_unary(y, "gelu_tanh", out=y)
+        return linear_f32(x, weight, bias, mkl_order=True, gelu=gelu, res=res, res_mod=res_mod, gate=gate, gate_mod=gate_mod, out=out, bias_last=bias_last)
+    _need_cuda(x, weight, bias, res, gate)
     assert weight.dtype == torch.float32 and weight.is_contiguous() and x.shape[-1] == K
     M, ldx = _rows2d(x)
     if out is None:
@@ -838,10 +852,12 @@ def ex_layernorm_mod(x: torch.Tensor, shift=None, scale=None, gamma=None, beta=N
 EX_UNARY = {"gelu_tanh": 0, "silu": 1, "sleef_expf": 2, "sleef_tanhf": 3, "exp_u20": 4}
 
 
-def ex_unary(x: torch.Tensor, kind: str) -> torch.Tensor:
+def ex_unary(x: torch.Tensor, kind: str, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """element-wise: y[i] = f(x[i]); `out` may be x itself (in place)"""
     _need_cuda(x)
     assert x.dtype == torch.float32 and x.is_contiguous()
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
+    assert y.dtype == torch.float32 and y.is_contiguous() and y.numel() == x.numel()
     _lib.check(_lib.load().selftok_ex_unary_f32(_p(x), _p(y), x.numel(), EX_UNARY[kind], _stream()), "selftok_ex_unary_f32")
     return y
 

@@ -597,6 +597,24 @@ def _(alloc):
                                      B * T, N, K, 2, None], dict(out=out)
 
 
+def _linear_f32(flags, exact_note):
+    def fn(alloc):
+        """csrc/gemm_fp32.hip through the C ABI: 300 rows (ragged tile), proj-like shape with the `x + gate * y` epilogue, a workspace for the tail split"""
+        r = rng(78)
+        M, K, N, T = 300, 1536, 256, 100
+        x = f32(r.standard_normal((M, K))); w = f32(r.standard_normal((N, K)) / np.sqrt(K)); b = f32(r.standard_normal(N))
+        res = f32(r.standard_normal((M, N))); gate = f32(r.standard_normal((T, 2 * N)))
+        out = alloc(np.zeros((M, N), np.float32))
+        ws = alloc(np.zeros(8 * 1 * 8 * 128 * 128 * 4, np.uint8))            # >= selftok_linear_f32_workspace_bytes(300, 256, 1536, .): 8 XCDs x 1 tail tile x (4 K-blocks | 8 units) planes
+        return "selftok_linear_f32", [alloc(x).ptr, K, alloc(w).ptr, alloc(b).ptr, alloc(res).ptr, N, 0, alloc(gate).ptr + 4 * N, 2 * N, T, out.ptr, N,
+                                      M, N, K, flags, ws.ptr, 8 * 8 * 128 * 128 * 4, None], dict(out=out)
+    return fn
+
+
+case("linear_f32_mkl_order_bias_last_gate")(_linear_f32(4 | 2, "MKL order"))                       # SELFTOK_LINEAR_MKL_ORDER | SELFTOK_LINEAR_BIAS_LAST: bit-exact on both builds
+case("linear_f32_free_order_gate", exact=False, tol=4e-6)(_linear_f32(0, "free order"))            # free order: the tail tiles' chains are split on the GPU
+
+
 @case("ex_layernorm_mod_per_sample")
 def _(alloc):
     r = rng(77)

@@ -71,6 +71,15 @@ def main():
                   "sg free, flat priority": t_ms(lambda: ops.linear_f32(x, w, b, out=out, _flags=1 << 16)),
                   "sg MKL": t_ms(lambda: ops.linear_f32(x, w, b, out=out, mkl_order=True)),
                   "sg MKL, tail unsplit": t_ms(lambda: ops.linear_f32(x, w, b, out=out, mkl_order=True, use_workspace=False))}
+            # the epilogues the exact MMDiT runs (sd3/mmdit.py:485-496): proj = x + gate * (y + bias last), fc1 = GELU, fc2 = x + gate * y; per-token gate table
+            T = 358 if M % 358 == 0 else 256
+            if name != "qkv":
+                res = torch.randn(M, N, device=dev, generator=g)
+                tab = torch.randn(T, N, device=dev, generator=g)
+                kw = dict(gelu=True) if name == "fc1" else dict(res=res, gate=tab, gate_mod=T, bias_last=(name == "proj"))
+                ms["xe_gemm128 + model epilogue"] = t_ms(lambda: ops.ex_linear(x, w, b, out=out, kernel="xe", **kw))
+                ms["sg MKL + model epilogue"] = t_ms(lambda: ops.ex_linear(x, w, b, out=out, kernel="sg", **kw))
+                ms["auto + model epilogue"] = t_ms(lambda: ops.ex_linear(x, w, b, out=out, **kw))
             tiles = ((M + 127) // 128) * (N // 128)
             print(f"{name:5s} [{M},{K}]x[{K},{N}] tiles {tiles} = {tiles / 512:.2f} rounds: " + "  ".join(f"{k} {v:.3f} ms ({fl / v / 1e9 / PEAK * 1e12:.3f})" for k, v in ms.items()), flush=True)
 
