@@ -365,6 +365,13 @@ int selftok_ex_unary_f32(const float* x, float* y, long n, int mode, hipStream_t
 size_t selftok_ex_attention_workspace_bytes(int B, int H, int Tq, int Tk, int D);
 int selftok_ex_attention_f32(const float* q, long qs, const float* k1, const float* v1, long kvs1, int Tk1, int valid1, int rows1, const float* k2, const float* v2,
                              long kvs2, int Tk2, float* out, void* workspace, int B, int H, int Tq, int D, hipStream_t stream);
+/* selftok_ex_attention_f32 in ONE kernel (round 6): the scores are computed twice per kv block of 512 keys (once for the block maximum ATen takes before it
+ * exponentiates, once for the probabilities) instead of being written to and re-read from a [B H, Tq, Tk] fp32 workspace; same bits.  head_dim 64, Tk1 % 64 == 0,
+ * Tk2 % 64 == 0, (Tk1 + Tk2) % 512 == 0 or <= 384 (selftok_ex_attention_fused_supported != 0) -- every attention of the MMDiT and the Q-Former's query attention
+ * at 256 x 256; other shapes (head_dim 16, the 320 px key counts): the entry above. */
+int selftok_ex_attention_fused_supported(int Tk1, int Tk2, int D);
+int selftok_ex_attention_fused_f32(const float* q, long qs, const float* k1, const float* v1, long kvs1, int Tk1, int valid1, int rows1, const float* k2, const float* v2,
+                                   long kvs2, int Tk2, float* out, int B, int H, int Tq, int D, hipStream_t stream);
 
 #ifdef __cplusplus
 }

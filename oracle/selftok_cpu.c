@@ -1087,3 +1087,18 @@ int selftok_ex_attention_f32(const float* q, long qs, const float* k1, const flo
     xe_attention_masked(q, qs, k1, v1, kvs1, Tk1, valid1, rows1, k2, v2, kvs2, Tk2, out, B, H, Tq, D);
     return SELFTOK_OK;
 }
+
+/* the fused entry of round 6: the same arithmetic (the CPU twin has one implementation), the GPU entry's shape restrictions */
+int selftok_ex_attention_fused_supported(int Tk1, int Tk2, int D)
+{
+    const int Tk = Tk1 + Tk2, last = Tk & 511;
+    return D == 64 && Tk1 >= 0 && Tk2 >= 0 && Tk > 0 && (Tk1 & 63) == 0 && (Tk2 & 63) == 0 && (last == 0 || last <= 384);
+}
+
+int selftok_ex_attention_fused_f32(const float* q, long qs, const float* k1, const float* v1, long kvs1, int Tk1, int valid1, int rows1, const float* k2, const float* v2,
+                                   long kvs2, int Tk2, float* out, int B, int H, int Tq, int D, hipStream_t s)
+{
+    if (B == 0) return SELFTOK_OK;
+    if (!selftok_ex_attention_fused_supported(Tk1, Tk2, D) || Tk1 <= 0) return fail("ex_attention_fused: unsupported shape");
+    return selftok_ex_attention_f32(q, qs, k1, v1, kvs1, Tk1, valid1, rows1, k2, v2, kvs2, Tk2, out, NULL, B, H, Tq, D, s);
+}

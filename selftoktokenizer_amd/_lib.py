@@ -74,6 +74,8 @@ SIGNATURES = {
     "selftok_ex_unary_f32": (_i, [_vp, _vp, _l, _i, _vp]),
     "selftok_ex_attention_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "selftok_ex_attention_f32": (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "selftok_ex_attention_fused_supported": (_i, [_i, _i, _i]),
+    "selftok_ex_attention_fused_f32": (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _l, _i, _vp, _i, _i, _i, _i, _vp]),
 }
 
 

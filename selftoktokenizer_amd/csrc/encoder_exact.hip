@@ -565,6 +565,243 @@ __global__ void xe_transpose_v_kernel(const float* __restrict__ v, long vs, floa
         if (d0 + r < D && t0 + tx < T) vt[((size_t)z * D + d0 + r) * Tk + t_off + t0 + tx] = tile[tx][r];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same attention FUSED (round 6): one kernel per call, no score matrix in HBM (unfused: QK^T GEMM -> [B H, Tq, Tk] fp32 scores in a workspace -> row pass ->
+// V transpose -> P V GEMM: four passes over 3.6 GB per joint block at B = 64, 19 % of the exact-order step).  head_dim 64, key slot counts multiples of 64.
+//
+// ATen's fp32 flash kernel takes the row maximum over a whole kv block of 512 keys before it exponentiates (p = exp_u20(s - max AFTER the block)), so a score is
+// needed twice.  Keeping 128 rows x 512 scores per workgroup would take 256 KiB of LDS and 32 rows per workgroup would re-fetch K / V four times as often, so the
+// scores are COMPUTED twice (a chain of 64 fp32 MFMAs gives the same bits both times): per kv block, sweep 1 walks the K tiles for the block maximum, sweep 2
+// walks K and V tiles for probabilities, row sums and P V.  3 units of matrix work instead of 2, and nothing else leaves the CU.
+//
+//   workgroup = 4 waves = 128 query rows of one (sample, head); a wave owns 32 rows.  K / V tiles of 64 keys x 64 floats reach LDS by LDS-DMA (double buffered;
+//   K rows XOR-swizzled on the source side for conflict-free ds_read_b128, V rows natural), 64 KiB per workgroup: two workgroups per CU.
+//   S^T = K Q^T on v_mfma_f32_32x32x1_2b_f32, one instruction per d (the k-ascending chain from 0 that MKL's sgemm runs for K = 64), the two blocks = the two key
+//   halves of the tile: lane (hh, i) ends with the scores of query i against keys 32 blk + (r & 3) + 8 (r >> 2) + 4 hh.  Scores * 1/sqrt(d), masked keys -inf.
+//   Row pass in registers: exp_u20, the 16 key-class sums (class = key mod 16: a lane holds 8 of them, accumulated tile after tile in key order = the 16-lane
+//   vector sum of ATen), folded 8 / 4 / 2 / 1 at the block end, sum = fma(expf(old max - new max), old sum, block sum) with glibc's expf.
+//   O^T += V^T P^T on the same instruction, one per KEY in ascending order (the sequential chain over the keys), blocks = the two d halves; the probability of a key
+//   sits in one lane half, v_permlane32_swap hands it to both.  Chains end every 256 keys (MKL's halves of a 512-key block): C += chain; C *= expf(old max - new
+//   max) when a new kv block starts; out = C * (1 / sum).  Fully masked tiles are skipped: their probabilities are exact zeros and acc + 0 = acc.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct XfArgs {
+    const float* q; long qs;
+    const float *k1, *v1; long kvs1; int Tk1, valid1, rows1;
+    const float *k2, *v2; long kvs2; int Tk2;
+    float* out;
+    int B, H, Tq, qtiles;
+    float scale;
+};
+
+__device__ __forceinline__ void xf_dma16(const void* base, unsigned voff, unsigned lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory", "m0");
+}
+
+struct XfStep { int jb, sweep, t; };          // kv block, sweep (1: maximum, 2: probabilities + P V), staged key tile (64 slots) -- all uniform
+
+__global__ __launch_bounds__(256, 2) void xe_fattn_kernel(XfArgs a)
+{
+    __shared__ __attribute__((aligned(1024))) float s_k[2][64 * 64];
+    __shared__ __attribute__((aligned(1024))) float s_v[2][64 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, hh = lane >> 5;
+    int qt, hd, b;
+    {   // XCD-aware order: the q tiles of one (sample, head) share K / V -- they run on ONE XCD (consecutive entries of that XCD's eighth of the list)
+        const int T = gridDim.x, orig = blockIdx.x;
+        const int q8 = T >> 3, r8 = T & 7, xcd = orig & 7, idx = orig >> 3;
+        const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        qt = w % a.qtiles;
+        hd = (w / a.qtiles) % a.H;
+        b = w / (a.qtiles * a.H);
+    }
+    qt = __builtin_amdgcn_readfirstlane(qt); hd = __builtin_amdgcn_readfirstlane(hd); b = __builtin_amdgcn_readfirstlane(b);
+    const int Tk = a.Tk1 + a.Tk2, nblk = (Tk + 511) >> 9;
+    const int my_q = qt * 128 + wave * 32 + i;
+    const bool row_ok = my_q < a.Tq;
+
+    // this lane's half of its query row: d = 2 j + hh (v_mfma_f32_32x32x2_f32 takes the even k of a pair from lanes 0..31, the odd k from lanes 32..63 and adds
+    // them in that order: fma(a1, b1, fma(a0, b0, acc)) -- a k-ascending chain, csrc/vq.hip)
+    float qf[32];
+    {
+        const float* qp = a.q + ((size_t)b * a.Tq + (row_ok ? my_q : a.Tq - 1)) * a.qs + hd * 64 + hh;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) qf[j] = qp[2 * j];
+    }
+
+    // ---- staging: a tile = 64 key rows x 256 bytes = 16 pieces of 4 rows; wave w issues pieces w, w + 4, w + 8, w + 12 of K (and of V in sweep 2) ----
+    const unsigned lds_k = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&s_k[0][0];
+    const unsigned lds_v = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&s_v[0][0];
+    const int kr = lane >> 4, pos = lane & 15;                 // row inside a piece, 16-byte position inside the 256-byte row
+    auto stage = [&](const XfStep& st, int buf) {
+        const int slot0 = st.t * 64;
+        const bool seg2 = slot0 >= a.Tk1;
+        const float* kp = seg2 ? a.k2 : a.k1;
+        const float* vp = seg2 ? a.v2 : a.v1;
+        const long rs = seg2 ? a.kvs2 : a.kvs1;
+        const int rows = seg2 ? a.Tk2 : a.rows1, nvis = seg2 ? a.Tk2 : a.valid1, key0 = seg2 ? slot0 - a.Tk1 : slot0;
+        const char* kb = reinterpret_cast<const char*>(kp + (size_t)b * rows * rs + hd * 64);
+        const char* vb = reinterpret_cast<const char*>(vp + (size_t)b * rows * rs + hd * 64);
+        const unsigned rs4 = (unsigned)rs * 4u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = wave + 4 * u, row = 4 * p + kr;      // tile row 0..63
+            const int src = min(key0 + row, nvis - 1);         // ragged tile: rows past the visible prefix fetch the last visible key (masked to -inf / probability 0 below)
+            xf_dma16(kb, (unsigned)src * rs4 + (unsigned)((pos ^ (row & 15)) << 4), lds_k + buf * 16384 + p * 1024);
+            if (st.sweep == 2) xf_dma16(vb, (unsigned)src * rs4 + (unsigned)(pos << 4), lds_v + buf * 16384 + p * 1024);
+        }
+    };
+    auto visible = [&](int t) { const int s0 = t * 64; return s0 >= a.Tk1 || s0 < a.valid1; };
+    auto advance = [&](XfStep st) {                             // successor of a step; jb == nblk: done
+        for (;;) {
+            ++st.t;
+            const int tend = min((st.jb + 1) * 8, Tk >> 6);
+            if (st.t >= tend) {
+                if (st.sweep == 1) { st.sweep = 2; st.t = st.jb * 8 - 1; continue; }
+                ++st.jb; st.sweep = 1; st.t = st.jb * 8 - 1;
+                if (st.jb >= nblk) return st;
+                continue;
+            }
+            if (visible(st.t)) return st;
+        }
+    };
+
+    f32x16 o0, o1;                                              // the running chain: O^T[d = 32 dh + (r & 3) + 8 (r >> 2) + 4 hh][query i]
+    float C0[16], C1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; C0[r] = 0.f; C1[r] = 0.f; }
+    float m_old = -__builtin_inff(), sum_old = 0.f, m_new = -__builtin_inff(), lane_max = -__builtin_inff();
+    float cls[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cls[c] = 0.f;
+    int chain = -1;
+    bool block_live = false;                                     // sweep 2 of the current block has something to do (some key of it or before it is visible)
+
+    // S^T of one 32-key half of the staged tile: rows (keys) 32 sub + i; this lane reads d = 4 c + hh and 4 c + 2 + hh of chunk c (one ds_read2_b32)
+    const int ksw = i & 15;
+    auto scores = [&](int buf, int sub, f32x16& sacc) {
+        const float* sk = s_k[buf] + (32 * sub + i) * 64 + hh;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float* pc = sk + ((c ^ ksw) << 2);
+            const float x0 = pc[0], x1 = pc[2];
+            if (c == 0) { const f32x16 zero = {0}; sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, qf[0], zero, 0, 0, 0); }
+            else sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, qf[2 * c], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, qf[2 * c + 1], sacc, 0, 0, 0);
+        }
+    };
+    auto finish_scores = [&](int slot0, f32x16& sacc) {         // * 1/sqrt(d); keys past the visible prefix of a ragged half: -inf
+        const int nvis = slot0 >= a.Tk1 ? 32 : a.valid1 - slot0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = sacc[r] * a.scale;
+        if (nvis < 32) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if ((r & 3) + 8 * (r >> 2) + 4 * hh >= nvis) sacc[r] = -__builtin_inff();
+        }
+    };
+    auto fold_chain = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { C0[r] = C0[r] + o0[r]; o0[r] = 0.f; C1[r] = C1[r] + o1[r]; o1[r] = 0.f; }
+    };
+
+    XfStep cur{0, 1, -1};
+    cur = advance(cur);
+    if (cur.jb >= nblk) return;                                  // (the launcher refuses calls without a visible key)
+    stage(cur, 0);
+    for (int s = 0; cur.jb < nblk; ++s) {
+        const XfStep nxt = advance(cur);
+        const int buf = s & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my pieces of this step's tile have landed
+        __syncthreads();                                         // everyone's have, and the other buffer (step s - 1) is free
+        if (nxt.jb < nblk) stage(nxt, buf ^ 1);
+
+        if (cur.sweep == 2 && block_live) {
+            const int slot_in_blk = cur.t * 64 - cur.jb * 512;
+            const int blen = min(512, Tk - cur.jb * 512);
+            const int ch = 2 * cur.jb + ((blen == 512 && slot_in_blk >= 256) ? 1 : 0);
+            if (ch != chain) { fold_chain(); chain = ch; }
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int slot0 = cur.t * 64 + 32 * sub;
+            if (slot0 < a.Tk1 && slot0 >= a.valid1) continue;    // a fully masked half (uniform)
+            if (cur.sweep == 2 && !block_live) continue;
+            f32x16 sacc;
+            scores(buf, sub, sacc);
+            finish_scores(slot0, sacc);
+            if (cur.sweep == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lane_max = fmaxf(lane_max, sacc[r]);
+                continue;
+            }
+            // probabilities, in place; the 8 key classes of this lane in key order: reg c (key < 16 of the half), then c + 8
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = xe_exp_u20(sacc[r] - m_new);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);       // four exponentials in flight, not sixteen
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { cls[c] = cls[c] + sacc[c]; cls[c] = cls[c] + sacc[c + 8]; }
+            // O^T += V^T P^T on key PAIRS in ascending order: the pair (k, k + 1) wants P[k] in lanes 0..31 and P[k + 1] in lanes 32..63; keys 8 g + {0..3} live in lane
+            // half 0 (regs 4 g + {0..3}), 8 g + {4..7} in half 1 -- one v_permlane32_swap of regs (4 g + e, 4 g + e + 1) makes the operands of pairs (8 g + e, + 1) and (8 g + 4 + e, + 1)
+            const float* sv = s_v[buf] + (32 * sub + hh) * 64 + i;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const auto w0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sacc[4 * g]), __float_as_uint(sacc[4 * g + 1]), false, false);
+                const auto w1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sacc[4 * g + 2]), __float_as_uint(sacc[4 * g + 3]), false, false);
+                const float px[4] = {__uint_as_float(w0[0]), __uint_as_float(w1[0]), __uint_as_float(w0[1]), __uint_as_float(w1[1])};   // pairs 8g+{0,1}, {2,3}, {4,5}, {6,7}
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = 8 * g + 2 * e;               // this lane's V row: key + hh
+                    const float v0 = sv[key * 64], v1 = sv[key * 64 + 32];
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, px[e], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, px[e], o1, 0, 0, 0);
+                }
+            }
+        }
+        if (cur.sweep == 1 && (nxt.jb != cur.jb || nxt.sweep != 1)) {        // the block's last tile of sweep 1: its maximum, the rescale of what was accumulated before it
+            const float bm = fmaxf(lane_max, __shfl_xor(lane_max, 32, WAVE));
+            m_new = m_old > bm ? m_old : bm;
+            lane_max = -__builtin_inff();
+            block_live = m_new != -__builtin_inff();             // every query of a call sees the same keys: uniform
+            if (block_live && cur.jb > 0) {
+                const float f = xe_expf_glibc(m_old - m_new);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { C0[r] = C0[r] * f; C1[r] = C1[r] * f; }
+            }
+        }
+        if (cur.sweep == 2 && nxt.jb != cur.jb && block_live) {  // the kv block is done: its chains into C, its row sum into the running sum
+            fold_chain();
+            chain = -1;
+            float s8[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s8[j] = cls[j] + cls[j + 4];                         // lanes l, l ^ 8 of ATen's 16-lane vector
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s8[j] = s8[j] + __shfl_xor(s8[j], 32, WAVE);        // l ^ 4: the other lane half
+            const float u0 = s8[0] + s8[2], u1 = s8[1] + s8[3];                              // l ^ 2
+            const float tot = u0 + u1;                                                       // l ^ 1
+            sum_old = fmaf(xe_expf_glibc(m_old - m_new), sum_old, tot);
+            m_old = m_new;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) cls[c] = 0.f;
+        }
+        cur = nxt;
+    }
+
+    // out[b][q][hd * 64 + d] = C * (1 / sum): lane (hh, i) holds d = 32 dh + 8 g + 4 hh + j in reg 4 g + j of half dh
+    if (row_ok) {
+        const float inv = 1.0f / sum_old;
+        float* op = a.out + ((size_t)b * a.Tq + my_q) * ((size_t)a.H * 64) + hd * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<float4*>(op + 8 * g + 4 * hh) = make_float4(C0[4 * g] * inv, C0[4 * g + 1] * inv, C0[4 * g + 2] * inv, C0[4 * g + 3] * inv);
+            *reinterpret_cast<float4*>(op + 32 + 8 * g + 4 * hh) = make_float4(C1[4 * g] * inv, C1[4 * g + 1] * inv, C1[4 * g + 2] * inv, C1[4 * g + 3] * inv);
+        }
+    }
+}
+
 }  // namespace selftok
 
 using namespace selftok;
@@ -674,6 +911,32 @@ int selftok_ex_attention_f32(const float* q, long qs, const float* k1, const flo
     g.nblk = n;
     for (int j = 0; j < n; ++j) if (g.blk_end[j] % 4) { set_last_error("ex_attention: a K-block boundary is not a multiple of 4"); return SELFTOK_EINVAL; }
     return launch_xe_gemm(g, Z, stream);
+}
+
+/* The same attention in ONE kernel (xe_fattn_kernel above): no workspace, no score matrix in HBM; bit-identical to selftok_ex_attention_f32.  head_dim 64, key
+ * slot counts multiples of 64, and a last kv block (Tk mod 512) of at most 384 keys (one MKL K-block) -- else SELFTOK_EINVAL: use the unfused entry. */
+int selftok_ex_attention_fused_supported(int Tk1, int Tk2, int D)
+{
+    const int Tk = Tk1 + Tk2, last = Tk & 511;
+    return D == 64 && Tk1 >= 0 && Tk2 >= 0 && Tk > 0 && (Tk1 & 63) == 0 && (Tk2 & 63) == 0 && (last == 0 || last <= 384);
+}
+
+int selftok_ex_attention_fused_f32(const float* q, long qs, const float* k1, const float* v1, long kvs1, int Tk1, int valid1, int rows1, const float* k2, const float* v2,
+                                   long kvs2, int Tk2, float* out, int B, int H, int Tq, int D, hipStream_t stream)
+{
+    if (B == 0) return SELFTOK_OK;
+    if (!q || !out || B < 0 || H <= 0 || Tq <= 0 || Tk1 < 0 || Tk2 < 0 || valid1 < 0 || valid1 > Tk1 || rows1 < valid1 || (valid1 > 0 && (!k1 || !v1)) || (Tk2 > 0 && (!k2 || !v2)) ||
+        qs % 4 || kvs1 % 4 || kvs2 % 4 || (valid1 == 0 && Tk2 == 0) || !selftok_ex_attention_fused_supported(Tk1, Tk2, D) ||
+        (size_t)(rows1 > Tk2 ? rows1 : Tk2) * (size_t)(kvs1 > kvs2 ? kvs1 : kvs2) * 4 > 0xffffffffull) {
+        set_last_error("ex_attention_fused: need head_dim 64, key slot counts % 64 == 0, a last kv block of <= 384 keys, 16-byte aligned rows, at least one visible key");
+        return SELFTOK_EINVAL;
+    }
+    XfArgs a{};
+    a.q = q; a.qs = qs; a.k1 = k1; a.v1 = v1; a.kvs1 = kvs1; a.Tk1 = Tk1; a.valid1 = valid1; a.rows1 = rows1;
+    a.k2 = k2; a.v2 = v2; a.kvs2 = kvs2; a.Tk2 = Tk2; a.out = out; a.B = B; a.H = H; a.Tq = Tq; a.qtiles = (Tq + 127) / 128;
+    a.scale = (float)(1.0 / sqrt((double)D));
+    hipLaunchKernelGGL(xe_fattn_kernel, dim3((unsigned)(B * H * a.qtiles)), dim3(256), 0, stream, a);
+    return check_launch("xe_fattn_kernel");
 }
 
 }  // extern "C"

@@ -16,15 +16,20 @@
 //   * both operand tiles reach LDS by `global_load_lds_dwordx4` (1 KiB = 8 rows x 128 bytes per wave instruction; uniform SGPR base + one constant per-lane offset
 //     register per piece; the 16-byte chunks of a row XOR-swizzled on the SOURCE side so that every ds_read_b128 lane group covers all 64 banks once: 0 bank
 //     conflicts in the PMC pass): no staging registers, no ds_write, no VALU in the k-loop besides the K-block fold.
-//   * workgroup = FOUR compute waves = 128 x 128 outputs (wave: 64 x 64 = two 2-block accumulators, 64 VGPRs) + TWO LOADER waves (one issues the A tile's 16 DMA
-//     pieces of a chunk, the other the B tile's), 32-k chunks, two stages of 32 KiB -> TWO INDEPENDENT workgroups per CU.  A DMA piece costs the ISSUING wave 60 - 180
-//     cycles during which its MFMA stream pauses: with the pieces spread over the compute waves the kernel lost 6 - 8 % to them wherever they were placed
-//     (profiles/r6_sgemm_v3*.txt: "no DMA" 0.88 / 0.94, "DMA issued, waits removed" = the product); loader waves never touch the matrix pipe.  What the measurements of the first versions said (profiles/r6_sgemm_v2_*.txt, r6_mfma_f32_forms.txt):
-//     one 8-wave 256 x 128 workgroup per CU ran at 0.80 (K = 1536) / 0.87 (K = 6144) of the peak whether its two waves per SIMD stood at the chunk barrier together
-//     or half a chunk apart; the chip holds 2.39 GHz under this load and a bare MFMA + fragment-read + barrier loop reaches 0.92; without DMA and barriers the kernel
-//     still stopped at 0.86 / 0.93 -- the missing part is PER TILE, not per chunk: ~30 k cycles of prologue (first DMA round trip), epilogue (64 outputs per lane)
-//     and workgroup turnover during which a CU that holds ONE workgroup has nothing to issue.  Two independent workgroups cover each other's prologue, epilogue,
-//     barrier and DMA waits with no software at all (the library's kernel does it with one wave per SIMD and a hand-scheduled stream).
+//   * workgroup = EIGHT compute waves = 256 x 128 outputs (wave: 64 x 64 = two 2-block accumulators, 64 VGPRs; two compute waves per SIMD) + TWO LOADER waves
+//     (one issues the A tile's 32 DMA pieces of a chunk, the other the B tile's 16), 32-k chunks, THREE stages of 48 KiB (144 of the CU's 160 KiB: one workgroup
+//     per CU); one barrier per chunk.  How the measurements led here (profiles/r6_sgemm_v*.txt, r6_mfma_f32_forms*.txt; the chip holds 2.39 GHz under every
+//     variant, so everything below is pipe cycles, not clock):
+//       - a DMA piece costs the ISSUING wave 60 - 180 cycles during which its MFMA stream pauses: with the pieces issued by the compute waves the kernel lost 6 - 8 %
+//         wherever they were placed ("no DMA" 0.88 / 0.94, "DMA issued, waits removed" = the product) -> loader waves, which never touch the matrix pipe;
+//       - ONE compute wave per SIMD pays ~6 pipe cycles for every instruction between two MFMAs (fragment reads, waits): 69.5 cycles per MFMA in the k-loop, 0.865
+//         (in-kernel stamps; a bare loop of that shape: 0.66 with one wave per SIMD, 0.80 - 0.93 with two) -> two compute waves per SIMD: the partner's MFMA takes
+//         the slot (8791 cycles per chunk for the 128 MFMAs of a SIMD = 0.93 in the loop);
+//       - two INDEPENDENT workgroups per CU do not interleave: issue arbitration is by age, the older workgroup's waves issue back to back and the younger one's
+//         prologue / first MFMAs wait (census: loops of the two workgroups of a CU never overlapped) -- and a 65-KiB workgroup is admitted once per CU whatever the
+//         occupancy query says.  So: one workgroup per CU, its stages deep enough (3) that the DMA round trip (~4300 cycles under load, longer than a chunk's
+//         MFMAs) is off the critical path.
+//     Prologue (first DMA round trip, 1.9 us) and epilogue (1.7 us plain) of a 176-us tile are what is left outside the loop.
 //   * XCD-aware 1-D tile order (bands of 8 row tiles: the 64 workgroups resident on an XCD cover 8 x 8 tiles = 8 A + 8 B operand tiles per chunk round).
 //   * the TAIL ROUND is split along K: the tiles left over after the last full round of 256 tiles (one per CU) are computed as S units of 1 / S of the K range each, raw
 //     partial sums to a workspace, and a small second kernel adds the planes IN ORDER and runs the epilogue.  In MKL order a unit is ONE K-block (S = the number of
@@ -45,18 +50,22 @@
 #ifndef SG_ABL
 #define SG_ABL 0
 #endif
+#ifndef SG_ONE_WG
+#define SG_ONE_WG 0
+#endif
 
 namespace selftok {
 
 typedef float sg_f32x32 __attribute__((ext_vector_type(32)));
 typedef float sg_f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SG_BM = 128, SG_BN = 128, SG_BK = 32;
-constexpr int SG_A_BYTES = SG_BM * SG_BK * 4;                 // 16 KiB
-constexpr int SG_STAGE = (SG_BM + SG_BN) * SG_BK * 4;         // 32 KiB
-constexpr int SG_STAGES = 2;
+constexpr int SG_BM = 256, SG_BN = 128, SG_BK = 32;
+constexpr int SG_A_BYTES = SG_BM * SG_BK * 4;                 // 32 KiB
+constexpr int SG_STAGE = (SG_BM + SG_BN) * SG_BK * 4;         // 48 KiB
+constexpr int SG_STAGES = 3;
 constexpr int SG_PLANE = SG_BM * SG_BN;                       // floats per workspace plane
-constexpr int SG_THREADS = 384;                               // 4 compute waves + 2 loader waves
+constexpr int SG_CW = 8;                                      // compute waves: 4 (rows) x 2 (columns) wave tiles of 64 x 64
+constexpr int SG_THREADS = 64 * (SG_CW + 2);                  // + 2 loader waves
 constexpr int SG_ROUND = 32;                                  // one tile per CU and tile time: the two workgroups of a CU run one BEHIND the other (issue priority by age), the
                                                               // second one only fills the first one's prologue / epilogue / stalls (profiles/r6_sgemm_v4_stamps_census.txt)
 
@@ -104,16 +113,11 @@ template <bool MKL>
 __global__ __launch_bounds__(SG_THREADS, 3) void sg_gemm_kernel(SgArgs g)
 {
     __shared__ __attribute__((aligned(1024))) char lds[SG_STAGES * SG_STAGE];
-    __shared__ int rowidx[2][SG_BM];           // epilogue: row of the gate / res table for every row of the tile (one integer division per row, not per output)
-    // Issue arbitration on a SIMD is by priority, then AGE: the older of the two workgroups of a CU issues its MFMAs back to back and the younger one gets the
-    // leftover slots -- for its prologue's VALU work (fp32 MFMAs and VALU share the port) that is almost none: measured, a workgroup lived 195 us of which 92 in its
-    // k-loop, the loops of the two workgroups of a CU never overlapped, and 9 us passed between the end of one loop and the start of the other
-    // (profiles/r6_sgemm_v4_stamps_census.txt).  So: the prologue and the loader waves run at raised priority (they are short and the DMA round trip they start is
-    // what the next loop waits for), the k-loop at priority 0 -- the younger workgroup then stands at its first MFMA with its first chunk landed when the older one
-    // leaves its loop.
+    // Issue arbitration on a SIMD is by priority, then AGE.  The prologue and the loader waves run at raised priority (short, and the DMA round trips they start are
+    // what the loop waits for), the k-loop at priority 0, the epilogue raised again (the next workgroup's prologue overlaps it).
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = (wave >> 1) & 1;
+    const int wm = wave & 3, wn = (wave >> 2) & 1;
     const int i = lane & 31, h = lane >> 5;
 
     // ---- which tile, which part of K ----
@@ -139,40 +143,39 @@ __global__ __launch_bounds__(SG_THREADS, 3) void sg_gemm_kernel(SgArgs g)
     unit = __builtin_amdgcn_readfirstlane(unit); te = __builtin_amdgcn_readfirstlane(te);
     const int row0 = tm * SG_BM, col0 = tn * SG_BN;
     const int nch = c1 - c0;
-    if (tid < SG_BM && unit < 0 && (g.gate != nullptr || g.res != nullptr)) {        // visible to everyone after the first chunk barrier
-        const int m = min(row0 + tid, g.M - 1);
-        rowidx[0][tid] = g.gate_mod > 0 ? m % g.gate_mod : (g.gate_mod < 0 ? m / -g.gate_mod : m);
-        rowidx[1][tid] = g.res_mod > 0 ? m % g.res_mod : (g.res_mod < 0 ? m / -g.res_mod : m);
-    }
 #ifdef SG_STAMP
     // tools: s_memtime at [before barrier, after barrier, after the chunk's MFMAs were issued] of the first 40 chunks, waves 0 (compute) and 4 (loader) of the
     // workgroups at list positions 256 and 288 of XCD 0 (two workgroups of the fifth round: every CU holds two by then) -> g.ws as u64 [wg 2][wave 2][chunk 40][3]
     unsigned long long* stamp = nullptr;
-    if (xcd == 0 && (pos == 256 || pos == 288) && (wave == 0 || wave == 4) && lane == 0)
-        stamp = reinterpret_cast<unsigned long long*>(g.ws) + ((pos == 288 ? 1 : 0) * 2 + (wave ? 1 : 0)) * 120;
+    if (xcd == 0 && (pos == 128 || pos == 160) && (wave == 0 || wave == SG_CW) && lane == 0)
+        stamp = reinterpret_cast<unsigned long long*>(g.ws) + ((pos == 160 ? 1 : 0) * 2 + (wave ? 1 : 0)) * 120;
 #define SG_TS(kc, j) do { if (stamp && (kc) < 40) stamp[(kc) * 3 + (j)] = __builtin_readcyclecounter(); } while (0)
     // residency census: every workgroup's (start, end) in 100 MHz ticks and where it ran -> u64 [blockIdx][3] behind the first 8 KiB
     struct SgCensus {
-        unsigned long long* p; unsigned long long t0;
+        unsigned long long* p; unsigned long long t0, t1 = 0, t2 = 0;
         __device__ SgCensus(unsigned long long* q) : p(q), t0(__builtin_amdgcn_s_memrealtime()) {}
         __device__ ~SgCensus() {
             if (!p) return;
             unsigned hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            p[0] = t0; p[1] = __builtin_amdgcn_s_memrealtime(); p[2] = ((unsigned long long)(xcc & 0xF) << 32) | hw;
+            p[0] = t0; p[1] = __builtin_amdgcn_s_memrealtime(); p[2] = ((unsigned long long)(xcc & 0xF) << 32) | hw; p[3] = t1; p[4] = t2;
         }
-    } census((tid == 0 && blockIdx.x < 16384) ? reinterpret_cast<unsigned long long*>(g.ws) + 1024 + 3 * blockIdx.x : nullptr);
+    } census((tid == 0 && blockIdx.x < 16384) ? reinterpret_cast<unsigned long long*>(g.ws) + 1024 + 5 * blockIdx.x : nullptr);
+#define SG_CENSUS_LOOP_START() do { if (census.p && census.t1 == 0) census.t1 = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SG_CENSUS_LOOP_END() do { if (census.p) census.t2 = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define SG_TS(kc, j) do { } while (0)
+#define SG_CENSUS_LOOP_START() do { } while (0)
+#define SG_CENSUS_LOOP_END() do { } while (0)
 #endif
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)&lds[0];
 
-    if (wave >= 4) {
-        // ---- the two LOADER waves: wave 4 stages the A tile, wave 5 the B tile, 16 pieces of 8 rows x 128 bytes per chunk each.  They never touch the matrix
+    if (wave >= SG_CW) {
+        // ---- the two LOADER waves: wave 8 stages the A tile (32 pieces of 8 rows x 128 bytes per chunk), wave 9 the B tile (16).  They never touch the matrix
         // pipe; the compute waves never issue a VMEM instruction.  Per chunk: [chunk kc landed] -> barrier kc -> issue chunk kc + 1 into the other stage (every
         // compute wave finished reading chunk kc - 1 before it arrived at barrier kc). ----
-        const bool isA = wave == 4;
+        const bool isA = wave == SG_CW;
         const char* base = isA ? reinterpret_cast<const char*>(g.a + (size_t)row0 * g.lda) : reinterpret_cast<const char*>(g.b + (size_t)col0 * g.K);
         const unsigned rs = (unsigned)(isA ? g.lda : (long)g.K) * 4u;
         const int rlast = isA ? g.M - 1 - row0 : SG_BN - 1;                      // ragged last row tile: fetch the matrix's last row instead (never stored)
@@ -182,25 +185,33 @@ __global__ __launch_bounds__(SG_THREADS, 3) void sg_gemm_kernel(SgArgs g)
             if (SG_ABL == 1 || SG_ABL == 3) return;
             const char* cb = base + (size_t)chunk * (SG_BK * 4);
             const unsigned l = lds0 + stage * SG_STAGE + (isA ? 0 : SG_A_BYTES);
+            if (isA) {
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const int rg = min(8 * p + pr, rlast);
-                sg_dma16(cb, (unsigned)rg * rs + ((p & 1) ? swz1 : swz0), l + p * 1024);
+                for (int p = 0; p < SG_BM / 8; ++p) sg_dma16(cb, (unsigned)min(8 * p + pr, rlast) * rs + ((p & 1) ? swz1 : swz0), l + p * 1024);
+            } else {
+#pragma unroll
+                for (int p = 0; p < SG_BN / 8; ++p) sg_dma16(cb, (unsigned)(8 * p + pr) * rs + ((p & 1) ? swz1 : swz0), l + p * 1024);
             }
         };
         issue(c0, 0);
+        if (nch > 1) issue(c0 + 1, 1);
         for (int kc = 0; kc < nch; ++kc) {
-            if (SG_ABL != 1 && SG_ABL != 2 && SG_ABL != 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // chunk kc has landed: at most the pieces of chunk kc + 1 (32 of the A tile / 16 of the B tile) may still fly
+            if (SG_ABL != 1 && SG_ABL != 2 && SG_ABL != 3) {
+                if (kc + 1 >= nch) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (isA) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            }
             SG_TS(kc, 0);
             if (SG_ABL != 3) __syncthreads();
             SG_TS(kc, 1);
-            if (kc + 1 < nch) issue(c0 + kc + 1, (kc + 1) & 1);
+            if (kc + 2 < nch) issue(c0 + kc + 2, (kc + 2) % SG_STAGES);      // its stage held chunk kc - 1: every compute wave finished it before barrier kc
             SG_TS(kc, 2);
         }
         return;
     }
 
-    // ---- the four COMPUTE waves.  Fragment addresses: A row 64 wm + lane, B rows 64 wn + 32 t + i; chunk q of a row sits at position q ^ ((lane >> 1) & 7) ----
+    // ---- the eight COMPUTE waves.  Fragment addresses: A row 64 wm + lane, B rows 64 wn + 32 t + i; chunk q of a row sits at position q ^ ((lane >> 1) & 7) ----
     const int sw16 = ((lane >> 1) & 7) << 4;
     const int a_row = (64 * wm + lane) * 128 + sw16;
     const int b_row = SG_A_BYTES + (64 * wn + i) * 128 + sw16;
@@ -236,6 +247,7 @@ __global__ __launch_bounds__(SG_THREADS, 3) void sg_gemm_kernel(SgArgs g)
         SG_TS(kc, 0);
         if (SG_ABL != 3) __syncthreads();
         SG_TS(kc, 1);
+        SG_CENSUS_LOOP_START();
         ldq(la, 0, va, vb0, vb1);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -257,10 +269,12 @@ __global__ __launch_bounds__(SG_THREADS, 3) void sg_gemm_kernel(SgArgs g)
                 for (int r = 0; r < 32; ++r) { C[t][r] = C[t][r] + acc[t][r]; acc[t][r] = 0.f; }
         }
     };
-    for (int kc = 0; kc < nch; kc += 2) {
+    for (int kc = 0; kc < nch; kc += 3) {
         body(kc, std::integral_constant<int, 0>{});
         if (kc + 1 < nch) body(kc + 1, std::integral_constant<int, 1>{});
+        if (kc + 2 < nch) body(kc + 2, std::integral_constant<int, 2>{});
     }
+    SG_CENSUS_LOOP_END();
     if (unit >= 0) {
         // a unit of a tail tile: its raw sum (MKL order: K-block `unit`; free order: chunks c0 .. c1) goes to plane `unit` of the tile's workspace slot
         float* p = g.ws + ((size_t)(xcd * g.tail_cnt + te) * g.planes + unit) * SG_PLANE;
@@ -300,6 +314,17 @@ __global__ __launch_bounds__(SG_THREADS, 3) void sg_gemm_kernel(SgArgs g)
         return;
     }
     const bool has_gate = g.gate != nullptr, has_res = g.res != nullptr, bias_l = g.bias_last && g.bias != nullptr, gelu = g.gelu != 0;
+    // the row of the gate / res table for every row of the tile: one integer division per ROW (not per output), kept in the first KiB of the stage memory -- free now:
+    // every chunk was consumed.  (A separate 1-KiB array made the workgroup 65 KiB and the hardware then admitted ONE workgroup per CU, whatever the occupancy query
+    // said: profiles/r6_sgemm_v8_stamps.txt.)  The loaders have left; the barrier counts the eight compute waves.
+    int (*rowidx)[SG_BM] = reinterpret_cast<int (*)[SG_BM]>(lds);
+    __syncthreads();                           // nobody still reads the last chunk's fragments
+    if (tid < SG_BM && (has_gate || has_res)) {
+        const int m = min(row0 + tid, g.M - 1);
+        rowidx[0][tid] = g.gate_mod > 0 ? m % g.gate_mod : (g.gate_mod < 0 ? m / -g.gate_mod : m);
+        rowidx[1][tid] = g.res_mod > 0 ? m % g.res_mod : (g.res_mod < 0 ? m / -g.res_mod : m);
+    }
+    __syncthreads();
     // 16 outputs (one 32 x 32 block's rows of this lane) at a time: their gate / res operands are loaded TOGETHER, then combined and stored -- one output at a
     // time made every output wait for its own two loads (64 serial round trips per lane: proj ran at 0.65 of the peak, profiles/r6_sgemm_v6b_model_epilogues.txt)
     // addresses as (uniform 64-bit base) + (32-bit per-lane byte offset): the launcher guarantees that the tables and the output stay below 4 GiB
@@ -354,7 +379,7 @@ __global__ __launch_bounds__(256) void sg_tail_finish_kernel(SgArgs g)
     if (e >= g.per || sidx >= g.tiles) return;
     int tm, tn;
     sg_tile_of(sidx, g.mt, g.nt, tm, tn);
-    const int idx = blockIdx.x * 256 + threadIdx.x;     // 0 .. 128 * 32 - 1
+    const int idx = blockIdx.x * 256 + threadIdx.x;     // 0 .. SG_BM * 32 - 1
     const int r = idx >> 5, c4 = (idx & 31) << 2;
     const int m = tm * SG_BM + r;
     if (m >= g.M) return;
@@ -466,8 +491,8 @@ int selftok_linear_f32(const float* x, long ldx, const float* w, const float* bi
     else hipLaunchKernelGGL((sg_gemm_kernel<false>), dim3(grid), dim3(SG_THREADS), 0, stream, g);
     int rc = check_launch("sg_gemm_kernel");
     if (rc || p.tail_cnt == 0) return rc;
-    if (mkl) hipLaunchKernelGGL((sg_tail_finish_kernel<true>), dim3(16, 8 * p.tail_cnt), dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((sg_tail_finish_kernel<false>), dim3(16, 8 * p.tail_cnt), dim3(256), 0, stream, g);
+    if (mkl) hipLaunchKernelGGL((sg_tail_finish_kernel<true>), dim3(SG_PLANE / 1024, 8 * p.tail_cnt), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((sg_tail_finish_kernel<false>), dim3(SG_PLANE / 1024, 8 * p.tail_cnt), dim3(256), 0, stream, g);
     return check_launch("sg_tail_finish_kernel");
 }
 

@@ -862,11 +862,20 @@ def ex_unary(x: torch.Tensor, kind: str, out: Optional[torch.Tensor] = None) -> 
     return y
 
 
-def ex_attention(q: torch.Tensor, k1, v1, heads: int, k2=None, v2=None, slots1: Optional[int] = None) -> torch.Tensor:
+EX_ATTENTION_DEFAULT = "auto"     # what kernel='auto' means in ex_attention (tools set 'unfused' for A/B runs)
+
+
+def ex_attention(q: torch.Tensor, k1, v1, heads: int, k2=None, v2=None, slots1: Optional[int] = None, kernel: str = "auto") -> torch.Tensor:
     """F.scaled_dot_product_attention as ATen's fp32 CPU flash kernel evaluates it.  q [B,Tq,H*D], k1 / v1 [B,Tk1,H*D] and an
     optional second key / value segment that follows the first; all may be column slices of fused projections.  -> [B,Tq,H*D].
     `slots1`: the first segment occupies slots1 >= Tk1 key positions of which only the Tk1 given ones are visible (a prefix mask: the
-    masked keys keep their place in the kv blocks, see include/selftok_hip.h); k1 = v1 = None with slots1: none of them is visible."""
+    masked keys keep their place in the kv blocks, see include/selftok_hip.h); k1 = v1 = None with slots1: none of them is visible.
+    `kernel`: 'fused' = one kernel, scores never leave the CU (round 6: head_dim 64, slot counts % 64 == 0), 'unfused' = scores GEMM -> row pass -> P V GEMM through a
+    workspace (round 5, any shape), 'auto' = fused where it applies.  Same bits (tests/test_encoder_exact_gpu.py)."""
+    if kernel == "auto":
+        kernel = EX_ATTENTION_DEFAULT
+    if kernel not in ("auto", "fused", "unfused"):
+        raise ValueError(f"ex_attention kernel {kernel!r}: expected 'auto', 'fused' or 'unfused'")
     _need_cuda(q, k1, v1, k2, v2)
     B, Tq, HD = q.shape
     D = HD // heads
@@ -886,6 +895,10 @@ def ex_attention(q: torch.Tensor, k1, v1, heads: int, k2=None, v2=None, slots1: 
     lib = _lib.load()
     out = torch.empty(B, Tq, HD, dtype=torch.float32, device=q.device)
     if B == 0:
+        return out
+    if kernel == "fused" or (kernel == "auto" and lib.selftok_ex_attention_fused_supported(Tk1, Tk2, D)):
+        _lib.check(lib.selftok_ex_attention_fused_f32(_p(q), qs, _p(k1), _p(v1), ks1, Tk1, rows1, rows1, _p(k2), _p(v2), ks2, Tk2, _p(out), B, heads, Tq, D, _stream()),
+                   "selftok_ex_attention_fused_f32")
         return out
     ws = torch.empty(lib.selftok_ex_attention_workspace_bytes(B, heads, Tq, Tk1 + Tk2, D), dtype=torch.uint8, device=q.device)
     _lib.check(lib.selftok_ex_attention_f32(_p(q), qs, _p(k1), _p(v1), ks1, Tk1, rows1, rows1, _p(k2), _p(v2), ks2, Tk2, _p(out), _p(ws), B, heads, Tq, D, _stream()),

@@ -138,6 +138,27 @@ def test_attention_flash_order(name, B, H, Tq, Tk1, Tk2, D):
     _same(out, ref, name)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("slots,valid,Tk2,Tq", [(512, 512, 256, 512), (512, 358, 256, 358), (512, 358, 256, 256), (512, 100, 256, 100), (512, 20, 256, 256), (512, 0, 256, 256),
+                                               (512, 300, 0, 300), (1024, 750, 256, 750), (1024, 300, 256, 256), (1024, 1024, 256, 200)])
+def test_attention_fused_equals_unfused_with_a_prefix_mask(slots, valid, Tk2, Tq):
+    """the MMDiT's joint attention (sd3/mmdit.py:508-553 with the bool prefix mask of models_ours.py:353): `slots` context key slots of which the first `valid` are
+    visible (ragged tiles, fully masked tiles and kv blocks, no visible context key at all = cfg_inference), then Tk2 image keys (0: the context rows of the renderer
+    see no image key); Tq rows that are no multiple of the 128-row tile.  One kernel (round 6) vs scores GEMM -> row pass -> P V GEMM (round 5): the same bits."""
+    B, H, D = 2, 3, 64
+    HD = H * D
+    q = _rand(0xC0 + Tq, (B, Tq, 3 * HD), 1.3).cuda()
+    ctx = _rand(0xC1 + valid, (B, max(valid, 1), 3 * HD), 1.3).cuda()
+    x = _rand(0xC2 + Tk2, (B, max(Tk2, 1), 3 * HD), 1.3).cuda()
+    k1, v1 = (ctx[..., HD:2 * HD], ctx[..., 2 * HD:]) if valid else (None, None)
+    k2, v2 = (x[..., HD:2 * HD], x[..., 2 * HD:]) if Tk2 else (None, None)
+    a = ops.ex_attention(q[..., :HD], k1, v1, H, k2, v2, slots1=slots, kernel="fused")
+    b = ops.ex_attention(q[..., :HD], k1, v1, H, k2, v2, slots1=slots, kernel="unfused")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(a).all())
+    _same(a, b.cpu().numpy(), f"fused vs unfused, {valid} of {slots} context keys + {Tk2}, {Tq} rows")
+
+
 # ---- the whole encoder against the REFERENCE's own runs --------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def encoder():

@@ -28,29 +28,20 @@ for wg in range(2):
         print(f"    barrier-to-barrier period {period[:24].tolist()}   mean of chunks 8..39: wait {wait[8:].mean():.0f} work {work[8:].mean():.0f} period {period[8:].mean():.0f}")
 print("start offset between the two workgroups (cycles):", int(st[1, 0, 0, 0] - st[0, 0, 0, 0]))
 
-# residency census: how many workgroups are alive at once on one CU
+# residency census: every workgroup's (entry, first barrier passed, k-loop end, exit) in us and its CU
 nb = 8 * ((4608 + 7) // 8)
-cen = ws[8192: 8192 + nb * 24].view(torch.int64).cpu().numpy().reshape(nb, 3)
+cen = ws[8192: 8192 + nb * 40].view(torch.int64).cpu().numpy().reshape(nb, 5)
 cen = cen[cen[:, 1] > 0]
 hw = cen[:, 2] & 0xFFFFFFFF
 xcc = cen[:, 2] >> 32
-# HW_ID (gfx9): wave_id [3:0], simd_id [5:4], pipe_id [7:6], cu_id [11:8], sh_id [12], se_id [15:13] ...
 cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 0x1) << 4) | (((hw >> 13) & 0x7) << 5)
 key = xcc * 1024 + cu
 t0 = cen[:, 0].min()
 print("workgroups recorded", len(cen), "distinct (xcc, cu) keys", len(set(key.tolist())), "kernel span (us)", (cen[:, 1].max() - t0) / 100.0)
-mx = []
-for k in sorted(set(key.tolist()))[:8]:
-    sel = cen[key == k]
-    ev = sorted([(int(a), 1) for a in sel[:, 0]] + [(int(b), -1) for b in sel[:, 1]])
-    c = m = 0
-    for _, d in ev:
-        c += d; m = max(m, c)
-    dur = (sel[:, 1] - sel[:, 0]) / 100.0
-    mx.append(m)
-    print(f"  (xcc, cu) {k}: {len(sel)} workgroups, max alive at once {m}, mean lifetime {dur.mean():.1f} us, first starts {sorted(((sel[:, 0] - t0) / 100.0).tolist())[:4]}")
-
-k0 = sorted(set(key.tolist()))[0]
-sel = cen[key == k0]
-order = np.argsort(sel[:, 0])
-print("timeline of CU", k0, "(start us, end us, SIMD of wave 0):", [(round((int(a) - t0) / 100.0, 1), round((int(b) - t0) / 100.0, 1), int((h >> 4) & 3)) for a, b, h in sel[order].tolist()])
+us = lambda v: round((int(v) - int(t0)) / 100.0, 1)
+for k0 in sorted(set(key.tolist()))[:2]:
+    sel = cen[key == k0]
+    sel = sel[np.argsort(sel[:, 0])]
+    print(f"CU {k0}: (entry, loop start, loop end, exit) us:")
+    for a, b, h, c, d in sel.tolist()[:12]:
+        print(f"    entry {us(a):8.1f}  loop {us(c):8.1f} .. {us(d):8.1f} ({(d - c) / 100.0:6.1f})  exit {us(b):8.1f}   prologue {(c - a) / 100.0:6.1f}  epilogue {(b - d) / 100.0:6.1f}")
