@@ -354,6 +354,14 @@ int selftok_ex_linear_f32(const float* x, long ldx, const float* w, const float*
  * `x * (1 + scale[tok]) + shift[tok]` (modules.py:29-32), tok = row % T (T > 0) or row / -T (T < 0: per-sample tables), table rows at stride ldt.  stats (may be NULL): [rows][2] mean, rstd. */
 int selftok_ex_layernorm_mod_f32(const float* x, long ldx, float* out, long ldo, const float* shift, const float* scale, long ldt, int T, const float* gamma,
                                  const float* beta, float* stats, long rows, int N, float eps, hipStream_t stream);
+/* The residual update of a DismantledBlock fused into the LayerNorm + modulate that follows it (round 6; sd3/mmdit.py:485-496):
+ *   x' = x + gate[row(m, gate_mod)] * (lin + lin_bias)      (lin_bias / gate may be NULL; product and sums separately rounded, in this order)
+ *   out = LayerNorm(x') * (1 + scale[tok]) + shift[tok]      (ATen's arithmetic, as selftok_ex_layernorm_mod_f32; no affine)
+ * x' goes to x_out (may alias x).  `lin` is the plain output of the block's Linear (selftok_linear_f32 / selftok_ex_linear_f32 without res / gate):
+ * the same bits as the Linear's `res + gate * y` epilogue followed by selftok_ex_layernorm_mod_f32. */
+int selftok_ex_res_layernorm_mod_f32(const float* x, long ldx, const float* lin, long ldl, const float* lin_bias, const float* gate, long ldg, int gate_mod,
+                                     float* x_out, long ldxo, float* out, long ldo, const float* shift, const float* scale, long ldt, int T, long rows, int N, float eps,
+                                     hipStream_t stream);
 /* element-wise: mode 0 GELU(tanh) (ATen GeluKernelImpl), 1 SiLU, and the building blocks 2 Sleef expf_u10, 3 Sleef tanhf_u10, 4 ATen exp_u20 */
 int selftok_ex_unary_f32(const float* x, float* y, long n, int mode, hipStream_t stream);
 /* F.scaled_dot_product_attention as ATen's fp32 flash kernel evaluates it.  q [B][Tq][..] rows at stride qs, head h = columns h*D .. h*D+D-1;

@@ -1058,6 +1058,25 @@ int selftok_ex_layernorm_mod_f32(const float* x, long ldx, float* out, long ldo,
     return SELFTOK_OK;
 }
 
+int selftok_ex_res_layernorm_mod_f32(const float* x, long ldx, const float* lin, long ldl, const float* lin_bias, const float* gate, long ldg, int gate_mod,
+                                     float* x_out, long ldxo, float* out, long ldo, const float* shift, const float* scale, long ldt, int T, long rows, int N, float eps,
+                                     hipStream_t s)
+{
+    if (rows == 0) return SELFTOK_OK;
+    if (!x || !lin || !x_out || !out || rows < 0 || N <= 0 || N % 8 || N > 4096 || ldx % 4 || ldl % 4 || ldxo % 4 || ldo % 4 || ((shift == NULL) != (scale == NULL)) ||
+        (scale && T == 0)) return fail("ex_res_layernorm: bad argument");
+    for (long r = 0; r < rows; ++r) {
+        const float* g = gate ? gate + (size_t)(gate_mod > 0 ? r % gate_mod : (gate_mod < 0 ? r / -gate_mod : r)) * ldg : NULL;
+        for (int n = 0; n < N; ++n) {
+            float v = lin[(size_t)r * ldl + n];
+            if (lin_bias) v = v + lin_bias[n];
+            if (g) v = g[n] * v;
+            x_out[(size_t)r * ldxo + n] = x[(size_t)r * ldx + n] + v;
+        }
+    }
+    return selftok_ex_layernorm_mod_f32(x_out, ldxo, out, ldo, shift, scale, ldt, T, NULL, NULL, NULL, rows, N, eps, s);
+}
+
 int selftok_ex_unary_f32(const float* x, float* y, long n, int mode, hipStream_t s)
 {
     (void)s;

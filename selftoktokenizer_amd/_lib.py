@@ -71,6 +71,7 @@ SIGNATURES = {
     "selftok_linear_f32_workspace_bytes": (_sz, [_l, _i, _i, _i]),
     "selftok_linear_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _vp, _l, _l, _i, _i, _i, _vp, _sz, _vp]),
     "selftok_ex_layernorm_mod_f32": (_i, [_vp, _l, _vp, _l, _vp, _vp, _l, _i, _vp, _vp, _vp, _l, _i, _f, _vp]),
+    "selftok_ex_res_layernorm_mod_f32": (_i, [_vp, _l, _vp, _l, _vp, _vp, _l, _i, _vp, _l, _vp, _l, _vp, _vp, _l, _i, _l, _i, _f, _vp]),
     "selftok_ex_unary_f32": (_i, [_vp, _vp, _l, _i, _vp]),
     "selftok_ex_attention_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "selftok_ex_attention_f32": (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -434,15 +434,30 @@ __device__ __forceinline__ void xe_add_moments_vec(int m0_add, XMom add, int& m0
 
 // 8 threads per row: thread l owns fp32 lane l of ATen's 8-wide vectors (elements 8 j + l).  x [rows][N] (row stride ldx), N % 8 == 0,
 // N <= 4096.  y = LN(x) [* (1 + scale[tok]) + shift[tok]], tok = row % T, tables with row stride ldt.
-__global__ __launch_bounds__(256) void xe_ln_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, const float* __restrict__ shift,
+// FUSE (round 6): the row is first UPDATED, x' = x + gate[row(m)] * (lin [+ bias]) -- the residual update of a DismantledBlock (`x + gate * post_attention(attn)`,
+// `x + gate * mlp(...)`, sd3/mmdit.py:485-496) that the Linear's epilogue carried in round 5: there 8 compute waves per CU waited for 64 operand loads each while
+// the matrix pipe idled (proj at 0.72 of the peak against 0.87 with the plain epilogue); here it is two more streams of a bandwidth-bound pass.  The same fp32
+// operations in the same order: v = lin + bias (only when the bias comes last), v = gate * v, x' = x + v.  x' is written to `xo` (may be x itself).
+struct XeLnFuse {
+    const float* lin; long ldl;                 // the Linear's output [rows][N]
+    const float* gate; long ldg; int gate_mod;  // gate[row(m, gate_mod)][n] or null; row(m, d) = m % d (d > 0), m / -d (d < 0), m (0)
+    const float* bias;                          // added to lin first, or null
+    float* xo; long ldxo;
+};
+
+template <bool FUSE>
+__global__ __launch_bounds__(256) void xe_ln_kernel(const float* x, long ldx, float* __restrict__ y, long ldy, const float* __restrict__ shift,
                                                     const float* __restrict__ scale, long ldt, int T, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, long rows, int N, float eps, float* __restrict__ stats)
+                                                    const float* __restrict__ beta, long rows, int N, float eps, float* __restrict__ stats, XeLnFuse f)
 {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long row = gid >> 3;
     const int l = (int)(gid & 7);
     if (row >= rows) return;                       // rows * 8 is padded to whole waves by the launcher's guard below (shuffles stay inside a row's 8 lanes)
     const float* xr = x + (size_t)row * ldx;
+    const float* lr = FUSE ? f.lin + (size_t)row * f.ldl : nullptr;
+    const float* gr = (FUSE && f.gate != nullptr) ? f.gate + (size_t)(f.gate_mod > 0 ? row % f.gate_mod : (f.gate_mod < 0 ? row / -f.gate_mod : row)) * f.ldg : nullptr;
+    float* xor_ = FUSE ? f.xo + (size_t)row * f.ldxo : nullptr;
     const int n = N >> 3, m = (n + 15) >> 4;
     int depth = 0;
     while ((1 << depth) < m) ++depth;
@@ -455,7 +470,15 @@ __global__ __launch_bounds__(256) void xe_ln_kernel(const float* __restrict__ x,
         XMom a{0.f, 0.f};
         for (int j = 0; j < cnt; ++j) {
             const float cj = 1.0f / (float)(j + 1);
-            const float x0 = xr[(ci * 16 + j) * 8 + l];
+            const int col = (ci * 16 + j) * 8 + l;
+            float x0 = xr[col];
+            if (FUSE) {
+                float v = lr[col];
+                if (f.bias != nullptr) v = v + f.bias[col];
+                if (gr != nullptr) v = gr[col] * v;
+                x0 = x0 + v;
+                xor_[col] = x0;                    // read back below by the other lanes of this row's group (same wave): fenced
+            }
             const float d0 = x0 - a.m1;
             a.m1 = fmaf(d0, cj, a.m1);
             const float e0 = x0 - a.m1;
@@ -494,6 +517,7 @@ __global__ __launch_bounds__(256) void xe_ln_kernel(const float* __restrict__ x,
     const float rstd = 1.0f / sqrtf(fmaxf(var, 0.f) + eps);
     if (stats != nullptr && l == 0) { stats[2 * row] = m1; stats[2 * row + 1] = rstd; }
     const float nmean = -m1;
+    if (FUSE) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); xr = xor_; }
     float* yr = y + (size_t)row * ldy;
     const long tok = T > 0 ? row % T : row / -T;                       // T > 0: per-token tables (row % T); T < 0: per-sample (row / -T)
     const float* sh = shift != nullptr ? shift + (size_t)tok * ldt : nullptr;
@@ -843,9 +867,25 @@ int selftok_ex_layernorm_mod_f32(const float* x, long ldx, float* out, long ldo,
         set_last_error("ex_layernorm: need N % 8 == 0, N <= 4096, 16-byte aligned rows, shift and scale together"); return SELFTOK_EINVAL;
     }
     const long threads = rows * 8;
-    hipLaunchKernelGGL(xe_ln_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, ldx, out, ldo, shift, scale, ldt, T != 0 ? T : 1, gamma, beta,
-                       rows, N, eps, stats);
+    hipLaunchKernelGGL(xe_ln_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, ldx, out, ldo, shift, scale, ldt, T != 0 ? T : 1, gamma, beta,
+                       rows, N, eps, stats, XeLnFuse{});
     return check_launch("xe_ln_kernel");
+}
+
+int selftok_ex_res_layernorm_mod_f32(const float* x, long ldx, const float* lin, long ldl, const float* lin_bias, const float* gate, long ldg, int gate_mod,
+                                     float* x_out, long ldxo, float* out, long ldo, const float* shift, const float* scale, long ldt, int T, long rows, int N, float eps,
+                                     hipStream_t stream)
+{
+    if (rows == 0) return SELFTOK_OK;
+    if (!x || !lin || !x_out || !out || rows < 0 || N <= 0 || N % 8 || N > 4096 || ldx % 4 || ldl % 4 || ldxo % 4 || ldo % 4 || ((shift == nullptr) != (scale == nullptr)) ||
+        (scale && T == 0)) {
+        set_last_error("ex_res_layernorm: need N % 8 == 0, N <= 4096, 16-byte aligned rows, shift and scale together"); return SELFTOK_EINVAL;
+    }
+    const long threads = rows * 8;
+    XeLnFuse f{lin, ldl, gate, ldg, gate_mod, lin_bias, x_out, ldxo};
+    hipLaunchKernelGGL(xe_ln_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, ldx, out, ldo, shift, scale, ldt, T != 0 ? T : 1,
+                       (const float*)nullptr, (const float*)nullptr, rows, N, eps, (float*)nullptr, f);
+    return check_launch("xe_ln_kernel<fused residual update>");
 }
 
 int selftok_ex_unary_f32(const float* x, float* y, long n, int mode, hipStream_t stream)

@@ -36,6 +36,7 @@ class MMDiTGPU(ModuleSurface):
     _sd_prefix = "model."
     GEMM_MODES = ("fp32", "f16x2", "exact")
     PRESPLIT = True     # f16x2 mode: producers (LN-modulate, attention, fc1+GELU) hand the next Linear its input already split
+    EXACT_FUSED_RESIDUAL_LN = True   # gemm='exact': `x + gate * Linear(.)` inside the LayerNorm pass that follows (ops.ex_res_layernorm_mod) instead of the Linear's epilogue
     SPLITK = True       # f16x2 mode, <= ops.SPLITK_MAX_ROWS rows (one .. four images): several work-groups per output tile (ops.f16x2_ksplit)
 
     def __init__(self, sd: Dict[str, torch.Tensor], device, K: int, renderer: bool = False, gemm: str = "fp32"):
@@ -167,7 +168,14 @@ class MMDiTGPU(ModuleSurface):
             wl, bl = self.w[lin_name + ".weight"], self.w[lin_name + ".bias"]
             rows = x.shape[1]
             # attn.proj reads a SLICE of the concatenated attention output in the reference (non-contiguous -> at::linear = matmul + add_(bias): bias last)
-            x = ops.ex_linear(lin_in, wl, bl, res=x, gate=gate, gate_mod=(-rows if gate_per_sample else rows), bias_last=lin_name.endswith(".attn.proj"))
+            bias_last = lin_name.endswith(".attn.proj")
+            if self.EXACT_FUSED_RESIDUAL_LN:
+                # round 6: the Linear keeps its plain epilogue (the matrix pipe does not wait for 64 operand loads per lane) and the residual update rides in the
+                # LayerNorm pass behind it -- the same fp32 operations in the same order
+                y = ops.ex_linear(lin_in, wl, None if bias_last else bl)
+                return ops.ex_res_layernorm_mod(x, y, lin_bias=bl if bias_last else None, gate=gate, gate_mod=(-rows if gate_per_sample else rows),
+                                                shift=ln_kw.get("shift"), scale=ln_kw.get("scale"), per_sample=bool(ln_kw.get("per_sample", False)))
+            x = ops.ex_linear(lin_in, wl, bl, res=x, gate=gate, gate_mod=(-rows if gate_per_sample else rows), bias_last=bias_last)
             n = ops.ex_layernorm_mod(x, shift=ln_kw.get("shift"), scale=ln_kw.get("scale"), per_sample=bool(ln_kw.get("per_sample", False)))
             return x, n
         split = self._pre(consumer) if split is None else split

@@ -849,6 +849,31 @@ def ex_layernorm_mod(x: torch.Tensor, shift=None, scale=None, gamma=None, beta=N
     return (out, stats) if want_stats else out
 
 
+def ex_res_layernorm_mod(x: torch.Tensor, lin: torch.Tensor, *, lin_bias=None, gate=None, gate_mod: int = 0, shift=None, scale=None, eps: float = 1e-6,
+                         per_sample: bool = False, x_out: Optional[torch.Tensor] = None):
+    """x' = x + gate[row] * (lin + lin_bias); n = LayerNorm(x') * (1 + scale[tok]) + shift[tok]  ->  (x', n).  The residual update of a DismantledBlock
+    (sd3/mmdit.py:485-496) fused into the LayerNorm + modulate behind it: the same bits as `ex_linear(..., res=x, gate=gate)` + `ex_layernorm_mod`, with the
+    Linear keeping its plain epilogue (round 6).  gate rows: m % gate_mod (> 0: per-token table), m / -gate_mod (< 0: per-sample), m (0).  x_out may be x."""
+    _need_cuda(x, lin, lin_bias, gate, shift, scale)
+    N = x.shape[-1]
+    rows, ldx = _rows2d(x)
+    rl, ldl = _rows2d(lin)
+    assert rl == rows and lin.shape[-1] == N
+    xo = torch.empty(x.shape, dtype=torch.float32, device=x.device) if x_out is None else x_out
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    ldg = _rows2d(gate)[1] if gate is not None else 0
+    T, ldt = 0, 0
+    if shift is not None:
+        assert scale is not None and shift.dim() == 2 and shift.shape == scale.shape and shift.stride(0) == scale.stride(0) and shift.stride(1) == 1 == scale.stride(1)
+        T, ldt = shift.shape[0], shift.stride(0)
+        if per_sample:
+            assert x.dim() == 3 and shift.shape[0] == x.shape[0]
+            T = -x.shape[1]
+    _lib.check(_lib.load().selftok_ex_res_layernorm_mod_f32(_p(x), ldx, _p(lin), ldl, _p(lin_bias), _p(gate), ldg, int(gate_mod), _p(xo), _rows2d(xo)[1], _p(out), N,
+                                                            _p(shift), _p(scale), ldt, T, rows, N, float(eps), _stream()), "selftok_ex_res_layernorm_mod_f32")
+    return xo, out
+
+
 EX_UNARY = {"gelu_tanh": 0, "silu": 1, "sleef_expf": 2, "sleef_tanhf": 3, "exp_u20": 4}
 
 

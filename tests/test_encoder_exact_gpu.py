@@ -117,6 +117,34 @@ def test_layernorm_aten_order(N, affine, mod):
     _same(out, ref, f"LayerNorm({N})")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("per_sample,bias_last,with_gate", [(False, True, True), (True, False, True), (False, False, False)])
+def test_residual_update_fused_into_layernorm(per_sample, bias_last, with_gate):
+    """round 6: x' = x + gate * (Linear(.) [+ bias last]) inside the LayerNorm + modulate pass = the Linear's res + gate epilogue followed by ex_layernorm_mod, bit for bit
+    (the MMDiT's per-token context tables and per-sample image tables, sd3/mmdit.py:485-496), incl. x' written in place"""
+    B, T, N, K = 3, 200, 1536, 1536
+    x = _rand(0xD0, (B, T, N), 1.5).cuda()
+    a = _rand(0xD1, (B, T, K), 1.0).cuda()
+    w = _rand(0xD2, (N, K), (1.0 / K) ** 0.5).cuda()
+    b = _rand(0xD3, (N,), 0.2).cuda()
+    tab = _rand(0xD4, (B if per_sample else T, 6 * N), 0.6).cuda()
+    gate = tab[:, 2 * N:3 * N] if with_gate else None
+    gm = (-T if per_sample else T) if with_gate else 0
+    sh, sc = tab[:, 3 * N:4 * N], tab[:, 4 * N:5 * N]
+    x1 = ops.ex_linear(a, w, b, res=x, gate=gate, gate_mod=gm, bias_last=bias_last, kernel="xe")
+    n1 = ops.ex_layernorm_mod(x1, shift=sh, scale=sc, per_sample=per_sample)
+    y = ops.ex_linear(a, w, None if bias_last else b, kernel="xe")
+    x2, n2 = ops.ex_res_layernorm_mod(x, y, lin_bias=b if bias_last else None, gate=gate, gate_mod=gm, shift=sh, scale=sc, per_sample=per_sample)
+    torch.cuda.synchronize()
+    _same(x2, x1.cpu().numpy(), "x'")
+    _same(n2, n1.cpu().numpy(), "LayerNorm(x') modulated")
+    xi = x.clone()
+    x3, n3 = ops.ex_res_layernorm_mod(xi, y, lin_bias=b if bias_last else None, gate=gate, gate_mod=gm, shift=sh, scale=sc, per_sample=per_sample, x_out=xi)
+    assert x3.data_ptr() == xi.data_ptr()
+    _same(x3, x1.cpu().numpy(), "x' in place")
+    _same(n3, n1.cpu().numpy(), "LayerNorm(x') modulated, in place")
+
+
 # ---- attention -------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,B,H,Tq,Tk1,Tk2,D", [("latent self-attention 4 x 16", 2, 4, 256, 256, 0, 16), ("query attention 8 x 64, 256 + 512 keys", 2, 8, 512, 256, 512, 64),
