@@ -753,6 +753,8 @@ def _rows2d(t: torch.Tensor):
     return rows, ld
 
 
+EX_LINEAR_GELU_ON_XE = True     # fc1 + GELU stays on xe_gemm128 with the GELU in its epilogue: in the model 620 / 252 ms per sampler step against 625 - 641 / 255 with
+                                # csrc/gemm_fp32.hip + a GELU pass (profiles/r6_exact_mode_ab_v11_fused_ln.txt; the difference is inside the run-to-run noise, the pass is not)
 EX_LINEAR_SG_MIN_ROWS = 256     # from this many rows on `ex_linear` runs on the LDS-DMA staged kernel (csrc/gemm_fp32.hip, bit-identical results) where the shape allows
 
 
@@ -766,7 +768,8 @@ def ex_linear(x: torch.Tensor, weight: torch.Tensor, bias=None, *, gelu: bool = 
     N, K = weight.shape
     if kernel not in ("auto", "xe", "sg"):
         raise ValueError(f"ex_linear kernel {kernel!r}: expected 'auto', 'xe' or 'sg'")
-    if kernel == "sg" or (kernel == "auto" and linear_f32_supported(N, K, mkl_order=True) and x.numel() // max(K, 1) >= EX_LINEAR_SG_MIN_ROWS):
+    if kernel == "sg" or (kernel == "auto" and linear_f32_supported(N, K, mkl_order=True) and x.numel() // max(K, 1) >= EX_LINEAR_SG_MIN_ROWS
+                          and not (gelu and EX_LINEAR_GELU_ON_XE)):
         if kernel == "auto" and gelu and res is None and (out is None or out.is_contiguous()):
             # fc1 + GELU: the Sleef-arithmetic GELU costs ~80 VALU instructions per output; in the GEMM's epilogue four waves per CU work through it while the
             # matrix pipe idles (measured +0.40 ms on a 2.28 ms Linear), as its own element-wise pass over every SIMD +0.2 ms.  Same bits: GELU of the same fp32 value.

@@ -26,8 +26,10 @@ def run(k_table):
 
 res = {}
 for name, min_rows, attn in (("sg (csrc/gemm_fp32.hip)", 256, "auto"), ("xe_gemm128 (round 5)", 10 ** 9, "auto"), ("sg again", 256, "auto"),
+                             ("sg, fc1 + GELU on xe_gemm128", -256, "auto"), ("xe_gemm128 again", 10 ** 9, "auto"),
                              ("sg, attention unfused (round 5)", 256, "unfused"), ("sg, attention fused", 256, "auto")):
-    ops.EX_LINEAR_SG_MIN_ROWS = min_rows
+    ops.EX_LINEAR_SG_MIN_ROWS = abs(min_rows)
+    ops.EX_LINEAR_GELU_ON_XE = min_rows < 0
     ops.EX_ATTENTION_DEFAULT = attn
     for label, kt in (("first steps (context 512..)", pipe.k_table), ("last steps (context ..20)", pipe.k_table[-steps:])):
         run(kt)
