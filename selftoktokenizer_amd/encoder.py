@@ -72,8 +72,9 @@ class QformerEncoderGPU(ModuleSurface):
     _sd_prefix = "encoder."
     def __init__(self, sd: Dict[str, torch.Tensor], device, K: int, mode: str = "exact"):
         """`mode`: 'exact' (default) -- every reduction / transcendental in the summation order torch-CPU executes for the reference
-        (csrc/encoder_exact.hip): the pre-quantizer features, and with them the token ids, are the reference's bit for bit and do not
-        depend on the batch size; 'fast' -- hipBLASLt GEMMs + the rounds 1-3 fused kernels (features within 6e-5, ids equal except
+        (csrc/encoder_exact.hip): the pre-quantizer features, and with them the token ids, are those of the reference's runs at 8 <= B <= 64
+        images per call bit for bit, and do not depend on the batch size HERE (every kernel is row independent; the reference's own B = 1 run
+        takes another MKL path, which this mode does not follow: DESIGN 15.2); 'fast' -- hipBLASLt GEMMs + the rounds 1-3 fused kernels (features within 6e-5, ids equal except
         at reference near-ties, ~2x faster encoder)."""
         g = lambda k: sd[k].to(device=device, dtype=torch.float32).contiguous()
         if mode not in ("exact", "fast"):

@@ -760,7 +760,9 @@ EX_LINEAR_SG_MIN_ROWS = 256     # from this many rows on `ex_linear` runs on the
 
 def ex_linear(x: torch.Tensor, weight: torch.Tensor, bias=None, *, gelu: bool = False, res=None, res_mod: int = 0, gate=None, gate_mod: int = 0,
               out: Optional[torch.Tensor] = None, bias_last: bool = False, kernel: str = "auto") -> torch.Tensor:
-    """F.linear in MKL sgemm's summation order (bit-equal to torch-CPU's nn.Linear for M >= 512 rows), optional exact GELU(tanh),
+    """F.linear in MKL sgemm's BLOCKED summation order -- bit-equal to torch-CPU's nn.Linear where MKL takes that path (probed: M >= 512 token rows, >= 16
+    conditioning rows; below that MKL switches strategy and this kernel still computes the blocked order: the result for a row is the one it has inside a large
+    batch, whatever M is here), optional exact GELU(tanh),
     optional `res + gate * y` epilogue (res / gate rows taken modulo res_mod / gate_mod when positive: per-token tables; divided by
     -mod when negative: per-sample tables).  bias_last: (sum of the K-blocks) + bias, what at::linear computes for a non-contiguous input.
     `kernel`: 'xe' = xe_gemm / xe_gemm128 (csrc/encoder_exact.hip, any shape), 'sg' = the LDS-DMA staged kernel of round 6 (csrc/gemm_fp32.hip: N % 128 == 0,
@@ -890,6 +892,7 @@ def ex_unary(x: torch.Tensor, kind: str, out: Optional[torch.Tensor] = None) -> 
     return y
 
 
+EX_ATTENTION_WS_LIMIT = 6 << 30          # bytes of score workspace one call of the unfused exact attention may allocate; larger batches run in slices
 EX_ATTENTION_DEFAULT = "auto"     # what kernel='auto' means in ex_attention (tools set 'unfused' for A/B runs)
 
 
@@ -928,7 +931,14 @@ def ex_attention(q: torch.Tensor, k1, v1, heads: int, k2=None, v2=None, slots1: 
         _lib.check(lib.selftok_ex_attention_fused_f32(_p(q), qs, _p(k1), _p(v1), ks1, Tk1, rows1, rows1, _p(k2), _p(v2), ks2, Tk2, _p(out), B, heads, Tq, D, _stream()),
                    "selftok_ex_attention_fused_f32")
         return out
-    ws = torch.empty(lib.selftok_ex_attention_workspace_bytes(B, heads, Tq, Tk1 + Tk2, D), dtype=torch.uint8, device=q.device)
-    _lib.check(lib.selftok_ex_attention_f32(_p(q), qs, _p(k1), _p(v1), ks1, Tk1, rows1, rows1, _p(k2), _p(v2), ks2, Tk2, _p(out), _p(ws), B, heads, Tq, D, _stream()),
-               "selftok_ex_attention_f32")
+    # the unfused route materialises the scores (B * heads * Tq * Tk * 4 bytes + V^T): bounded by running the batch in slices (rows are independent: same bits),
+    # which also keeps B * heads inside gridDim.z
+    per = int(lib.selftok_ex_attention_workspace_bytes(1, heads, Tq, Tk1 + Tk2, D))
+    nb = max(1, min(B, EX_ATTENTION_WS_LIMIT // max(per, 1), 65535 // max(heads, 1)))
+    ws = torch.empty(int(lib.selftok_ex_attention_workspace_bytes(nb, heads, Tq, Tk1 + Tk2, D)), dtype=torch.uint8, device=q.device)
+    for b0 in range(0, B, nb):
+        n = min(nb, B - b0)
+        sl = lambda t: None if t is None else t[b0:b0 + n]
+        _lib.check(lib.selftok_ex_attention_f32(_p(sl(q)), qs, _p(sl(k1)), _p(sl(v1)), ks1, Tk1, rows1, rows1, _p(sl(k2)), _p(sl(v2)), ks2, Tk2, _p(out[b0:b0 + n]), _p(ws),
+                                                n, heads, Tq, D, _stream()), "selftok_ex_attention_f32")
     return out

@@ -186,8 +186,9 @@ class SelftokPipeline():
         'parity' elsewhere; decode 'parity' (pixels within the north star's 1e-3 dB of the reference either way), and 'exact' while gemm == 'exact'
         (the mode whose pixels ARE the reference's) unless `vae_decode_mode` / `vae_mode` was given.
         `encoder_mode` (extension): 'exact' (default: the Q-Former encoder in the summation order of every reduction and the polynomial of every
-        transcendental torch-CPU executes for the reference, csrc/encoder_exact.hip -- pre-quantizer features and token ids equal the reference's
-        bit for bit at every batch size) or 'fast' (hipBLASLt GEMMs + the fused rounds 1-3 kernels: features within 6e-5, ~2x faster encoder).
+        transcendental torch-CPU executes for the reference, csrc/encoder_exact.hip -- pre-quantizer features and token ids equal those of the
+        reference's runs at 8 <= B <= 64 images per call bit for bit, and are the same here for every batching; the reference itself takes other MKL paths at
+        B = 1 and for Linears below 16 / 512 rows, which this mode does not follow: DESIGN 15.2, 15.8) or 'fast' (hipBLASLt GEMMs + the fused rounds 1-3 kernels: features within 6e-5, ~2x faster encoder).
         No environment variable is read: every knob is a constructor argument.
         `tune_gemm` (extension, OPT-IN): pick hipBLASLt's kernel for the fp32 block Linears by a ~4 s measurement per batch size
         (gemm_tune.py) -- up front through `pipe.tune_linears(batch)`, or at the first decode of a batch size.  TunableOp is enabled

@@ -433,6 +433,11 @@ class AutoencoderKLGPU(ModuleSurface):
     @torch.no_grad()
     def decode(self, z, return_dict=False):
         if self.decode_mode == "exact":
+            if z.shape[0] > 64 and not getattr(self, "_warned_big_exact_decode", False):
+                import warnings
+                self._warned_big_exact_decode = True            # say it once instead of extrapolating silently
+                warnings.warn(f"exact VAE decode of {z.shape[0]} images in one call: oneDNN's order switch at 2^31-byte activations was probed at 48 / 64 images per call; "
+                              "above 64 the layer set that switches is an extrapolation (no reference run to pin it) -- decode in calls of <= 64 images for pinned pixels")
             return (self._x_decode(z),)
         if self.decode_mode == "parity":
             return (self._n_decode(z),)

@@ -187,6 +187,23 @@ def test_attention_fused_equals_unfused_with_a_prefix_mask(slots, valid, Tk2, Tq
     _same(a, b.cpu().numpy(), f"fused vs unfused, {valid} of {slots} context keys + {Tk2}, {Tq} rows")
 
 
+@pytest.mark.gpu
+def test_unfused_attention_runs_a_large_batch_in_slices(monkeypatch):
+    """the unfused route's score workspace is bounded -- above `ops.EX_ATTENTION_WS_LIMIT` the batch runs in slices (rows are independent: the same bits)"""
+    B, H, D, Tq, valid, Tk2 = 5, 3, 64, 200, 130, 256
+    HD = H * D
+    q = _rand(0xD0, (B, Tq, 3 * HD), 1.3).cuda()
+    ctx = _rand(0xD1, (B, valid, 3 * HD), 1.3).cuda()
+    x = _rand(0xD2, (B, Tk2, 3 * HD), 1.3).cuda()
+    args = (q[..., :HD], ctx[..., HD:2 * HD], ctx[..., 2 * HD:], H, x[..., HD:2 * HD], x[..., 2 * HD:])
+    whole = ops.ex_attention(*args, slots1=512, kernel="unfused")
+    per = int(ops._lib.load().selftok_ex_attention_workspace_bytes(1, H, Tq, 512 + Tk2, D))
+    monkeypatch.setattr(ops, "EX_ATTENTION_WS_LIMIT", 2 * per)                   # slices of 2, 2, 1 samples
+    sliced = ops.ex_attention(*args, slots1=512, kernel="unfused")
+    torch.cuda.synchronize()
+    _same(sliced, whole.cpu().numpy(), "unfused attention, batch in slices of two")
+
+
 # ---- the whole encoder against the REFERENCE's own runs --------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def encoder():
