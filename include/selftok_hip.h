@@ -317,7 +317,8 @@ int selftok_vx_expf_f32(const float* x, float* y, long n, hipStream_t stream);
  *                             out = ((bias + c0) + c1) + ...): bit-identical to selftok_ex_linear_f32, the kernel of gemm='exact'.  Without it the order is
  *                             free: ONE k-ascending chain per output over the whole K (tail tiles: a few, see below), bias added last -- the kernel of gemm='fp32'
  *                             where it beats the library's.
- *   SELFTOK_LINEAR_GELU       out = GELU_tanh(out), ATen / Sleef arithmetic (as SELFTOK_EX_GELU)
+ *   SELFTOK_LINEAR_GELU       out = GELU_tanh(out), ATen / Sleef arithmetic (as SELFTOK_EX_GELU); a second launch over `out`: needs ldo == N and no res / gate
+ *                             (the Mlp's fc1 -> act, sd3/other_impls.py:82-90, has neither), SELFTOK_EINVAL otherwise
  *   SELFTOK_LINEAR_BIAS_LAST  as SELFTOK_EX_BIAS_LAST
  *   SELFTOK_LINEAR_SPLIT(n)   tools / tests: force the tail split to n units (0: planned)
  * res / gate / res_mod / gate_mod / aliasing: as selftok_ex_linear_f32.

@@ -121,7 +121,7 @@ def crop_pos(pos, h, w):
     return pos.reshape(grid, grid, -1)[top:top + h, left:left + w].reshape(1, h * w, -1)
 
 
-def encoder_features(sd, x0, pos_emb, tables=None, bias_first=0, trace=None):
+def encoder_features(sd, x0, pos_emb, tables=None, bias_first=0, trace=None, pre_norm=False):
     """x0 [B,16,h,w] fp32 -> pre-quantizer features z [B,K,16] with the reference's bits (B >= 8: see encoder_exact.c)"""
     g = lambda k: sd[k].detach().cpu().numpy() if hasattr(sd[k], "detach") else sd[k]
     x0 = _f32(x0)
@@ -152,4 +152,6 @@ def encoder_features(sd, x0, pos_emb, tables=None, bias_first=0, trace=None):
         q = q + g_mlp * linear(h, g(p + ".q_mlp.fc2.weight"), g(p + ".q_mlp.fc2.bias"))
         if trace is not None:
             trace.append((x.copy(), q.copy()))
+    if pre_norm:                                     # models_ours.py:219-220: outs = self.final_layer_norm(outs)
+        q = layernorm(q, g("encoder.final_layer_norm.weight"), g("encoder.final_layer_norm.bias"))
     return linear(q, g("encoder.quantizer.project_in.weight"), g("encoder.quantizer.project_in.bias"))

@@ -132,9 +132,10 @@ def dual_block(sd: SD, i: int, x: torch.Tensor, q: torch.Tensor, table: torch.Te
     return x, q
 
 
-def encoder_features(sd: SD, x0: torch.Tensor, tables=None) -> torch.Tensor:
+def encoder_features(sd: SD, x0: torch.Tensor, tables=None, pre_norm: bool = False) -> torch.Tensor:
     """x0 [B,16,32,32] fp32 (process_in'ed VAE mean) -> pre-quantizer features z [B,K,16]
-    (Encoder.forward up to and incl. quantizer.project_in: models_ours.py:204-221, vq:844)"""
+    (Encoder.forward up to and incl. quantizer.project_in: models_ours.py:204-221, vq:844).  pre_norm: `outs = self.final_layer_norm(outs)`
+    before the quantizer (models_ours.py:219-220; encoder_config.pre_norm, False in the shipped configs)"""
     K = sd["encoder.query_tokens"].shape[1]
     tables = tables or encoder_tables(sd, K)
     B, _, H, W = x0.shape
@@ -143,6 +144,8 @@ def encoder_features(sd: SD, x0: torch.Tensor, tables=None) -> torch.Tensor:
     q = sd["encoder.query_tokens"].expand(B, -1, -1)
     for i in range(ENC_DEPTH):
         x, q = dual_block(sd, i, x, q, tables[i])
+    if pre_norm:
+        q = F.layer_norm(q, (q.shape[-1],), sd["encoder.final_layer_norm.weight"], sd["encoder.final_layer_norm.bias"], 1e-6)
     return lin(sd, "encoder.quantizer.project_in", q)
 
 

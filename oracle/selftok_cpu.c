@@ -1019,6 +1019,7 @@ int selftok_linear_f32(const float* x, long ldx, const float* w, const float* bi
     (void)workspace; (void)workspace_bytes;
     if (M == 0) return SELFTOK_OK;
     if (!x || !w || !out || M < 0 || N <= 0 || K <= 0 || N % 128 || K % 32 || ldx % 4 || ldx < K || ldo < N || ldo % 4 || (gate && !res)) return fail("linear_f32: bad argument");
+    if ((flags & SELFTOK_LINEAR_GELU) && (res || gate || ldo != N)) return fail("linear_f32: SELFTOK_LINEAR_GELU needs a contiguous out and no res / gate");
     if (flags & SELFTOK_LINEAR_MKL_ORDER) {
         if (K > 384 && K < 768) return fail("linear_f32: MKL order for 384 < K < 768 is served by selftok_ex_linear_f32");
         return selftok_ex_linear_f32(x, ldx, w, bias, res, ldr, res_mod, gate, ldg, gate_mod, out, ldo, M, N, K,

@@ -103,7 +103,6 @@ __device__ __forceinline__ void sg_dma16(const void* base, unsigned voff, unsign
 __device__ __forceinline__ float sg_epilogue(const SgArgs& g, float v, int m, int n)
 {
     if (g.bias_last && g.bias != nullptr) v = v + g.bias[n];
-    if (g.gelu) v = xe_gelu_tanh1(v);
     if (g.gate != nullptr) v = g.gate[(size_t)(g.gate_mod > 0 ? m % g.gate_mod : (g.gate_mod < 0 ? m / -g.gate_mod : m)) * g.ldg + n] * v;
     if (g.res != nullptr) v = g.res[(size_t)(g.res_mod > 0 ? m % g.res_mod : (g.res_mod < 0 ? m / -g.res_mod : m)) * g.ldr + n] + v;
     return v;
@@ -225,7 +224,8 @@ __global__ __launch_bounds__(SG_THREADS, 3) void sg_gemm_kernel(SgArgs g)
     if (MKL) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const float b0 = (g.bias != nullptr && !g.bias_last && unit < 0) ? g.bias[col0 + 64 * wn + 32 * t + i] : 0.f;
+            // a tail unit's plane is its raw chain: C starts at -0 there (-0 + x = x for every x, signed zeros included), so that after the loop only C is live
+            const float b0 = unit >= 0 ? -0.f : ((g.bias != nullptr && !g.bias_last) ? g.bias[col0 + 64 * wn + 32 * t + i] : 0.f);
 #pragma unroll
             for (int r = 0; r < 32; ++r) C[t][r] = b0;
         }
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(SG_THREADS, 3) void sg_gemm_kernel(SgArgs g)
             va = na; vb0 = nb0; vb1 = nb1;
         }
         SG_TS(kc, 2);
-        if (MKL && unit < 0 && (++cb == g.blk_chunks || kc + 1 == nch)) {         // K-block done: C += chain, the next chain starts from 0 (a tail unit IS one K-block)
+        if (MKL && (++cb == g.blk_chunks || kc + 1 == nch)) {                     // K-block done: C += chain, the next chain starts from 0 (a tail unit IS one K-block)
             cb = 0;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(SG_THREADS, 3) void sg_gemm_kernel(SgArgs g)
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    p[(64 * wm + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h) * SG_BN + 64 * wn + 32 * t + i] = acc[t][16 * b + r];
+                    p[(64 * wm + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h) * SG_BN + 64 * wn + 32 * t + i] = MKL ? C[t][16 * b + r] : acc[t][16 * b + r];
                     __builtin_amdgcn_sched_barrier(0);
                 }
         return;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(SG_THREADS, 3) void sg_gemm_kernel(SgArgs g)
     // workgroup's MFMAs (they do not overlap: same port), so it is kept short: uniform decisions hoisted, row addresses scalar (row base in SGPRs + one
     // per-lane offset), the table rows of gate / res looked up in LDS. ----
     __builtin_amdgcn_s_setprio(3);
-    const bool plain = !g.gelu && g.gate == nullptr && g.res == nullptr && !(g.bias_last && g.bias != nullptr);
+    const bool plain = g.gate == nullptr && g.res == nullptr && !(g.bias_last && g.bias != nullptr);
     const bool whole = row0 + SG_BM <= g.M;
     const int ncol = col0 + 64 * wn + i;
     if (plain && whole) {
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(SG_THREADS, 3) void sg_gemm_kernel(SgArgs g)
         }
         return;
     }
-    const bool has_gate = g.gate != nullptr, has_res = g.res != nullptr, bias_l = g.bias_last && g.bias != nullptr, gelu = g.gelu != 0;
+    const bool has_gate = g.gate != nullptr, has_res = g.res != nullptr, bias_l = g.bias_last && g.bias != nullptr;
     // the row of the gate / res table for every row of the tile: one integer division per ROW (not per output), kept in the first KiB of the stage memory -- free now:
     // every chunk was consumed.  (A separate 1-KiB array made the workgroup 65 KiB and the hardware then admitted ONE workgroup per CU, whatever the occupancy query
     // said: profiles/r6_sgemm_v8_stamps.txt.)  The loaders have left; the barrier counts the eight compute waves.
@@ -340,30 +340,34 @@ __global__ __launch_bounds__(SG_THREADS, 3) void sg_gemm_kernel(SgArgs g)
         const float blast = bias_l ? g.bias[n] : 0.f;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            float gv[16], rv[16];
+            // EB outputs at a time (16 = one 32 x 32 block's rows of this lane)
+            constexpr int EB = 16;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { gv[r] = 1.f; rv[r] = 0.f; }
-            if (has_gate) {                                 // the uniform decision OUTSIDE the 16 loads: inside, every load sat in its own branch with its own wait
+            for (int r0 = 0; r0 < 16; r0 += EB) {
+                float gv[EB], rv[EB];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    gv[r] = *reinterpret_cast<const float*>(gbase + ((unsigned)rowidx[0][64 * wm + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h] * ldg4 + n4));
-            }
-            if (has_res) {
+                for (int r = 0; r < EB; ++r) { gv[r] = 1.f; rv[r] = 0.f; }
+                if (has_gate) {                             // the uniform decision OUTSIDE the loads: inside, every load sat in its own branch with its own wait
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    rv[r] = *reinterpret_cast<const float*>(rbase + ((unsigned)rowidx[1][64 * wm + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h] * ldr4 + n4));
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int r = 0; r < EB; ++r)
+                        gv[r] = *reinterpret_cast<const float*>(gbase + ((unsigned)rowidx[0][64 * wm + 32 * b + ((r0 + r) & 3) + 8 * ((r0 + r) >> 2) + 4 * h] * ldg4 + n4));
+                }
+                if (has_res) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = 64 * wm + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float v = MKL ? C[t][16 * b + r] : acc[t][16 * b + r] + bfree;
-                if (bias_l) v = v + blast;
-                if (gelu) v = xe_gelu_tanh1(v);
-                if (has_gate) v = gv[r] * v;
-                if (has_res) v = rv[r] + v;
-                if (whole || row0 + ml < g.M) *reinterpret_cast<float*>(cbase + ((unsigned)ml * ldc4 + n4)) = v;
-                __builtin_amdgcn_sched_barrier(0);          // the arithmetic one output at a time (16 interleaved GELUs would set the kernel's register count)
+                    for (int r = 0; r < EB; ++r)
+                        rv[r] = *reinterpret_cast<const float*>(rbase + ((unsigned)rowidx[1][64 * wm + 32 * b + ((r0 + r) & 3) + 8 * ((r0 + r) >> 2) + 4 * h] * ldr4 + n4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < EB; ++r) {
+                    const int ml = 64 * wm + 32 * b + ((r0 + r) & 3) + 8 * ((r0 + r) >> 2) + 4 * h;
+                    float v = MKL ? C[t][16 * b + r0 + r] : acc[t][16 * b + r0 + r] + bfree;
+                    if (bias_l) v = v + blast;
+                    if (has_gate) v = gv[r] * v;
+                    if (has_res) v = rv[r] + v;
+                    if (whole || row0 + ml < g.M) *reinterpret_cast<float*>(cbase + ((unsigned)ml * ldc4 + n4)) = v;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
@@ -470,6 +474,10 @@ int selftok_linear_f32(const float* x, long ldx, const float* w, const float* bi
         return SELFTOK_EINVAL;
     }
     const bool mkl = (flags & SELFTOK_LINEAR_MKL_ORDER) != 0;
+    // GELU (fc1 -> act, no residual in the reference) is a second launch over `out`: ~80 VALU instructions per output inside the GEMM's epilogue kept four waves per
+    // CU busy while the matrix pipe idled (+0.40 ms on a 2.28 ms Linear) and set the kernel's register count; as an element-wise pass over every SIMD it is +0.2 ms
+    const bool gelu = (flags & SELFTOK_LINEAR_GELU) != 0;
+    if (gelu && (res || gate || ldo != N)) { set_last_error("linear_f32: SELFTOK_LINEAR_GELU needs a contiguous out and no res / gate (the Mlp's fc1 -> act)"); return SELFTOK_EINVAL; }
     if (mkl && K > 384 && K < 768) { set_last_error("linear_f32: MKL order for 384 < K < 768 (two half blocks) is served by selftok_ex_linear_f32"); return SELFTOK_EINVAL; }
     const int force = (flags >> 8) & 0xff;                       // tools / tests: SELFTOK_LINEAR_SPLIT(n) forces the tail split
     SgPlan p = sg_plan(M, N, K, mkl, workspace ? workspace_bytes : 0, 0);
@@ -483,17 +491,20 @@ int selftok_linear_f32(const float* x, long ldx, const float* w, const float* bi
     g.res = res; g.ldr = ldr; g.res_mod = res_mod; g.gate = gate; g.ldg = ldg; g.gate_mod = gate_mod;
     g.ws = (float*)workspace;
     g.flat_prio = (flags >> 16) & 1;
-    g.M = (int)M; g.N = N; g.K = K; g.gelu = (flags & SELFTOK_LINEAR_GELU) ? 1 : 0; g.bias_last = (flags & SELFTOK_LINEAR_BIAS_LAST) ? 1 : 0;
+    g.M = (int)M; g.N = N; g.K = K; g.gelu = 0; g.bias_last = (flags & SELFTOK_LINEAR_BIAS_LAST) ? 1 : 0;
     g.mt = p.mt; g.nt = p.nt; g.tiles = p.tiles; g.per = p.per; g.full_pos = p.full_pos; g.tail_cnt = p.tail_cnt; g.split = p.split; g.planes = p.planes;
     g.blk_chunks = (!mkl && p.split > 1) ? p.nchunks / p.split : p.blk_chunks; g.nchunks = p.nchunks;
     const unsigned grid = 8u * (unsigned)(p.full_pos + p.tail_cnt * p.split);
     if (mkl) hipLaunchKernelGGL((sg_gemm_kernel<true>), dim3(grid), dim3(SG_THREADS), 0, stream, g);
     else hipLaunchKernelGGL((sg_gemm_kernel<false>), dim3(grid), dim3(SG_THREADS), 0, stream, g);
     int rc = check_launch("sg_gemm_kernel");
-    if (rc || p.tail_cnt == 0) return rc;
-    if (mkl) hipLaunchKernelGGL((sg_tail_finish_kernel<true>), dim3(SG_PLANE / 1024, 8 * p.tail_cnt), dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((sg_tail_finish_kernel<false>), dim3(SG_PLANE / 1024, 8 * p.tail_cnt), dim3(256), 0, stream, g);
-    return check_launch("sg_tail_finish_kernel");
+    if (rc) return rc;
+    if (p.tail_cnt > 0) {
+        if (mkl) hipLaunchKernelGGL((sg_tail_finish_kernel<true>), dim3(SG_PLANE / 1024, 8 * p.tail_cnt), dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((sg_tail_finish_kernel<false>), dim3(SG_PLANE / 1024, 8 * p.tail_cnt), dim3(256), 0, stream, g);
+        if ((rc = check_launch("sg_tail_finish_kernel")) != 0) return rc;
+    }
+    return gelu ? selftok_ex_unary_f32(out, out, M * (long)N, 0, stream) : SELFTOK_OK;
 }
 
 }  // extern "C"

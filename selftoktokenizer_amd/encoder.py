@@ -70,12 +70,14 @@ class _Quantizer:
 
 class QformerEncoderGPU(ModuleSurface):
     _sd_prefix = "encoder."
-    def __init__(self, sd: Dict[str, torch.Tensor], device, K: int, mode: str = "exact"):
+    def __init__(self, sd: Dict[str, torch.Tensor], device, K: int, mode: str = "exact", pre_norm: bool = False):
         """`mode`: 'exact' (default) -- every reduction / transcendental in the summation order torch-CPU executes for the reference
         (csrc/encoder_exact.hip): the pre-quantizer features, and with them the token ids, are those of the reference's runs at 8 <= B <= 64
         images per call bit for bit, and do not depend on the batch size HERE (every kernel is row independent; the reference's own B = 1 run
         takes another MKL path, which this mode does not follow: DESIGN 15.2); 'fast' -- hipBLASLt GEMMs + the rounds 1-3 fused kernels (features within 6e-5, ids equal except
-        at reference near-ties, ~2x faster encoder)."""
+        at reference near-ties, ~2x faster encoder).  `pre_norm`: encoder_config.pre_norm (models_ours.py:219-220): final_layer_norm on the query tokens
+        before the quantizer (ATen's LayerNorm arithmetic in both modes)."""
+        self.pre_norm = bool(pre_norm)
         g = lambda k: sd[k].to(device=device, dtype=torch.float32).contiguous()
         if mode not in ("exact", "fast"):
             raise ValueError(f"encoder mode {mode!r}: expected 'exact' or 'fast'")
@@ -156,6 +158,12 @@ class QformerEncoderGPU(ModuleSurface):
             self._pos_cache[key] = pe.reshape(grid, grid, -1)[top:top + h, left:left + w].reshape(h * w, -1).contiguous()
         return self._pos_cache[key]
 
+    def _pre_norm(self, q: torch.Tensor) -> torch.Tensor:
+        """`outs = self.final_layer_norm(outs)` (models_ours.py:219-220) when encoder_config.pre_norm"""
+        if not self.pre_norm:
+            return q
+        return ops.ex_layernorm_mod(q, gamma=self.w["encoder.final_layer_norm.weight"], beta=self.w["encoder.final_layer_norm.bias"])
+
     @torch.no_grad()
     def features_exact(self, x0: torch.Tensor) -> torch.Tensor:
         """`features` with every operation in the order / polynomial torch-CPU executes for the reference (models_ours.py:204-257,
@@ -184,7 +192,7 @@ class QformerEncoderGPU(ModuleSurface):
             q = lin(p + ".attn.query_proj", qa, res=q, gate=t[:, 2 * Q:3 * Q], gate_mod=K)   # q + g1 * proj(attn_q)
             h = lin(p + ".q_mlp.fc1", ops.ex_layernorm_mod(q, shift=t[:, 3 * Q:4 * Q], scale=t[:, 4 * Q:5 * Q]), gelu=True)
             q = lin(p + ".q_mlp.fc2", h, res=q, gate=t[:, 5 * Q:6 * Q], gate_mod=K)          # q + g2 * mlp_q(mod(LN(q)))
-        return lin("encoder.quantizer.project_in", q)
+        return lin("encoder.quantizer.project_in", self._pre_norm(q))
 
     @torch.no_grad()
     def features(self, x0: torch.Tensor) -> torch.Tensor:
@@ -226,7 +234,7 @@ class QformerEncoderGPU(ModuleSurface):
             else:
                 tn = tab[i + 1]
                 q, qn = ops.residual_ln_mod(q, y=m, gate=t[:, 5 * Q:6 * Q], shift=tn[:, 0:Q], scale=tn[:, Q:2 * Q])
-        return self.lin("encoder.quantizer.project_in", q)
+        return self.lin("encoder.quantizer.project_in", self._pre_norm(q))
 
     @torch.no_grad()
     def __call__(self, x=None, hidden_states=None, d=None, kwargs=None):

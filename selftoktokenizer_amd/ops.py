@@ -770,13 +770,11 @@ def ex_linear(x: torch.Tensor, weight: torch.Tensor, bias=None, *, gelu: bool = 
     N, K = weight.shape
     if kernel not in ("auto", "xe", "sg"):
         raise ValueError(f"ex_linear kernel {kernel!r}: expected 'auto', 'xe' or 'sg'")
-    if kernel == "sg" or (kernel == "auto" and linear_f32_supported(N, K, mkl_order=True) and x.numel() // max(K, 1) >= EX_LINEAR_SG_MIN_ROWS
+    sg_ok = not (gelu and (res is not None or gate is not None or (out is not None and not out.is_contiguous())))      # the LDS-DMA kernel's GELU: contiguous out, no res / gate
+    if kernel == "sg" or (kernel == "auto" and sg_ok and linear_f32_supported(N, K, mkl_order=True) and x.numel() // max(K, 1) >= EX_LINEAR_SG_MIN_ROWS
                           and not (gelu and EX_LINEAR_GELU_ON_XE)):
-        if kernel == "auto" and gelu and res is None and (out is None or out.is_contiguous()):
-            # fc1 + GELU: the Sleef-arithmetic GELU costs ~80 VALU instructions per output; in the GEMM's epilogue four waves per CU work through it while the
-            # matrix pipe idles (measured +0.40 ms on a 2.28 ms Linear), as its own element-wise pass over every SIMD +0.2 ms.  Same bits: GELU of the same fp32 value.
-            y = linear_f32(x, weight, bias, mkl_order=True, out=out, bias_last=bias_last)
-            return ex_unary(y, "gelu_tanh", out=y)
+        # fc1 + GELU: selftok_linear_f32 runs the GELU as a second launch over `out` (in the GEMM's epilogue four waves per CU worked through ~80 VALU instructions
+        # per output while the matrix pipe idled: +0.40 ms on a 2.28 ms Linear; as an element-wise pass +0.2 ms).  Same bits: GELU of the same fp32 value.
         return linear_f32(x, weight, bias, mkl_order=True, gelu=gelu, res=res, res_mod=res_mod, gate=gate, gate_mod=gate_mod, out=out, bias_last=bias_last)
     _need_cuda(x, weight, bias, res, gate)
     assert weight.dtype == torch.float32 and weight.is_contiguous() and x.shape[-1] == K

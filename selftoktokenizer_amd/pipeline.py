@@ -227,9 +227,7 @@ class SelftokPipeline():
         cut = p.get("cut_of_k", None)
         if cut and float(cut) < 1:
             raise NotImplementedError("cut_of_k < 1 (context padding, rectified_flow.py:216-224) is not implemented; the shipped configs do not set it")
-        if bool(p.get("encoder_config", {}).get("pre_norm", False)):
-            raise NotImplementedError("encoder_config.pre_norm = True (Encoder.forward applies final_layer_norm to the image tokens, "
-                                      "models_ours.py:219-220) is not implemented; the shipped configs set it False")
+        pre_norm = bool(p.get("encoder_config", {}).get("pre_norm", False))        # models_ours.py:219-220 (round 6; False in the shipped configs)
         K = int(p.k)
         renderer = "Renderer" in str(p.model)
         self.diti = DiTiCont(1000, K, p.stages, p.k_per_stage)
@@ -253,7 +251,7 @@ class SelftokPipeline():
         dit_sd = sd
         if ema_decoder:   # reference :193-194: EMA copy of the DiT under 'ema_state_dict' (keys without the 'model.' prefix)
             dit_sd = {"model." + k: v for k, v in sd["ema_state_dict"].items()}       # strict contract checked above: bare MMDiT keys only
-        encoder = QformerEncoderGPU(sd, self.device, K, mode=encoder_mode or "exact")
+        encoder = QformerEncoderGPU(sd, self.device, K, mode=encoder_mode or "exact", pre_norm=pre_norm)
         dit = MMDiTGPU(dit_sd, self.device, K, renderer=renderer)
         dit.set_gemm(gemm or DEFAULT_GEMM)
         self.model = _Tokenizer(encoder, dit, self.diti)

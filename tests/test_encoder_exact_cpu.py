@@ -127,6 +127,21 @@ def enc_sd():
     return W.synthetic_state_dict(shapes)
 
 
+def test_pre_norm_encoder_equals_the_reference_features(enc_sd):
+    """encoder_config.pre_norm = True (models_ours.py:219-220; round 6): the reference Encoder built with the flag on (`gen_golden.py encoder_prenorm`),
+    2 of its 8 images: 0 differing bits through the exact oracle, and the flag matters (features move by 0.5)"""
+    pos = encoder_pos_embedding(512).numpy()
+    tables = EX.encoder_tables(enc_sd, 512, pos)
+    g, g64 = np.load(os.path.join(GOLD, "encoder_prenorm_b8.npz")), np.load(os.path.join(GOLD, "encode_b64.npz"))
+    x0 = torch.from_numpy(g64["x0_bf16"][2:4]).view(torch.bfloat16).float().numpy()
+    z = EX.encoder_features(enc_sd, x0, pos, tables=tables, pre_norm=True)
+    _same(z, g["z"][2:4], "pre_norm features vs the reference's")
+    assert float(np.abs(z - g64["z"][2:4]).max()) > 0.1
+    from oracle import model as OM
+    zt = OM.encoder_features(enc_sd, torch.from_numpy(x0), pre_norm=True)
+    assert float((zt - torch.from_numpy(g["z"][2:4])).abs().max()) < 2e-5
+
+
 def test_whole_encoder_equals_the_reference_features(enc_sd):
     """4 images of the reference pipeline's 16-image run and 4 of its 64-image run: 0 differing bits in the [B, 512, 16] features"""
     pos = encoder_pos_embedding(512).numpy()

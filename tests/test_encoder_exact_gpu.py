@@ -240,6 +240,32 @@ def test_features_equal_reference_16_images(encoder):
 
 
 @pytest.mark.gpu
+def test_pre_norm_features_and_ids_equal_the_reference():
+    """encoder_config.pre_norm = True (models_ours.py:219-220; no shipped config sets it; implemented in round 6): the reference Encoder built with the flag on
+    (tests/golden/encoder_prenorm_b8.npz, the first 8 latents of its 64-image run): exact mode features 0 differing bits, ids equal; fast mode within 1e-4; the
+    pipeline takes the flag from the YAML's encoder_config"""
+    from selftoktokenizer_amd.encoder import QformerEncoderGPU
+    from selftoktokenizer_amd.config import default_config
+    from selftoktokenizer_amd.pipeline import SelftokPipeline
+    g, g64 = np.load(os.path.join(GOLD, "encoder_prenorm_b8.npz")), np.load(os.path.join(GOLD, "encode_b64.npz"))
+    x0 = torch.from_numpy(g64["x0_bf16"][:8]).view(torch.bfloat16).float().cuda()
+    shapes = {k: v for k, v in W.expected_shapes(512).items() if k.startswith("encoder.")}
+    dev = torch.device("cuda", torch.cuda.current_device())
+    enc = QformerEncoderGPU(W.synthetic_state_dict(shapes), dev, 512, mode="exact", pre_norm=True)
+    z = enc.features(x0)
+    _same(z, g["z"], "pre_norm features vs the reference's")
+    assert np.array_equal(enc(x0)[1].cpu().numpy(), g["ids"].astype(np.int64))
+    assert float((z.cpu() - torch.from_numpy(g64["z"][:8])).abs().max()) > 0.1                     # the flag matters
+    fast = QformerEncoderGPU(W.synthetic_state_dict(shapes), dev, 512, mode="fast", pre_norm=True)
+    assert float((fast.features(x0).cpu() - torch.from_numpy(g["z"])).abs().max()) < 1e-4
+    cfg = default_config(512)
+    cfg.tokenizer.params.encoder_config.pre_norm = True
+    pipe = SelftokPipeline(cfg, None, None, device="cuda", state_dict=W.synthetic_state_dict(W.expected_shapes(512), device="cuda"),
+                           vae_state_dict=W.synthetic_vae_state_dict(device="cuda"), verbose=False)
+    assert pipe.model.encoder.pre_norm and np.array_equal(pipe.model.encoder(x0[:2])[1].cpu().numpy(), g["ids"][:2].astype(np.int64))
+
+
+@pytest.mark.gpu
 def test_features_and_ids_equal_reference_64_images_and_batch_invariance(encoder):
     """BASELINE configs[1]'s batch: the reference's `encoding` on 64 images in ONE batch (tests/golden/encode_b64.npz): features bit-equal,
     ids 32768 / 32768; the same 64 latents as 4 x 16, 8 x 8 and 64 x 1 give IDENTICAL features (every kernel is row-independent)"""

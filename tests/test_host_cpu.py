@@ -273,7 +273,8 @@ def test_unsupported_config_knobs_are_refused_not_ignored():
     before touching a GPU (cut_of_k < 1 cannot even run through the reference's own SelftokPipeline: p_sample_loop concatenates a
     super_mask the pipeline never passes, rectified_flow.py:216-222).  parameterization 'x0' IS implemented since round 3."""
     src = open(os.path.join(ROOT, "selftoktokenizer_amd", "pipeline.py")).read()
-    assert "cut_of_k < 1" in src and src.count("raise NotImplementedError") >= 3 and "encoder_config.pre_norm = True" in src
+    assert "cut_of_k < 1" in src and src.count("raise NotImplementedError") >= 3
+    assert "pre_norm=pre_norm" in src            # encoder_config.pre_norm is implemented since round 6 (tests/test_encoder_exact_*: the reference built with the flag on)
     from selftoktokenizer_amd.pipeline import _Flow
     assert _Flow(50, 1.0, "cpu", "x0").parameterization == "x0" and _Flow(50, 1.0, "cpu").parameterization == "velocity"
     with pytest.raises(ValueError):

@@ -38,15 +38,17 @@ def main():
         b = torch.randn(N, device=dev, generator=g)
         res = torch.randn(M, N, device=dev, generator=g)
         gate = torch.randn(250, N, device=dev, generator=g)
-        ref = ops.ex_linear(x, w, b)
+        ref = ops.ex_linear(x, w, b, kernel="xe")
         nblk = (K // 32 + 11) // 12
         for split in (0, nblk):
             got = ops.linear_f32(x, w, b, mkl_order=True, split=split)
             assert torch.equal(got, ref), (name, "mkl", split, float((got - ref).abs().max()))
-        ref2 = ops.ex_linear(x, w, b, res=res, gate=gate, gate_mod=250, bias_last=True, gelu=(name == "fc1"))
-        got2 = ops.linear_f32(x, w, b, mkl_order=True, res=res, gate=gate, gate_mod=250, bias_last=True, gelu=(name == "fc1"), split=nblk)
+        ref2 = ops.ex_linear(x, w, b, res=res, gate=gate, gate_mod=250, bias_last=True, kernel="xe")
+        got2 = ops.linear_f32(x, w, b, mkl_order=True, res=res, gate=gate, gate_mod=250, bias_last=True, split=nblk)
         assert torch.equal(got2, ref2), (name, "mkl epilogue")
-        ref3 = ops.ex_linear(x, w, b, res=res, gate=gate[:4], gate_mod=-250)
+        if name == "fc1":                   # GELU: a second launch over out (contiguous out, no res / gate)
+            assert torch.equal(ops.linear_f32(x, w, b, mkl_order=True, gelu=True, split=nblk), ops.ex_linear(x, w, b, gelu=True, kernel="xe")), (name, "mkl + GELU")
+        ref3 = ops.ex_linear(x, w, b, res=res, gate=gate[:4], gate_mod=-250, kernel="xe")
         got3 = ops.linear_f32(x, w, b, mkl_order=True, res=res, gate=gate[:4], gate_mod=-250)
         assert torch.equal(got3, ref3), (name, "mkl per-sample gate")
         r64 = x.double() @ w.double().t() + b.double()

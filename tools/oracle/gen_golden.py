@@ -168,6 +168,34 @@ def stage_encoder():
                         outs_q=outs_q.numpy(), gap=gap.numpy())
 
 
+def stage_encoder_prenorm(B=8):
+    """encoder_config.pre_norm = True (models_ours.py:219-220: `outs = self.final_layer_norm(outs)` before the quantizer; no shipped config sets it --
+    VERDICT r5 "missing" item 4): the reference Encoder built with the flag on, on the first B latents of its own 64-image run (encode_b64.npz)."""
+    cfg = H.load_cfg(CFG_256)
+    cfg.tokenizer.params.encoder_config.pre_norm = True
+    model, _ = H.build_tokenizer(cfg)
+    assert model.encoder.pre_norm is True
+    sd = {k: v for k, v in model.state_dict().items()}
+    g = np.load(os.path.join(GOLD, "encode_b64.npz"))
+    x0 = torch.from_numpy(g["x0_bf16"][:B]).view(torch.bfloat16).float()
+    cap = {}
+    hk = model.encoder.quantizer.project_in.register_forward_hook(lambda m, i, o: cap.__setitem__("z", o.detach().clone()))
+    with torch.no_grad():
+        outs_q, ids = model.encoder(x0, d=None)
+    hk.remove()
+    z = cap["z"]
+    z_o = OM.encoder_features(sd, x0, pre_norm=True)
+    sys.path.insert(0, "/root/repo")
+    from oracle import encoder_exact as EX
+    from selftoktokenizer_amd.encoder import encoder_pos_embedding
+    z_x = EX.encoder_features({k: v for k, v in sd.items() if k.startswith("encoder.")}, x0.numpy(), encoder_pos_embedding(512).numpy(), pre_norm=True)
+    off = float((torch.from_numpy(g["z"][:B]) - z).abs().max())
+    report("encoder_prenorm", images=B, z_maxdiff_torch_oracle=maxdiff(z_o, z), z_bits_differing_exact_oracle=int((z_x.view(np.uint32) != z.numpy().view(np.uint32)).sum()),
+           ids_match_exact_oracle=float((OM.vq_ids(sd, torch.from_numpy(z_x)) == ids).float().mean()), z_absmax=float(z.abs().max()),
+           z_maxdiff_to_pre_norm_off=off, ids_differing_from_pre_norm_off=int((ids.numpy().astype(np.int16) != g["tokens"][:B]).sum()))
+    np.savez_compressed(os.path.join(GOLD, "encoder_prenorm_b8.npz"), z=z.numpy(), ids=ids.numpy().astype(np.int16))
+
+
 def stage_dit():
     cfg, model, sd = tokenizer(CFG_256)
     ids = torch.from_numpy(synth.synthetic_token_ids(1))
@@ -1100,7 +1128,7 @@ def stage_rmsnorm_rotary():
     report("rmsnorm_rotary", arrays=sorted(out), rms_absmax=float(np.abs(out["rms_affine"]).max()), rot_absmax=float(np.abs(out["rot_full"]).max()))
 
 
-STAGES = dict(pipeline64=stage_pipeline64, k1024_pipe16=stage_k1024_pipe16, renderer16=stage_renderer16, res128=lambda: stage_res(128), res320=lambda: stage_res(320), k1024_16=stage_k1024_16, cfg16=stage_cfg16, dit4=stage_dit4, config=stage_config, decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
+STAGES = dict(encoder_prenorm=stage_encoder_prenorm, pipeline64=stage_pipeline64, k1024_pipe16=stage_k1024_pipe16, renderer16=stage_renderer16, res128=lambda: stage_res(128), res320=lambda: stage_res(320), k1024_16=stage_k1024_16, cfg16=stage_cfg16, dit4=stage_dit4, config=stage_config, decode16=stage_decode16, encode64=stage_encode64, vq_entropy=stage_vq_entropy, rmsnorm_rotary=stage_rmsnorm_rotary, sampler_options=stage_sampler_options, keys=stage_keys, vq=stage_vq, schedule=stage_schedule, encoder=stage_encoder, dit=stage_dit,
               vae=stage_vae, pipeline=stage_pipeline, pipeline16=stage_pipeline16, renderer=stage_renderer, cfg=stage_cfg, k1024=stage_k1024, vqtrain=stage_vqtrain)
 
 if __name__ == "__main__":
