@@ -655,6 +655,9 @@ def token_match(pipe, images, tokens_gpu, sd_gpu, vsd_gpu, K, n_check=2, first_i
                     "gap = oracle top-1 minus top-2 cosine score of each mismatching token"}
 
 
+T_PROCESS_START = time.perf_counter()
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
@@ -838,27 +841,37 @@ def main(argv=None):
                         "-- final latents and pixels bit-equal to the reference pipeline's (parity_16.exact_mode, parity_64.exact)")
     if args.decode_steps is not None and not renderer:
         line["config"]["INVALID"] = "decode loop truncated with --decode-steps (debug run)"
+    legs = {"timed_region": round(elapsed * (args.steps + args.warmup) / max(args.steps, 1), 1),
+            "other_gemm_steps": round(other["ms_per_step"] * (other["steps"] + other["warmup"]) / 1e3, 1) if other else 0.0}        # seconds each part of this run took (the run's own wall clock, rank 0)
+
+    def leg(name, fn):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize(); legs[name] = round(time.perf_counter() - t0, 1)
+        return out
     if not args.no_kernel_roofs and not renderer:
-        line["roofline_kernels"] = kernel_roofs(pipe, B, K, pipe.k_table)
+        line["roofline_kernels"] = leg("roofline_kernels", lambda: kernel_roofs(pipe, B, K, pipe.k_table))
     if not args.no_token_check:
-        line["token_match"] = token_match(pipe, images, last["tokens"], sd, vsd, K, first_index=rank * B)
+        line["token_match"] = leg("token_match", lambda: token_match(pipe, images, last["tokens"], sd, vsd, K, first_index=rank * B))
         if K == 512 and os.path.exists(GOLD16) and not args.no_parity16:
-            line["parity_16"] = parity_16(pipe, exact_leg=not args.no_exact)
+            line["parity_16"] = leg("parity_16", lambda: parity_16(pipe, exact_leg=not args.no_exact))
         if K == 512 and not renderer and all(os.path.exists(f) for f in GOLD64) and not args.no_parity64 and pipe.vae.mode in ("exact", "parity"):
-            line["parity_64"] = parity_64(pipe)
+            line["parity_64"] = leg("parity_64", lambda: parity_64(pipe))
     if pending_exact:
-        exact = time_exact("after the exact-mode parity legs of this run (kernels loaded, tables built)" if ("parity_64" in line or "parity_16" in line) else
-                           "first exact-mode call of the process")
+        exact = leg("exact_step", lambda: time_exact("after the exact-mode parity legs of this run (kernels loaded, tables built)" if ("parity_64" in line or "parity_16" in line) else
+                           "first exact-mode call of the process"))
         if exact is not None:
             line.setdefault("gemm_modes", {gemm_main: {"value": line["value"], "ms_per_step": line["ms_per_step"]}})["exact"] = dict(
                 exact, note="the parity mode: every Linear / LayerNorm / GELU / SiLU / attention of the MMDiT in the summation order torch-CPU executes for the reference "
                             "(csrc/gemm_fp32.hip + csrc/encoder_exact.hip; MKL's K-blocking on chained fp32 MFMAs, the joint attention fused on the full masked key sequence) "
                             "-- final latents and pixels bit-equal to the reference pipeline's (parity_16.exact_mode, parity_64.exact)")
     if args.latency and not renderer:
-        line["latency_b1"] = latency_b1(pipe)
+        line["latency_b1"] = leg("latency_b1", lambda: latency_b1(pipe))
     if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, K)
+        line["cpu_baseline"] = leg("cpu_baseline", lambda: cpu_baseline(sd, vsd, cfg, K))
         line["cpu_baseline_reference_survey"] = REFERENCE_SURVEY_BASELINE
+    legs["process_so_far"] = round(time.perf_counter() - T_PROCESS_START, 1)
+    line["leg_seconds"] = legs
     print(json.dumps(line), flush=True)
     D.shutdown()
 

@@ -397,3 +397,30 @@ def test_default_config_equals_the_reference_yamls():
         assert absent == ([] if not rnd else ["tokenizer.params.context_see_xt"])
     assert default_config(512, renderer=True).tokenizer.params.context_see_xt is False
     assert gold["k512"]["tokenizer"]["params"]["decoder_config"]["time_adaln"] == "pos_emb" and gold["k512"]["tokenizer"]["params"]["k"] == 512
+
+
+def test_driver_scripts_have_no_undefined_names():
+    """bench.py cannot run without a GPU, so a misspelt or misplaced global would only show at the round-end run (it did once, round 6): every name the driver's
+    entry scripts and the package modules LOAD must be bound somewhere in the same file (imports, definitions, assignments, arguments) or be a builtin"""
+    import ast
+    import builtins
+    import glob
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")] + sorted(glob.glob(os.path.join(ROOT, "selftoktokenizer_amd", "*.py")))
+    for path in files:
+        tree = ast.parse(open(path).read())
+        bound = set(dir(builtins)) | {"__file__", "__name__", "__doc__"}
+        for n in ast.walk(tree):
+            if isinstance(n, (ast.FunctionDef, ast.ClassDef, ast.AsyncFunctionDef)):
+                bound.add(n.name)
+            elif isinstance(n, ast.Import):
+                bound.update((a.asname or a.name).split(".")[0] for a in n.names)
+            elif isinstance(n, ast.ImportFrom):
+                bound.update(a.asname or a.name for a in n.names)
+            elif isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+                bound.add(n.id)
+            elif isinstance(n, ast.arg):
+                bound.add(n.arg)
+            elif isinstance(n, ast.ExceptHandler) and n.name:
+                bound.add(n.name)
+        loose = sorted({n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in bound})
+        assert not loose, f"{os.path.relpath(path, ROOT)}: names never bound in the file: {loose}"
