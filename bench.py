@@ -125,7 +125,7 @@ def host_cores() -> int:
 def cpu_baseline(sd_gpu, vsd_gpu, cfg, K):
     """oracle/ on the host cores.  Headline: B=1, full encode (VAE-enc + Q-Former + VQ), 2 of the 50 decode steps (every
     step has identical FLOPs up to the shrinking context, extrapolated x25), full VAE decode.  Breadth:
-    encode at B=8, the VQ nearest-code lookup alone at N = 512 and 32768 rows."""
+    encode at B=8, the VQ nearest-code lookup alone on one thread (N = 512, 8192) and on all threads (N = B K of configs[1..3]).  About 27 s of CPU work."""
     import torch
     from oracle import clib, model as OM, schedule as OS
     from selftoktokenizer_amd import synth
@@ -150,12 +150,10 @@ def cpu_baseline(sd_gpu, vsd_gpu, cfg, K):
         t0 = time.perf_counter()
         OM.pipeline_encode(sd, vsd, synth.synthetic_images(8), enc_tables)
         t_enc8 = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        OM.pipeline_encode(sd, vsd, synth.synthetic_images(64), enc_tables)            # BASELINE configs[1]'s batch, encode only
-        t_enc64 = time.perf_counter() - t0
+        # (B = 64, configs[1]'s batch, was timed here through round 6's first runs: 1.691 images/s against 1.689 at B = 8 -- 38 s of a 79 s leg for the same figure; dropped)
         cb = sd["encoder.quantizer._codebook.embed"][0].numpy()
         vq, vq_mt = {}, {}
-        for n in (512, 32768):
+        for n in (512, 8192):                                                          # one thread: 1730 / 1756 rows/s at N = 512 / 32768 (round 6): the rate does not depend on N
             z = synth.synthetic_vq_rows(n, seed=0xBE0C).numpy()
             t0 = time.perf_counter()
             clib.vq_encode(z, cb)
@@ -192,7 +190,7 @@ def cpu_baseline(sd_gpu, vsd_gpu, cfg, K):
             "sample": f"B=1 256x256 K={K}: full encode {t_enc:.2f}s + 2 of 50 decode steps {t_2:.2f}s (x25 extrapolated) "
                       f"+ VAE decode {t_vd:.2f}s on {torch.get_num_threads()} host threads; oracle/ = lean restatement "
                       "(no redundant encoder passes / table recomputes of the reference)",
-            "encode_images_per_s": {"B1": round(1.0 / t_enc, 3), "B8": round(8.0 / t_enc8, 3), "B64": round(64.0 / t_enc64, 3)},
+            "encode_images_per_s": {"B1": round(1.0 / t_enc, 3), "B8": round(8.0 / t_enc8, 3)},
             "vq_lookup_scalar_C_1_thread": vq, "vq_lookup_scalar_C_all_threads": vq_mt, "twin": twin,
             "kinds": "every figure here is the build's own CPU restatement (oracle/: torch-CPU GEMMs / convolutions + oracle/libselftok_oracle.so for the "
                      "VQ lookup) on this box's host cores -- 'port'; the reference itself was timed only in the build container (cpu_baseline_reference_survey)"}
