@@ -796,6 +796,8 @@ def main(argv=None):
                       "on chained fp32 MFMAs): ids, latents and pixels bit-equal to the reference's",
              "f16x2": "fp32 Q-Former/VQ/MMDiT with the MMDiT block Linears and joint attention as f16x2-split products on the f16 matrix cores "
                       "(fp32-equivalent: error vs fp64 below the fp32 kernels', tests/test_gemm_gpu.py, test_kernels_gpu.py), bf16 SD3-VAE"}
+    from selftoktokenizer_amd import gemm_tune as _gt
+    gemm_tune_cuts = dict(_gt.LAST_CUTS)
     line = {
         "metric": "images/sec encode+decode, 256x256 %d-token" % K, "value": round(world * B * args.steps / elapsed, 4),
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -808,7 +810,7 @@ def main(argv=None):
                    "encoder": pipe.model.encoder.mode,
                    "tune_gemm": bool(args.tune_gemm), "tune_gemm_note": "opt-in extension of the pipeline (default off there): hipBLASLt's kernel per Linear shape family chosen by a "
                                                                         "~4 s measurement before the warm-up; --tune-gemm 0 measures hipBLASLt's own choice",
-                   "fp32_linear_kernels": (None if not pipe.gemm_tune_report else {f"{n}x{k}": {"kernel": b or "hipBLASLt default", "ms_default": t0, "ms_chosen": t1}
+                   "fp32_linear_kernels": (None if not pipe.gemm_tune_report else {f"{n}x{k}": {"kernel": b or "hipBLASLt default", "ms_default": t0, "ms_chosen": t1, "rows_up_to_this_keep_the_default": gemm_tune_cuts.get((n, k), 0)}
                                                                                        for (n, k), (b, t0, t1) in pipe.gemm_tune_report.items()}),
                    "parallelism": "batch-shard x%d" % world,
                    "api": "pipe.encoding(images) -> id all-gather -> pipe.decoding(ids.cpu().numpy()) (noise from the CPU generator, as the reference)",

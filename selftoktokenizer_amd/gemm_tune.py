@@ -10,7 +10,8 @@ decode has 50 distinct context lengths -- 204 shapes, half an hour -- so it is n
   * at the first decode of a batch size, every candidate (and the default) is timed on two representative row counts of each of the four
     (N, K) families -- a probe is a TunableOp results file that maps a not-otherwise-used row count to the candidate, read back with
     tuning disabled, two passes, the faster one counts -- about 4 s in total;
-  * the winner of each family is written for ALL row counts of the step (TunableOp file, read back); a family whose default wins gets no
+  * the winner of each family is written for the row counts of the step (TunableOp file, read back) -- except the small ones at which it loses to the default
+    (three extra probes at the low end of the row list, round 6: a kernel chosen at 16384 rows can lose 3x at 1280); a family whose default wins gets no
     entry.  Nothing here can be slower than the default by more than the timing noise.
 
 The candidate names are solution indices of ONE hipBLASLt build (`FOUND_WITH`).  On any other build an index may not exist -- TunableOp
@@ -43,6 +44,7 @@ _H = 1536                                                                    # w
 FAMILIES = ((3 * _H, _H), (_H, _H), (4 * _H, _H), (_H, 4 * _H))              # (N, K) of qkv, proj / out, fc1, fc2
 
 _done: Dict[Tuple[int, Tuple[int, ...]], Dict] = {}
+LAST_CUTS: Dict[Tuple[int, int], int] = {}          # (N, K) -> row counts up to this one were left on hipBLASLt's own choice by the last autotune (0: none)
 
 
 def _key(N: int, M: int, K: int) -> str:
@@ -174,8 +176,34 @@ def autotune_linears(row_counts: Iterable[int], device: torch.device, reps: Opti
             if best is not None and times[best] > 0.99 * times[None]:          # below the timing noise: keep the default
                 best = None
             report[(N, K)] = (best, round(times[None], 4), round(times[best], 4))
+            cut = 0
+            if best is not None and len(rows) > 8:
+                # the winner was chosen on the median and the largest row count; a 50-step decode also issues a few SMALL ones (the last steps' context: B (k + 1) rows,
+                # k < 64), where a kernel picked for 16384 rows can lose 3x to the library's own small-M choice (round 6: proj at 1280 rows 175 vs 60 us).  Three probes
+                # at the low end: rows up to the largest probe the winner loses at keep the default.
+                for Mq in sorted({rows[0], rows[len(rows) // 8], rows[len(rows) // 4]}):
+                    if Mq >= reps[0]:
+                        break
+                    free = [m for m in range(Mq + 1, Mq + 9) if m not in rows]           # two row counts next to Mq that no real call uses: their keys are ours alone
+                    if len(free) < 2:
+                        continue
+                    Md, Mb = free[0], free[-1]
+                    buf = torch.randn(Mb, K, device=device)
+                    try:
+                        path = os.path.join(td, f"probe{probe_id}.csv")
+                        probe_id += 1
+                        _write(path, [(_key(N, Mb, K), best)])
+                        tun.read_file(path)
+                        t_def = min(_time(lambda: F.linear(buf[:Md], w, bias)) for _ in range(2))
+                        t_best = min(_time(lambda: F.linear(buf[:Mb], w, bias)) for _ in range(2))
+                        if t_best > t_def:
+                            cut = Mq
+                    except Exception:                   # a probe must never take the tuning down: leave the small rows on the default
+                        cut = max(cut, Mq)
+                    del buf
+            LAST_CUTS[(N, K)] = cut
             if best is not None:
-                final += [(_key(N, M, K), best) for M in rows]
+                final += [(_key(N, M, K), best) for M in rows if M > cut]
             del w, bias
         if final:
             path = os.path.join(td, "selftok_linears.csv")

@@ -273,3 +273,30 @@ def test_gemm_tune_installs_measured_kernels_and_keeps_the_numbers(capsys):
     print(f"max abs err vs fp64: default kernel {e0:.2e}, installed kernel {e1:.2e}")
     assert e1 <= 2.0 * e0 + 1e-6
     assert G.autotune_linears(rows, torch.device("cuda"), reps=reps) is rep          # cached per (device, row counts)
+
+
+@pytest.mark.gpu
+def test_gemm_tune_leaves_small_row_counts_on_the_default_where_the_winner_loses():
+    """round 6: the family winner is chosen at 16384 rows and the median context length; the last steps of a decode issue Linears of ~1300 rows, where such a kernel lost 3x
+    to hipBLASLt's own small-M choice (profiles/r6_sweep_fp32_linear_vs_sg.txt: proj 175 vs 60 us).  Three probes at the low end of the row list now keep those rows on
+    the default: inside an enabled() block the smallest row count of the step must not run much slower than outside"""
+    from selftoktokenizer_amd import gemm_tune as G
+    from selftoktokenizer_amd.config import default_config
+    from selftoktokenizer_amd.schedule import DiTiCont
+    if not G.validators_match()[0]:
+        pytest.skip("another hipBLASLt build than the candidates': autotune is a no-op")
+    p = default_config(512).tokenizer.params
+    import numpy as np
+    k_table = DiTiCont(1000, 512, p.stages, p.k_per_stage).to_indices(np.linspace(999, 0, 50).astype(np.int64))
+    rows, reps = G.step_row_counts(64, k_table, 256)
+    rep = G.autotune_linears(rows, torch.device("cuda"), reps=reps)
+    assert rep is not None and set(G.LAST_CUTS) >= set(G.FAMILIES)
+    M = rows[0]
+    for (N, K), (best, _, _) in rep.items():
+        assert 0 <= G.LAST_CUTS[(N, K)] < reps[0]
+        a, w, b = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * 0.03, torch.randn(N, device="cuda")
+        t_out = min(G._time(lambda: torch.nn.functional.linear(a, w, b)) for _ in range(3))
+        with G.enabled():
+            t_in = min(G._time(lambda: torch.nn.functional.linear(a, w, b)) for _ in range(3))
+        print(f"({N}, {K}) winner {best or 'default'}, rows <= {G.LAST_CUTS[(N, K)]} keep the default; {M} rows: {1e3 * t_out:.1f} us default, {1e3 * t_in:.1f} us inside enabled()")
+        assert t_in <= 1.5 * t_out + 0.01, ((N, K), best, t_in, t_out)
