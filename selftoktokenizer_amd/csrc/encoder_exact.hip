@@ -465,9 +465,53 @@ __global__ __launch_bounds__(256) void xe_ln_kernel(const float* x, long ldx, fl
     XMom stk[MAXD]; int m0s[MAXD];
 #pragma unroll
     for (int v = 0; v < MAXD; ++v) { stk[v] = XMom{0.f, 0.f}; m0s[v] = 0; }
+    // whole chunks (N % 128 == 0: every shape of the models): the 16 elements of a chunk (and, fused, the 16 of lin / bias / gate) are loaded TOGETHER and one chunk AHEAD
+    // of the Welford chain that consumes them -- one element at a time made every step of the chain wait for its own loads (round 6, fused: 284 -> 218 us at 22912 rows,
+    // 200 -> 135 us at 16384: profiles/r6_ex_layernorm_batched_loads.txt).  Same operations in the same order.
+    const bool whole = (n & 15) == 0;
+    float xs[16], vs[16];
+    auto fetch = [&](int ci) {                        // the two HBM streams; the bias row and the gate rows (one per sample) come from L1 / L2 at use
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xs[j] = xr[(ci * 16 + j) * 8 + l];
+        if (FUSE) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) vs[j] = lr[(ci * 16 + j) * 8 + l];
+        }
+    };
+    if (whole) fetch(0);
     for (int ci = 0; ci < m; ++ci) {
         const int cnt = min(16, n - ci * 16);
         XMom a{0.f, 0.f};
+        if (whole) {
+            float cur[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cur[j] = xs[j];
+            if (FUSE) {
+                float v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = vs[j];
+                if (f.bias != nullptr) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) v[j] = v[j] + f.bias[(ci * 16 + j) * 8 + l];
+                }
+                if (gr != nullptr) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) v[j] = gr[(ci * 16 + j) * 8 + l] * v[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) cur[j] = cur[j] + v[j];
+            }
+            if (ci + 1 < m) fetch(ci + 1);             // in flight while this chunk's chain runs (x_out may alias x: other columns than the stores below)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (FUSE) xor_[(ci * 16 + j) * 8 + l] = cur[j];          // read back below by the other lanes of this row's group (same wave): fenced
+                const float cj = 1.0f / (float)(j + 1);
+                const float d0 = cur[j] - a.m1;
+                a.m1 = fmaf(d0, cj, a.m1);
+                const float e0 = cur[j] - a.m1;
+                a.m2 = fmaf(d0, e0, a.m2);
+            }
+        } else
         for (int j = 0; j < cnt; ++j) {
             const float cj = 1.0f / (float)(j + 1);
             const int col = (ci * 16 + j) * 8 + l;

@@ -9,6 +9,7 @@
 //   form 4: same, AGPRs
 //   form 5: 16x16x4, 4 compute waves of 64 x 128 (32 accumulators of 4), VGPRs      (the vendor kernel's shape; k order inside a 16-k group is permuted: free order only)
 //   form 6: same, AGPRs
+//   form 15 / 16: forms 7 / 8 on a layout that makes ds_read2_b32 conflict free (DMA pieces staggered by 4 bytes, swizzle by row & 7)
 //   form 11 / 12: forms 2 / 3 fed k-ascending from ALIGNED b128 reads: lane (r, h) reads k = 8 t + 4 h .. + 3, two v_permlane32_swap pair them up
 //   form 13 / 14: forms 2 / 3 fed k-ascending by ds_read_b64 from operands stored k-interleaved (k0 k2 k1 k3 per aligned four) in memory
 //   form 9 / 10: forms 2 / 3 with lanes 32..63 reading their ds_read_b128 at +4 bytes (elements [0], [2] = k + h, k + 2 + h): k ascending at b128 cost?
@@ -35,9 +36,9 @@ __device__ __forceinline__ void dma16(const void* base, unsigned voff, unsigned 
 #define MFMA_A(op, acc, a, b) asm volatile(op " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 
 template <int FORM>
-__global__ __launch_bounds__((FORM <= 2 || FORM == 7 || FORM == 9 || FORM == 11 || FORM == 13) ? 640 : 384) void loop_kernel(float* out, const float* src, int iters, int dma)
+__global__ __launch_bounds__((FORM <= 2 || FORM == 7 || FORM == 9 || FORM == 11 || FORM == 13 || FORM == 15) ? 640 : 384) void loop_kernel(float* out, const float* src, int iters, int dma)
 {
-    constexpr int CW = (FORM <= 2 || FORM == 7 || FORM == 9 || FORM == 11 || FORM == 13) ? 8 : 4;
+    constexpr int CW = (FORM <= 2 || FORM == 7 || FORM == 9 || FORM == 11 || FORM == 13 || FORM == 15) ? 8 : 4;
     __shared__ __attribute__((aligned(1024))) char lds[STAGES * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < STAGES * STAGE / 4; i += blockDim.x) reinterpret_cast<float*>(lds)[i] = src[(i * 7 + blockIdx.x * 13) & 0xFFFFF];
@@ -235,6 +236,37 @@ __global__ __launch_bounds__((FORM <= 2 || FORM == 7 || FORM == 9 || FORM == 11 
             }
         }
         for (int k = 0; k < 8; ++k) for (int r = 0; r < 16; ++r) s += c[k][r];
+    } else if (FORM == 15 || FORM == 16) {
+        // forms 7 / 8 with a layout in which ds_read2_b32 is conflict free: the 1-KiB DMA piece that holds rows 8 p .. 8 p + 7 lands 4 (p % 4) bytes further on (M0 is a
+        // byte address) and a row's 16-byte granules are swizzled by row & 7 -- the 32 rows of a fragment then cover 8 granule positions x 4 dword residues = all 32 banks
+        constexpr int NA = 2, NB = (FORM == 15) ? 2 : 4;
+        const int r = lane & 31;
+        const int lane_off = r * 128 + ((r >> 3) & 3) * 4 + (lane >> 5) * 4;
+        const int a_row = (64 * (FORM == 15 ? (wave & 3) : wave)) * 128 + lane_off;
+        const int b_row = 32768 + (FORM == 15 ? 64 * (wave >> 2) : 0) * 128 + lane_off;
+        const int sw = (r & 7) << 4;
+        f32x16 c[NA * NB];
+#pragma unroll
+        for (int k = 0; k < NA * NB; ++k) c[k] = f32x16{0};
+        for (int it = 0; it < iters; ++it) {
+            const char* la = lds + (it % STAGES) * STAGE;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float va[NA][2], vb[NB][2];
+#pragma unroll
+                for (int f = 0; f < NA; ++f) { const float* pa = reinterpret_cast<const float*>(la + a_row + f * 4096 + ((q << 4) ^ sw)); va[f][0] = pa[0]; va[f][1] = pa[2]; }
+#pragma unroll
+                for (int f = 0; f < NB; ++f) { const float* pb = reinterpret_cast<const float*>(la + b_row + f * 4096 + ((q << 4) ^ sw)); vb[f][0] = pb[0]; vb[f][1] = pb[2]; }
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int i = 0; i < NA; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) c[NB * i + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[i][e], vb[j][e], c[NB * i + j], 0, 0, 0);
+            }
+        }
+        for (int k = 0; k < NA * NB; ++k) for (int rr = 0; rr < 16; ++rr) s += c[k][rr];
     } else if (FORM == 7) {
         // form 2 with the operands read as ds_read2_b32 (elements h and 2 + h of the 4-k group): what a k-ascending chain needs from 32x32x2
         const int a_row = (64 * (wave & 3) + (lane & 31)) * 128 + (((lane >> 1) & 7) << 4) + (lane >> 5) * 4;
@@ -381,6 +413,8 @@ int main(int argc, char** argv)
         run("6: 16x16x4,    4 waves of 64x128, AGPR acc (the vendor kernel's shape)", loop_kernel<6>, out, src, iters, dma);
         run("7: 32x32x2,    8 waves of 64x64, VGPR acc, ds_read2_b32 feed (k ascending)", loop_kernel<7>, out, src, iters, dma, 640);
         run("8: 32x32x2,    4 waves of 64x128, VGPR acc, ds_read2_b32 feed (k ascending)", loop_kernel<8>, out, src, iters, dma);
+        run("15: 32x32x2,   8 waves of 64x64, VGPR acc, ds_read2_b32 from a dword-STAGGERED layout (k ascending)", loop_kernel<15>, out, src, iters, dma, 640);
+        run("16: 32x32x2,   4 waves of 64x128, VGPR acc, ds_read2_b32 from a dword-STAGGERED layout (k ascending)", loop_kernel<16>, out, src, iters, dma);
         run("11: 32x32x2,   8 waves of 64x64, VGPR acc, b128 per 8 k + 2 permlane32_swap (k ascending)", loop_kernel<11>, out, src, iters, dma, 640);
         run("12: 32x32x2,   4 waves of 64x128, VGPR acc, b128 per 8 k + 2 permlane32_swap (k ascending)", loop_kernel<12>, out, src, iters, dma);
         run("13: 32x32x2,   8 waves of 64x64, VGPR acc, ds_read_b64 of k-interleaved operands (k ascending)", loop_kernel<13>, out, src, iters, dma, 640);
