@@ -580,6 +580,141 @@ __global__ __launch_bounds__(256) void xe_ln_kernel(const float* x, long ldx, fl
     }
 }
 
+// Wide rows (round 6): the same arithmetic with a row spread over G = chunks / 4 waves.  A chunk's Welford chain starts from zero, so the 12 chunks of a 1536-wide row
+// are independent until ATen's cascade combines them: wave g of a workgroup computes the raw moments of chunks 4 g .. 4 g + 3 for the workgroup's 8 rows (8 lanes per
+// row, as above) and leaves them in LDS; wave 0 then replays the cascade loop of xe_ln_kernel over the stored chunk moments -- the same calls with the same
+// arguments in the same order -- and publishes mean / rstd; every wave applies 1 / G of the columns.  G x the waves in flight of the 8-threads-per-row kernel
+// (whose grid is 8 waves per CU at 16384 rows).  N % 512 == 0 (whole chunks, a multiple of 4 of them), G <= 8.
+template <bool FUSE>
+__global__ __launch_bounds__(512) void xe_lnw_kernel(const float* x, long ldx, float* __restrict__ y, long ldy, const float* __restrict__ shift,
+                                                     const float* __restrict__ scale, long ldt, int T, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, long rows, int N, float eps, float* __restrict__ stats, XeLnFuse f)
+{
+    __shared__ float s_m1[8][32][8], s_m2[8][32][8];            // [row of the workgroup][chunk][lane]
+    __shared__ float s_mean[8], s_rstd[8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, rl = lane >> 3, l = lane & 7;
+    const int G = blockDim.x >> 6;
+    const long row = (long)blockIdx.x * 8 + rl;
+    const bool live = row < rows;
+    const long rowc = live ? row : rows - 1;
+    const float* xr = x + (size_t)rowc * ldx;
+    const float* lr = FUSE ? f.lin + (size_t)rowc * f.ldl : nullptr;
+    const float* gr = (FUSE && f.gate != nullptr) ? f.gate + (size_t)(f.gate_mod > 0 ? rowc % f.gate_mod : (f.gate_mod < 0 ? rowc / -f.gate_mod : rowc)) * f.ldg : nullptr;
+    float* xor_ = FUSE ? f.xo + (size_t)rowc * f.ldxo : nullptr;
+    const int n = N >> 3, m = n >> 4;                          // m = 4 G whole chunks
+    float xs[16], vs[16];
+    auto fetch = [&](int ci) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xs[j] = xr[(ci * 16 + j) * 8 + l];
+        if (FUSE) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) vs[j] = lr[(ci * 16 + j) * 8 + l];
+        }
+    };
+    fetch(4 * wave);
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const int ci = 4 * wave + cc;
+        float cur[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cur[j] = xs[j];
+        if (FUSE) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = vs[j];
+            if (f.bias != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = v[j] + f.bias[(ci * 16 + j) * 8 + l];
+            }
+            if (gr != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = gr[(ci * 16 + j) * 8 + l] * v[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cur[j] = cur[j] + v[j];
+        }
+        if (cc + 1 < 4) fetch(ci + 1);
+        XMom a{0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (FUSE && live) xor_[(ci * 16 + j) * 8 + l] = cur[j];
+            const float cj = 1.0f / (float)(j + 1);
+            const float d0 = cur[j] - a.m1;
+            a.m1 = fmaf(d0, cj, a.m1);
+            const float e0 = cur[j] - a.m1;
+            a.m2 = fmaf(d0, e0, a.m2);
+        }
+        s_m1[rl][ci][l] = a.m1; s_m2[rl][ci][l] = a.m2;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int depth = 0;
+        while ((1 << depth) < m) ++depth;
+        constexpr int MAXD = 6;
+        XMom stk[MAXD]; int m0s[MAXD];
+#pragma unroll
+        for (int v = 0; v < MAXD; ++v) { stk[v] = XMom{0.f, 0.f}; m0s[v] = 0; }
+        for (int ci = 0; ci < m; ++ci) {                        // xe_ln_kernel's loop with the chunk moments read instead of computed
+            const XMom a{s_m1[rl][ci][l], s_m2[rl][ci][l]};
+            xe_add_moments_vec(16, a, m0s[0], stk[0]);
+            int mask = ci + 1;
+            bool go = true;
+#pragma unroll
+            for (int j = 1; j < MAXD; ++j) {
+                go = go && j < depth && (mask & 1) == 0;
+                if (go) {
+                    xe_add_moments_vec(m0s[j - 1], stk[j - 1], m0s[j], stk[j]);
+                    m0s[j - 1] = 0; stk[j - 1] = XMom{0.f, 0.f};
+                    mask >>= 1;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 1; j < MAXD; ++j)
+            if (j < depth) xe_add_moments_vec(m0s[j], stk[j], m0s[0], stk[0]);
+        float m1 = 0.f, m2 = 0.f;
+        int m0 = 0;
+        const int m0_add = m0s[0];
+        for (int k = 0; k < 8; ++k) {
+            const float a1 = __shfl(stk[0].m1, (lane & ~7) + k, WAVE), a2 = __shfl(stk[0].m2, (lane & ~7) + k, WAVE);
+            const int nn = m0 + m0_add;
+            const float c = nn == 0 ? 0.f : (float)m0_add / (float)nn;
+            const float delta = a1 - m1;
+            m1 = fmaf(c, delta, m1);
+            m2 = m2 + fmaf(delta * delta * c, (float)m0, a2);
+            m0 = nn;
+        }
+        const float var = m2 / (float)N;
+        const float rstd = 1.0f / sqrtf(fmaxf(var, 0.f) + eps);
+        if (l == 0) {
+            s_mean[rl] = m1; s_rstd[rl] = rstd;
+            if (stats != nullptr && live) { stats[2 * row] = m1; stats[2 * row + 1] = rstd; }
+        }
+    }
+    if (FUSE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (FUSE) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); xr = xor_; }
+    if (!live) return;
+    const float nmean = -s_mean[rl], rstd = s_rstd[rl];
+    float* yr = y + (size_t)row * ldy;
+    const long tok = T > 0 ? row % T : row / -T;
+    const float* sh = shift != nullptr ? shift + (size_t)tok * ldt : nullptr;
+    const float* sc = scale != nullptr ? scale + (size_t)tok * ldt : nullptr;
+    const int per = N / G;                                       // this wave's columns
+    for (int e0 = wave * per + l * 4; e0 < (wave + 1) * per; e0 += 32) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + e0);
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = (o[e] + nmean) * rstd;
+            float r = fmaf(t, gamma != nullptr ? gamma[e0 + e] : 1.0f, beta != nullptr ? beta[e0 + e] : 0.0f);
+            if (sc != nullptr) r = r * (1.0f + sc[e0 + e]) + sh[e0 + e];
+            o[e] = r;
+        }
+        *reinterpret_cast<float4*>(yr + e0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // attention row pass (fp32 flash kernel of ATen)
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -910,6 +1045,11 @@ int selftok_ex_layernorm_mod_f32(const float* x, long ldx, float* out, long ldo,
     if (!x || !out || rows < 0 || N <= 0 || N % 8 || N > 4096 || ldx % 4 || ldo % 4 || ((shift == nullptr) != (scale == nullptr)) || (scale && T == 0)) {
         set_last_error("ex_layernorm: need N % 8 == 0, N <= 4096, 16-byte aligned rows, shift and scale together"); return SELFTOK_EINVAL;
     }
+    if (N % 512 == 0 && N >= 1024 && rows >= 2048) {           // wide rows of a large batch: N / 512 waves per row (the MMDiT's 1536)
+        hipLaunchKernelGGL(xe_lnw_kernel<false>, dim3((unsigned)((rows + 7) / 8)), dim3(64 * (N / 512)), 0, stream, x, ldx, out, ldo, shift, scale, ldt, T != 0 ? T : 1, gamma, beta,
+                           rows, N, eps, stats, XeLnFuse{});
+        return check_launch("xe_lnw_kernel");
+    }
     const long threads = rows * 8;
     hipLaunchKernelGGL(xe_ln_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, ldx, out, ldo, shift, scale, ldt, T != 0 ? T : 1, gamma, beta,
                        rows, N, eps, stats, XeLnFuse{});
@@ -927,6 +1067,11 @@ int selftok_ex_res_layernorm_mod_f32(const float* x, long ldx, const float* lin,
     }
     const long threads = rows * 8;
     XeLnFuse f{lin, ldl, gate, ldg, gate_mod, lin_bias, x_out, ldxo};
+    if (N % 512 == 0 && N >= 1024 && rows >= 2048) {
+        hipLaunchKernelGGL(xe_lnw_kernel<true>, dim3((unsigned)((rows + 7) / 8)), dim3(64 * (N / 512)), 0, stream, x, ldx, out, ldo, shift, scale, ldt, T != 0 ? T : 1,
+                           (const float*)nullptr, (const float*)nullptr, rows, N, eps, (float*)nullptr, f);
+        return check_launch("xe_lnw_kernel<fused residual update>");
+    }
     hipLaunchKernelGGL(xe_ln_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, ldx, out, ldo, shift, scale, ldt, T != 0 ? T : 1,
                        (const float*)nullptr, (const float*)nullptr, rows, N, eps, (float*)nullptr, f);
     return check_launch("xe_ln_kernel<fused residual update>");

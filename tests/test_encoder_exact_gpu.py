@@ -145,6 +145,35 @@ def test_residual_update_fused_into_layernorm(per_sample, bias_last, with_gate):
     _same(n3, n1.cpu().numpy(), "LayerNorm(x') modulated, in place")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1536, 1024, 2048])
+def test_wide_row_layernorm_equals_the_oracle(N):
+    """round 6: rows >= 2048 of N % 512 == 0 columns run on xe_lnw_kernel (a row's chunks spread over N / 512 waves, the cascade replayed from LDS): against the CPU oracle
+    (ATen's bits) -- gamma / beta + statistics, a per-token modulation table, and the fused residual form against the separately rounded fp32 operations; a ragged last
+    workgroup (rows % 8 != 0); and the same bits as the 8-threads-per-row kernel that serves fewer rows"""
+    rows, T = 2051, 293                                        # 7 x 293 rows
+    x = _rand(0xE0 + N, (rows, N), 1.5, 0.1)
+    g, b = _rand(0xE1, (N,), 0.3, 1.0), _rand(0xE2, (N,), 0.2)
+    ref, st = EX.layernorm(x.numpy(), g.numpy(), b.numpy(), want_stats=True)
+    out, stats = ops.ex_layernorm_mod(x.cuda(), gamma=g.cuda(), beta=b.cuda(), want_stats=True)
+    _same(out, ref, f"wide-row LayerNorm N = {N}")
+    _same(stats, st, "mean / rstd")
+    _same(ops.ex_layernorm_mod(x[:1000].cuda(), gamma=g.cuda(), beta=b.cuda()), ref[:1000], "the narrow kernel on the same rows")
+    tab = _rand(0xE3, (T, 2 * N), 0.6)
+    sh, sc = tab[:, :N], tab[:, N:]
+    plain = EX.layernorm(x.numpy())
+    idx = np.arange(rows) % T
+    want = plain * (np.float32(1) + sc.numpy()[idx]) + sh.numpy()[idx]
+    tc = tab.cuda()
+    _same(ops.ex_layernorm_mod(x.cuda(), shift=tc[:, :N], scale=tc[:, N:]), want, "modulated, per-token table")
+    lin, bias, gate = _rand(0xE4, (rows, N), 1.0), _rand(0xE5, (N,), 0.2), _rand(0xE6, (T, N), 0.7)
+    x1 = x.numpy() + gate.numpy()[idx] * (lin.numpy() + bias.numpy())                      # three separately rounded fp32 operations
+    want2 = EX.layernorm(x1) * (np.float32(1) + sc.numpy()[idx]) + sh.numpy()[idx]
+    x2, n2 = ops.ex_res_layernorm_mod(x.cuda(), lin.cuda(), lin_bias=bias.cuda(), gate=gate.cuda(), gate_mod=T, shift=tc[:, :N], scale=tc[:, N:])
+    _same(x2, x1, "x' (fused residual update)")
+    _same(n2, want2, "LayerNorm(x') modulated")
+
+
 # ---- attention -------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,B,H,Tq,Tk1,Tk2,D", [("latent self-attention 4 x 16", 2, 4, 256, 256, 0, 16), ("query attention 8 x 64, 256 + 512 keys", 2, 8, 512, 256, 512, 64),
