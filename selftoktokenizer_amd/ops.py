@@ -791,15 +791,16 @@ def ex_linear(x: torch.Tensor, weight: torch.Tensor, bias=None, *, gelu: bool = 
 
 
 LINEAR_BIAS_LAST, LINEAR_MKL_ORDER = 2, 4
-_LINEAR_WS = {}          # device index -> workspace tensor of the tail split (grown on demand, reused by every call on that device's stream order)
+_LINEAR_WS = {}          # (device index, stream handle) -> workspace tensors of the tail split, largest last: grown on demand, reused by the calls of THAT stream (they are
+                         # ordered); two streams never share one (their tail rounds could overlap); outgrown tensors stay referenced (a captured hipGraph may replay on them)
 
 
 def _linear_ws(device, nbytes: int):
-    ws = _LINEAR_WS.get(device.index)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-        _LINEAR_WS[device.index] = ws
-    return ws
+    key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
+    held = _LINEAR_WS.setdefault(key, [])
+    if not held or held[-1].numel() < nbytes:
+        held.append(torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device))
+    return held[-1]
 
 
 def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias=None, *, mkl_order: bool = False, gelu: bool = False, res=None, res_mod: int = 0, gate=None,
