@@ -42,6 +42,9 @@ def stubs():
     ns16 = dict(ns)                                              # section 2.4b defines its own `linear` (the f16x2 arithmetic): a namespace of its own
     exec(_blocks(text, "### 2.4b fp32-equivalent")[0], ns16)
     ns["f16x2"] = ns16
+    nsv = dict(ns)                                               # section 2.6c (the exact VAE): its own `sdpa`; the SiLU table is made on the device the stubs run on
+    exec(_blocks(text, "### 2.6c The VAE encoder")[0].replace('device="cuda"', 'device="cpu"'), nsv)
+    ns["vae"] = nsv
     return ns
 
 
@@ -142,3 +145,32 @@ def test_joint_attention_and_f16x2_linear_stubs(stubs):
     got = f["linear"](x, packed, lin.bias.detach(), 128, False, flag)
     want = (x.double() @ lin.weight.detach().double().t() + lin.bias.detach().double()).float()
     assert int(flag.item()) == 0 and float((got - want).abs().max()) < 5e-6
+
+
+def test_exact_vae_stubs(stubs):
+    """section 2.6c: convolution (stride 1 with the ResnetBlock residual, the Downsample layer), GroupNorm + SiLU, the AttnBlock attention -- bf16 bits against oracle/vae_exact"""
+    from oracle import vae_exact as VX
+    v = stubs["vae"]
+    bf = lambda seed, shape, scale=1.0: _rand(seed, shape, scale).to(torch.bfloat16)
+    x, res = bf(40, (1, 16, 16, 128)), bf(41, (1, 16, 16, 128))
+
+    class Conv:                                                   # what the stub reads of a conv module: weight_nhwc, bias
+        def __init__(self, seed, cout, cin):
+            self.weight_nhwc, self.bias = bf(seed, (cout, 3, 3, cin), 0.03), bf(seed + 1, (cout,), 0.1)
+    c1 = Conv(42, 128, 128)
+    got = v["conv"](x, c1, residual=res)
+    want = VX.conv2d(VX.bf16_bits(x), VX.bf16_bits(c1.weight_nhwc), VX.bf16_bits(c1.bias), residual=VX.bf16_bits(res))
+    assert np.array_equal(VX.bf16_bits(got), want)
+    xd = bf(44, (1, 32, 32, 128))
+    got = v["conv"](xd, c1, stride=2)
+    want = VX.conv2d(VX.bf16_bits(xd), VX.bf16_bits(c1.weight_nhwc), VX.bf16_bits(c1.bias), stride=2, pad=0)
+    assert got.shape == (1, 16, 16, 128) and np.array_equal(VX.bf16_bits(got), want)
+    norm = torch.nn.GroupNorm(32, 128, eps=1e-6)
+    with torch.no_grad():
+        norm.weight.copy_(_rand(45, (128,), 0.3) + 1); norm.bias.copy_(_rand(46, (128,), 0.2))
+    norm = norm.to(torch.bfloat16)
+    got = v["norm_swish"](x, norm)
+    want = VX.group_norm(VX.bf16_bits(x), VX.bf16_bits(norm.weight), VX.bf16_bits(norm.bias), silu=VX.silu_table())
+    assert np.array_equal(VX.bf16_bits(got), want)
+    q, k, vv = bf(47, (1, 64, 128)), bf(48, (1, 64, 128)), bf(49, (1, 64, 128))
+    assert np.array_equal(VX.bf16_bits(v["sdpa"](q, k, vv)), VX.attention(VX.bf16_bits(q), VX.bf16_bits(k), VX.bf16_bits(vv)))
