@@ -10,7 +10,7 @@ out = torch.empty(M, N, device="cuda")
 for _ in range(5):
     F.linear(x, w, b)
 for _ in range(5):
-    ops.ex_linear(x, w, b, out=out)
+    ops.ex_linear(x, w, b, out=out, kernel="xe")
 for _ in range(5):
     ops.linear_f32(x, w, b, out=out)
 for _ in range(5):
