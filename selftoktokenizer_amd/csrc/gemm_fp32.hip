@@ -18,8 +18,8 @@
 //     conflicts in the PMC pass): no staging registers, no ds_write, no VALU in the k-loop besides the K-block fold.
 //   * workgroup = EIGHT compute waves = 256 x 128 outputs (wave: 64 x 64 = two 2-block accumulators, 64 VGPRs; two compute waves per SIMD) + TWO LOADER waves
 //     (one issues the A tile's 32 DMA pieces of a chunk, the other the B tile's 16), 32-k chunks, THREE stages of 48 KiB (144 of the CU's 160 KiB: one workgroup
-//     per CU); one barrier per chunk.  How the measurements led here (profiles/r6_sgemm_v*.txt, r6_mfma_f32_forms*.txt; the chip holds 2.39 GHz under every
-//     variant, so everything below is pipe cycles, not clock):
+//     per CU); one barrier per chunk.  How the measurements led here (profiles/r6_sgemm_v*.txt, r6_mfma_f32_forms*.txt; everything below is pipe CYCLES -- the
+//     bare MFMA loops hold 2.39 GHz, the finished kernel does not: see the note on the clock at the end of this list):
 //       - a DMA piece costs the ISSUING wave 60 - 180 cycles during which its MFMA stream pauses: with the pieces issued by the compute waves the kernel lost 6 - 8 %
 //         wherever they were placed ("no DMA" 0.88 / 0.94, "DMA issued, waits removed" = the product) -> loader waves, which never touch the matrix pipe;
 //       - ONE compute wave per SIMD pays ~6 pipe cycles for every instruction between two MFMAs (fragment reads, waits): 69.5 cycles per MFMA in the k-loop, 0.865
@@ -30,13 +30,18 @@
 //         occupancy query says.  So: one workgroup per CU, its stages deep enough (3) that the DMA round trip (~4300 cycles under load, longer than a chunk's
 //         MFMAs) is off the critical path.
 //     Prologue (first DMA round trip, 1.9 us) and epilogue (1.7 us plain) of a 176-us tile are what is left outside the loop.
+//       - THE CLOCK: per cycle this kernel equals the vendor's (PMC: matrix pipe busy 0.926 - 0.929 of GUI-active, hipBLASLt 0.925), in time it is 0.85 - 0.90 against
+//         0.92 - 0.96 -- a probe kernel beside it reads 2.14 - 2.27 GHz (beside hipBLASLt: 2.39; tools/clock_probe.py).  The K = 1 MFMA form moves its 32 accumulator
+//         registers per instruction (4x the register traffic per FLOP of the vendor's 16x16x4) and with the GEMM's DMA / L2 traffic crosses what the chip sustains at
+//         2.4 GHz; every K >= 2 form holds the clock but needs lane halves to hold ALTERNATE k, which row-major operands give only at a cost (ds_read2_b32, lane
+//         swaps, k-interleaved operands: 0.86 - 0.91 in tools/microbench/mfma_power_forms.hip against this form's 0.89 - 0.93 there).  DESIGN.md section 16.4.
 //   * XCD-aware 1-D tile order (bands of 8 row tiles: the 64 workgroups resident on an XCD cover 8 x 8 tiles = 8 A + 8 B operand tiles per chunk round).
 //   * the TAIL ROUND is split along K: the tiles left over after the last full round of 256 tiles (one per CU) are computed as S units of 1 / S of the K range each, raw
 //     partial sums to a workspace, and a small second kernel adds the planes IN ORDER and runs the epilogue.  In MKL order a unit is ONE K-block (S = the number of
 //     K-blocks), its plane the block's chain, so the result is still ((bias + c0) + c1) + ... bit for bit; in free order a unit is 1 / S of the chunks.
 //
-// Epilogue (both kernels): [+ bias last] -> [GELU(tanh), Sleef arithmetic] -> [gate * y] -> [res + y], each separately rounded (-ffp-contract=off), the
-// operation sequence of csrc/encoder_exact.hip's epilogue.
+// Epilogue (both kernels): [+ bias last] -> [gate * y] -> [res + y], each separately rounded (-ffp-contract=off), the operation sequence of csrc/encoder_exact.hip's
+// epilogue; GELU(tanh) (fc1 -> act: no res / gate there) is a second launch of the element-wise kernel over `out`, issued by the C entry.
 #include "common.h"
 #include "exact_math.h"
 #include "selftok_hip.h"
