@@ -4,8 +4,8 @@
 //
 // replaces (a) in gemm='exact' the wide Linears of the MMDiT joint blocks and of the Q-Former (mimogpt/models/selftok/sd3/mmdit.py:266-307, 413-419;
 // modules.py:186-199, 293) that xe_gemm128_kernel (csrc/encoder_exact.hip) carried at 0.76 - 0.84 of the fp32 matrix peak -- same bits: MKL sgemm's order, one
-// sequential fmaf chain per K-block of 384, out = ((bias + c0) + c1) + ... -- and (b) in gemm='fp32' the Linears for which hipBLASLt's kernels run at 0.79 - 0.90
-// of that peak (qkv, proj): there the order is free and the whole K is ONE chain per output.
+// sequential fmaf chain per K-block of 384, out = ((bias + c0) + c1) + ... -- and offers (b) a FREE-order form (flags = 0: the whole K is ONE chain per output), built as a candidate for
+// gemm='fp32' and not wired in: over the 204 Linear shapes of a B = 64 step the tuned library kernels lose to it at 7 (0.06 % of the time; profiles/r6_sweep_fp32_linear_vs_sg.txt).
 //
 // Design:
 //   * v_mfma_f32_32x32x1_2b_f32: one k per instruction and TWO 32 x 32 blocks.  A lane supplies A[row 32 h + i][k] and B[col i][k] (h = lane / 32, i = lane % 32):
