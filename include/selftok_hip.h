@@ -315,8 +315,8 @@ int selftok_vx_expf_f32(const float* x, float* y, long n, hipStream_t stream);
  * w [N][K] contiguous, N % 128 == 0, K % 32 == 0.  flags:
  *   SELFTOK_LINEAR_MKL_ORDER  the summation order of torch-CPU's MKL sgemm (K <= 384 or K >= 768: sequential fmaf chains per K-block of 384,
  *                             out = ((bias + c0) + c1) + ...): bit-identical to selftok_ex_linear_f32, the kernel of gemm='exact'.  Without it the order is
- *                             free: ONE k-ascending chain per output over the whole K (tail tiles: a few, see below), bias added last -- the kernel of gemm='fp32'
- *                             where it beats the library's.
+ *                             free: ONE k-ascending chain per output over the whole K (tail tiles: a few, see below), bias added last -- a candidate for gemm='fp32',
+ *                             not wired in (the tuned library kernels win at 197 of the step's 204 shapes).
  *   SELFTOK_LINEAR_GELU       out = GELU_tanh(out), ATen / Sleef arithmetic (as SELFTOK_EX_GELU); a second launch over `out`: needs ldo == N and no res / gate
  *                             (the Mlp's fc1 -> act, sd3/other_impls.py:82-90, has neither), SELFTOK_EINVAL otherwise
  *   SELFTOK_LINEAR_BIAS_LAST  as SELFTOK_EX_BIAS_LAST
